@@ -1,0 +1,565 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE implementation on seeded inputs.
+
+TEST INFRASTRUCTURE - runs only in the development container, where
+/root/reference is mounted.  It imports the authoritative source
+(/root/reference/vapor_vali/Simple_function.pyx, plain Python despite the suffix;
+SURVEY.md §0.2, §8c) by path, replaces its two samtools pipes with an in-memory
+world built by this repo's own generator (vapor_amd.synth), and writes inputs
+together with the reference's outputs to tests/golden/*.json.gz.
+
+Nothing from the reference is copied: fixtures hold data only (sequences made
+here, numbers the reference returned).  Re-run:  python oracle/gen_golden.py
+"""
+from __future__ import annotations
+
+import gzip
+import hashlib
+import importlib.machinery
+import importlib.util
+import io
+import json
+import math
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vapor_amd import synth  # noqa: E402
+from vapor_amd.seqio import MemorySamtools  # noqa: E402
+
+REF_SF = "/root/reference/vapor_vali/Simple_function.pyx"
+REF_CLI = "/root/reference/vapor_vali/vapor"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load_reference():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    ld = importlib.machinery.SourceFileLoader("vapor_ref_sf", REF_SF)
+    spec = importlib.util.spec_from_loader("vapor_ref_sf", ld)
+    m = importlib.util.module_from_spec(spec)
+    ld.exec_module(m)
+    return m
+
+
+class _ShimPath:
+    def __getattr__(self, k):
+        return getattr(os.path, k)
+
+    @staticmethod
+    def isfile(p):
+        return str(p).endswith(".bam") or os.path.isfile(p)
+
+
+class ShimOS:
+    """Stands in for the `os` name inside the reference module: popen answers the two
+    samtools commands from memory, everything else is the real os."""
+
+    def __init__(self, world):
+        self.be = MemorySamtools(world)
+        self.path = _ShimPath()
+        self.calls = 0
+
+    def __getattr__(self, k):
+        return getattr(os, k)
+
+    def popen(self, cmd):
+        self.calls += 1
+        f = cmd.split()
+        assert f[0] == "samtools", cmd
+        if f[1] == "faidx":
+            lines = self.be.faidx_lines(f[2], f[3])
+        elif f[1] == "view":
+            lines = self.be.view_lines(f[2], f[3])
+        else:
+            raise AssertionError(cmd)
+        return io.StringIO("".join(l + "\n" for l in lines))
+
+    def system(self, cmd):
+        if cmd.startswith("mkdir"):
+            os.makedirs(cmd.split()[-1], exist_ok=True)
+            return 0
+        raise AssertionError(cmd)
+
+
+def jsonable(x):
+    if isinstance(x, (np.floating,)):
+        return float(x)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (list, tuple)):
+        return [jsonable(i) for i in x]
+    if isinstance(x, dict):
+        return {k: jsonable(v) for k, v in x.items()}
+    if isinstance(x, float) and math.isnan(x):
+        return "nan"
+    return x
+
+
+def dump(name, obj):
+    p = os.path.join(OUT, name)
+    raw = json.dumps(jsonable(obj), separators=(",", ":")).encode()
+    with gzip.GzipFile(p, "wb", mtime=0) as f:
+        f.write(raw)
+    print("wrote %s: %d cases, %.1f KB" % (name, len(obj["cases"]) if "cases" in obj else -1,
+                                           os.path.getsize(p) / 1024))
+
+
+def hits_digest(hits):
+    a = np.asarray(hits, dtype=np.int32).reshape(-1, 2)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def call(fn, *a):
+    try:
+        return {"ok": fn(*a)}
+    except Exception as e:  # noqa: BLE001 - the reference's failure mode is part of the vector
+        return {"error": type(e).__name__}
+
+
+# ---------------------------------------------------------------------------
+def gen_kmerhits(m):
+    rng = np.random.default_rng(101)
+    cases = []
+
+    def add(name, k, s1, s2, full=None):
+        r = call(m.dotdata, k, s1, s2)
+        c = {"name": name, "k": k, "seq1": s1, "seq2": s2}
+        if "error" in r:
+            c["error"] = r["error"]
+        else:
+            h = r["ok"]
+            c["n_hits"] = len(h)
+            c["sha256"] = hits_digest(h)
+            if full or (full is None and len(h) <= 1500):
+                c["hits"] = [list(t) for t in h]
+        cases.append(c)
+
+    kat = "ACGTACGTACGTTTGACCA"
+    add("kat_self", 10, kat, kat)
+    add("empty_both", 10, "", "")
+    add("short_seq1", 10, "ACGTACG", synth.random_dna(rng, 50))
+    add("short_seq2", 10, synth.random_dna(rng, 50), "ACGTACG")
+    add("len_eq_k", 10, "ACGTTGCAAC", "ACGTTGCAAC")
+    for k in (10, 20, 30, 40):
+        a = synth.random_dna(rng, 1500)
+        r, _ = synth.mutate(rng, a[200:1300])
+        add("noisy_k%d" % k, k, r, a)
+        r2, _ = synth.mutate(rng, a[200:1300], 0.002, 0.01, 0.005)
+        add("clean_k%d" % k, k, r2, a)
+        add("revstrand_k%d" % k, k, synth.revcomp(r2), a)
+        add("self_k%d" % k, k, a[:600], a[:600])
+    # palindromes (read k-mer equal to its own reverse complement -> duplicate tuples)
+    pal = "ACGTACGTAC" + "GTACGTACGT"
+    add("palindrome_k10", 10, pal * 3, pal * 2)
+    add("palindrome_k20", 20, pal * 3, pal * 2)
+    at = "AT" * 40
+    add("at_repeat_k10", 10, at, at)
+    add("homopolymer", 10, "A" * 60, "A" * 45 + "T" * 45)
+    # case sensitivity, N, IUPAC
+    a = synth.random_dna(rng, 400)
+    low = a[:100] + a[100:220].lower() + a[220:]
+    add("lower_seq2", 10, a, low)
+    add("lower_seq1", 10, low, a)
+    add("lower_both", 10, low, low)
+    mixed = a[:150] + "".join(c.lower() if i % 3 == 0 else c for i, c in enumerate(a[150:200])) + a[200:]
+    add("mixed_case_both", 10, mixed, mixed)
+    nn = a[:120] + "N" * 25 + a[145:300] + "n" * 12 + a[312:]
+    add("N_runs_both", 10, nn, nn)
+    add("N_runs_seq2_only", 10, a, nn)
+    add("allN", 10, "N" * 30, "N" * 40)
+    iu = a[:50] + "R" + a[51:90] + "y" + a[91:130] + "SWKM" + a[134:170] + "bdhv" + a[174:]
+    add("iupac_both", 10, iu, iu)
+    add("iupac_vs_N", 10, iu, iu.replace("R", "N").replace("y", "n"))
+    add("iupac_k20", 20, iu, iu)
+    add("X_in_seq2", 10, a, a[:200] + "X" * 15 + a[215:])
+    add("X_in_seq1", 10, a[:200] + "X" * 15 + a[215:], a)
+    add("X_in_seq1_too_short", 10, "ACGXT", a)
+    add("star_in_seq1", 10, a[:30] + "*" + a[31:], a)
+    add("U_in_seq2", 10, a, a[:100] + "U" + a[101:])
+    add("lower_x_seq2", 10, a, a[:100] + "x" + a[101:])
+    # tandem repeats -> off-diagonal structure
+    unit = synth.random_dna(rng, 37)
+    rep = synth.random_dna(rng, 150) + unit * 12 + synth.random_dna(rng, 150)
+    rr, _ = synth.mutate(rng, rep)
+    add("tandem_repeat", 10, rr, rep)
+    add("tandem_repeat_self_k20", 20, rep, rep)
+    # benchmark-like shapes, digest only
+    big = synth.random_dna(rng, 20000)
+    br, _ = synth.mutate(rng, big[3000:13000])
+    add("10k_x_20k", 10, br[:10000], big, full=False)
+    add("10k_x_20k_k20", 20, br[:10000], big, full=False)
+    big2 = big[:8000] + big[8000:14000].lower() + big[14000:]
+    add("10k_x_20k_softmasked", 10, br[:10000], big2, full=False)
+    dump("kmerhits.json.gz", {"source": "dotdata() SF:545-549/951-983", "cases": cases})
+
+
+# ---------------------------------------------------------------------------
+def gen_cleaners(m):
+    """C1 / C2 / R4 on explicit hit lists, including tie and threshold edges."""
+    rng = np.random.default_rng(202)
+    cases = []
+
+    def diag(j0, i0, n, step=1):
+        return [(j0 + t * step, i0 + t * step) for t in range(n)]
+
+    def anti(j0, i0, n):
+        return [(j0 + t, i0 - t) for t in range(n)]
+
+    def add(name, hits):
+        hits = sorted(hits)
+        c = {"name": name, "hits": [list(h) for h in hits]}
+        c["c1"] = call(m.clean_dotdata_diagnal_and_anti_diagnal, list(hits))
+        d = call(m.clean_dotdata_diagnal_m1b, list(hits))
+        c["c2_diag"] = {"ok": d["ok"][0]} if "ok" in d else d
+        if "ok" in d:
+            kept = d["ok"][0]
+            left = [h for h in hits if list(h) not in kept]
+            a = call(m.clean_dotdata_anti_diagnal_m1b, left)
+            c["c2_anti_on_left"] = {"ok": a["ok"][0]} if "ok" in a else a
+            uni = kept + (a["ok"][0] if "ok" in a else [])
+            if uni:
+                c["count10"] = m.eu_dis_dots_within_10perc(uni)
+        if "ok" in c["c1"] and len(c["c1"]["ok"]) > 0 and c["c1"]["ok"] != [[], []]:
+            kept1 = c["c1"]["ok"]
+            c["meanabs"] = m.eu_dis_abs_calcu(kept1)
+            r4 = call(m.dis_to_diagnal_most_abundant_defined, [list(h) for h in kept1])
+            c["r4"] = r4
+            if "ok" in r4:
+                c["dir"] = call(m.eu_dis_dir_calcu, [[h[0] + r4["ok"], h[1]] for h in kept1])
+        cases.append(c)
+
+    add("one_diag_11", diag(5, 5, 11))
+    add("one_diag_10", diag(5, 5, 10))
+    add("diag_51", diag(0, 3, 51))
+    add("diag_50", diag(0, 3, 50))
+    add("two_diags_tie", diag(0, 0, 30) + diag(0, 200, 30))
+    add("two_diags_gap9", diag(0, 0, 30) + diag(100, 109, 30))
+    add("two_diags_gap10", diag(0, 0, 30) + diag(100, 110, 30))
+    add("diag_plus_anti", diag(0, 0, 60) + anti(100, 300, 40))
+    add("anti_only_12", anti(10, 200, 12))
+    add("anti_only_60", anti(10, 200, 60))
+    add("noise_only", [(int(a), int(b)) for a, b in rng.integers(0, 3000, size=(40, 2))])
+    add("diag_with_noise", diag(0, 0, 200) + [(int(a), int(b)) for a, b in rng.integers(0, 400, size=(60, 2))])
+    add("dup_tuples", diag(0, 0, 8) + diag(0, 0, 8))
+    add("shifted_diag_del", diag(0, 0, 150) + diag(150, 450, 150))
+    add("r4_kat", [(100 + t, 103 + t) for t in range(50)] + [(100 + t, 600 + t) for t in range(20)])
+    add("zero_j", [(0, 0), (0, 5)] + diag(1, 1, 20))
+    add("chain_gaps", [(0, 9 * t) for t in range(30)])
+    add("chain_gaps10", [(0, 10 * t) for t in range(30)])
+    for t in range(12):
+        n = int(rng.integers(30, 400))
+        base = diag(0, int(rng.integers(0, 50)), n)
+        pts = list(base)
+        for _ in range(int(rng.integers(0, 4))):
+            pts += diag(int(rng.integers(0, 300)), int(rng.integers(0, 900)), int(rng.integers(5, 70)))
+        for _ in range(int(rng.integers(0, 3))):
+            pts += anti(int(rng.integers(0, 300)), int(rng.integers(300, 900)), int(rng.integers(5, 70)))
+        pts += [(int(a), int(b)) for a, b in rng.integers(0, 900, size=(int(rng.integers(0, 80)), 2))]
+        add("random_mix_%d" % t, pts)
+    dump("cleaners.json.gz", {"source": "SF:404-448,551-591,705-733", "cases": cases})
+
+
+# ---------------------------------------------------------------------------
+def gen_scorers(m):
+    rng = np.random.default_rng(303)
+    cases = []
+
+    def add(name, ref, alt, read, miss, k):
+        x = [read, miss, name]
+        c = {"name": name, "ref": ref, "alt": alt, "read": read, "miss": miss, "k": k}
+        c["s1"] = call(m.calcu_vapor_single_read_score_abs_dis_m1b, ref, alt, x, k)
+        c["s2"] = call(m.calcu_vapor_single_read_score_within_10Perc_m1b, ref, alt, x, k)
+        c["s3"] = call(m.calcu_vapor_single_read_score_directed_dis_m1b_redefine_diagnal, ref, alt, x, k)
+        cases.append(c)
+
+    for t in range(40):
+        svt = ["DEL", "TANDUP", "INV", "INS"][t % 4]
+        span = int(rng.integers(60, 1800))
+        f = min(500, span)
+        g = synth.random_dna(rng, 2 * f + 3 * span + 400)
+        s, e = f + 100, f + 100 + span
+        refw = g[s - f:e + f]
+        if svt == "DEL":
+            altw = refw[:f] + refw[-f:]
+        elif svt == "TANDUP":
+            altw = refw[:f] + refw[f:-f] * 2 + refw[-f:]
+        elif svt == "INV":
+            altw = refw[:f] + synth.revcomp(refw[f:-f]) + refw[-f:]
+        else:
+            ins = synth.random_dna(rng, span)
+            refw = g[s - f:s + f + span]
+            altw = g[s - f:s] + ins + g[s:s + f]
+        hap = altw if (t // 4) % 2 == 0 else refw
+        wl = {"DEL": 2 * f, "TANDUP": 2 * span + 2 * f, "INV": span + 2 * f, "INS": span + 2 * f}[svt]
+        src = hap + synth.random_dna(rng, 200)
+        err = (0.01, 0.08, 0.04) if t % 5 else (0.001, 0.004, 0.002)
+        read, _ = synth.mutate(rng, src, *err)
+        miss = 0 if t % 7 else int(rng.integers(1, 40))
+        read = read[:max(wl - miss, 20)]
+        k = 10 if t % 9 else 20
+        add("%s_%d" % (svt, t), refw, altw, read, miss, k)
+    # gate/edge cases
+    g = synth.random_dna(rng, 1200)
+    add("unrelated_read", g, g[:500] + g[-500:], synth.random_dna(rng, 900), 0, 10)
+    add("perfect_diag_ref", g, g[:500] + g[-500:], g[:1000], 0, 10)
+    add("perfect_diag_alt", g, g[:500] + g[-500:], (g[:500] + g[-500:])[:990], 0, 10)
+    add("tiny_read", g, g[:500] + g[-500:], g[:25], 0, 10)
+    add("read_shorter_than_k", g, g[:500] + g[-500:], "ACGT", 0, 10)
+    add("only_ref_span", g, g[:300], g[:1100], 0, 10)
+    add("only_alt_span", g[:300], g, g[:1100], 0, 10)
+    junk = synth.random_dna(rng, 700)
+    add("ref_span_alt_short_cover", g, g[:300] + junk, g[:1100], 0, 10)
+    add("alt_span_ref_short_cover", g[:300] + junk, g, g[:1100], 0, 10)
+    add("neither_span", g[:300] + junk, g[:280] + junk[::-1], g[:1100], 0, 10)
+    low = g[:400] + g[400:800].lower() + g[800:]
+    rd, _ = synth.mutate(rng, g[:1100], 0.002, 0.01, 0.005)
+    add("softmasked_ref", low, low[:500] + low[-500:], rd, 0, 10)
+    add("softmasked_ref_read_alt", low, low[:500] + low[-500:], (g[:500] + g[-500:])[:950], 0, 10)
+    add("ref_with_N", g[:600] + "N" * 40 + g[640:], g[:500] + g[-500:], rd, 0, 10)
+    add("read_with_N", g, g[:500] + g[-500:], rd[:300] + "N" * 15 + rd[315:], 0, 10)
+    add("alt_all_X_ins", g[:1000], g[:500] + "X" * 300 + g[500:1000], rd[:1000], 0, 10)
+    add("miss_bp_large", g, g[:500] + g[-500:], rd[200:], 200, 10)
+    add("k30", g, g[:500] + g[-500:], rd, 0, 30)
+    add("k40", g, g[:500] + g[-500:], rd, 0, 40)
+    add("read_X", g, g[:500] + g[-500:], rd[:100] + "X" + rd[101:], 0, 10)
+    dump("scorers.json.gz", {"source": "SF:182-203,241-257,277-294", "cases": cases})
+
+
+# ---------------------------------------------------------------------------
+def gen_window(m):
+    rng = np.random.default_rng(404)
+    cases = []
+    trace = []
+    orig_qc = m.qual_check_repetitive_region
+    orig_xm = m.X_means_cluster_reformat
+    xm_calls = [0]
+
+    def qc(hits):
+        n = len(hits)
+        d = sum(1 for x in hits if x[0] == x[1])
+        lo = sum(1 for x in hits if x[0] > x[1])
+        trace.append([n, d, lo])
+        return orig_qc(hits)
+
+    def xm(other):
+        xm_calls[0] += 1
+        return orig_xm(other)
+
+    m.qual_check_repetitive_region = qc
+    m.X_means_cluster_reformat = xm
+
+    def add(name, seq):
+        del trace[:]
+        xm_calls[0] = 0
+        r = call(m.window_size_refine, seq)
+        c = {"name": name, "seq": seq, "qc_trace": [list(t) for t in trace], "xmeans_calls": xm_calls[0]}
+        if "error" in r:
+            c["error"] = r["error"]
+        else:
+            w, q = r["ok"]
+            c["window_size"] = w
+            c["qc"] = q
+        cases.append(c)
+
+    for n in (60, 500, 1500, 4000):
+        add("random_%d" % n, synth.random_dna(rng, n))
+    add("short", "ACGTAC")
+    add("empty", "")
+    g = synth.random_dna(rng, 900)
+    add("many_N", g[:300] + "N" * 101 + g[300:])
+    add("N_100_ok", g[:300] + "N" * 60 + "n" * 40 + g[300:])
+    add("with_X", g[:300] + "X" * 200 + g[300:])
+    add("softmasked", g[:300] + g[300:600].lower() + g[600:])
+    add("all_lower", g.lower())
+    for unit_len, copies in ((37, 12), (120, 5), (300, 3), (15, 40), (500, 2)):
+        unit = synth.random_dna(rng, unit_len)
+        add("tandem_%dx%d" % (unit_len, copies),
+            synth.random_dna(rng, 200) + unit * copies + synth.random_dna(rng, 200))
+    unit = synth.random_dna(rng, 200)
+    add("inverted_repeat", synth.random_dna(rng, 200) + unit + synth.random_dna(rng, 100) + synth.revcomp(unit) + synth.random_dna(rng, 200))
+    add("homopolymer", "A" * 300)
+    add("dinuc", "AC" * 200)
+    m.qual_check_repetitive_region = orig_qc
+    m.X_means_cluster_reformat = orig_xm
+    dump("window.json.gz", {"source": "window_size_refine SF:2030-2046, qual_check SF:1154-1171",
+                            "note": "cases with xmeans_calls>0 depend on unseeded KMeans (SURVEY §8a-Q): "
+                                    "only qc_trace is pinned for them", "cases": cases})
+
+
+# ---------------------------------------------------------------------------
+def gen_genotype(m):
+    rng = np.random.default_rng(505)
+    cases = []
+
+    def add(scores):
+        r = call(m.result_organize_ins, ["key", list(scores)])
+        c = {"scores": list(scores), "organize": r}
+        if "ok" in r and "NA" not in r["ok"]:
+            c["gt"] = call(m.gt_estimate_log_likelihood, r["ok"])
+        cases.append(c)
+
+    add([])
+    add([0.5, 0.4, -0.3, -1.0])
+    add([0.5] * 10)
+    add([0.004, -0.2, -0.3, -0.4, -0.5, -0.6])
+    add([0.3, -0.2, -0.3, -0.4, -0.5, -0.6, -0.7, -0.8])
+    add([0.0])
+    add([-0.0, 1e-9])
+    add([0.005, 0.015, 0.025, -0.005, 0.125, 0.675])
+    for n in range(1, 21):
+        for l in sorted({0, 1, n // 4, n // 2, (3 * n) // 4, n - 1, n}):
+            if 0 <= l <= n:
+                s = [float(rng.uniform(0.05, 0.9)) for _ in range(n - l)] + \
+                    [float(-rng.uniform(0.0, 30.0)) for _ in range(l)]
+                rng.shuffle(s)
+                add(s)
+    for _ in range(40):
+        n = int(rng.integers(1, 25))
+        add([float(x) for x in rng.normal(0, 1, size=n)])
+    dump("genotype.json.gz", {"source": "result_organize_ins SF:1219-1231, gt_estimate_log_likelihood SF:2054-2077",
+                              "cases": cases})
+
+
+# ---------------------------------------------------------------------------
+def world_to_json(w):
+    return {"contigs": w.contigs,
+            "reads": {c: [[r.qname, r.pos, r.cigar, r.seq, r.ref_span] for r in rs] for c, rs in w.reads.items()},
+            "loci": [[l.chrom, l.svtype, l.start, l.end, l.svid, l.ins_seq, l.extra] for l in w.loci]}
+
+
+def gen_io(m):
+    rng = np.random.default_rng(606)
+    cases = []
+    kats = [("100S500M20I300M", 1000, 1200, 2200), ("50M300D500M", 1000, 1200, 2200),
+            ("500M", 1000, 1200, 2200), ("10S20M5I30M5D400M", 100, 130, 400),
+            ("100M", 1000, 1200, 2200), ("20M1000N50M", 100, 150, 300), ("30M5X40M", 100, 120, 160),
+            ("10H20S300M", 5, 100, 200), ("*", 5, 100, 200), ("5I100M", 1, 1, 50)]
+    for c in kats:
+        cases.append({"fn": "cigar2alignstart_by_pos", "args": list(c), "out": call(m.cigar2alignstart_by_pos, *c)})
+    for _ in range(30):
+        seg = synth.random_dna(rng, int(rng.integers(50, 600)))
+        _r, cg = synth.mutate(rng, seg)
+        a0 = int(rng.integers(1, 500))
+        st = a0 + int(rng.integers(-20, len(seg) + 30))
+        args = [cg, a0, st, st + 100]
+        cases.append({"fn": "cigar2alignstart_by_pos", "args": args, "out": call(m.cigar2alignstart_by_pos, *args)})
+    # read extraction on a small world
+    w = synth.make_world(61, 4, ("DEL", "TANDUP", "INV", "INS"), span_range=(150, 700), read_len=2600, n_reads=26)
+    shim = ShimOS(w)
+    m.os = shim
+    for l in w.loci:
+        f = min(500, l.end - l.start) if l.svtype != "INS" else min(500, len(l.ins_seq))
+        for fn, info in (("simple_del_chop_pacbio_read_simple_short", [l.chrom, l.start, l.end]),
+                         ("simple_chop_pacbio_read_simple_short", [l.chrom, l.start, l.end])):
+            cases.append({"fn": fn, "args": ["x.bam", info, f], "out": call(getattr(m, fn), "x.bam", info, f)})
+        cases.append({"fn": "ref_seq_readin", "args": ["ref.fa", l.chrom, l.start - f, l.end + f],
+                      "out": call(m.ref_seq_readin, "ref.fa", l.chrom, l.start - f, l.end + f)})
+        cases.append({"fn": "ref_seq_readin", "args": ["ref.fa", l.chrom, l.start, l.start + 75, "TRUE"],
+                      "out": call(m.ref_seq_readin, "ref.fa", l.chrom, l.start, l.start + 75, "TRUE")})
+    m.os = os
+    many = [[synth.random_dna(rng, 10), int(rng.integers(0, 6)), "q%d" % i] for i in range(45)]
+    cases.append({"fn": "minimize_pacbio_read_list", "args": [many], "out": call(m.minimize_pacbio_read_list, many)})
+    cases.append({"fn": "minimize_pacbio_read_list", "args": [many[:7]], "out": call(m.minimize_pacbio_read_list, many[:7])})
+    for b in ([["c", 100, 150]], [["c", 100, 700]], [["c", 100, 600]], [["c", 100, 190]]):
+        cases.append({"fn": "flank_length_calculate", "args": b, "out": call(m.flank_length_calculate, *b)})
+    dump("io.json.gz", {"source": "SF:309-354,1091-1102,1203-1217,1378-1401,794-802",
+                        "world": world_to_json(w), "cases": cases})
+
+
+# ---------------------------------------------------------------------------
+def load_cli(m):
+    """Pull the parsing helpers out of the reference CLI script without running its
+    argparse tail: exec only the `def` blocks above the `if len(sys.argv)<2:` line."""
+    src = open(REF_CLI).read()
+    head = src.split("\nif len(sys.argv)<2:")[0]
+    ns = {"__name__": "vapor_ref_cli"}
+    ns.update({k: getattr(m, k) for k in dir(m) if not k.startswith("__")})
+    exec(compile(head, REF_CLI, "exec"), ns)
+    return ns
+
+
+def run_bed(m, cli, world, tmp, num_reads_cff=3):
+    """What `vapor bed` does (vapor_vali/vapor:322-367) with figures disabled."""
+    bed = os.path.join(tmp, "in.bed")
+    open(bed, "w").write(synth.bed_text(world))
+    out_name = os.path.join(tmp, "out.vapor")
+    out_path = os.path.join(tmp, "figs") + "/"
+    os.makedirs(out_path, exist_ok=True)
+    bed_info = cli["bed_info_readin"](bed, out_path)
+    m.write_output_initiate(out_name)
+    per_locus = []
+    for x in bed_info:
+        if x[-1] in ["a/", "/a", "/", "DEL"]:
+            key = ":".join([str(i) for i in x[:-3]] + ["DEL"])
+            sc = call(m.vapor_simple_del_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", x[:-3], out_path + "f.png")
+        elif x[-1] in ["a/a^", "a^/a", "a^/a^", "INV"]:
+            key = ":".join([str(i) for i in x[:-3]] + ["INV"])
+            sc = call(m.vapor_simple_inv_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", x[:-3], out_path + "f.png")
+        elif x[-1] in ["INS"]:
+            key = ":".join([str(i) for i in x[:-3] + ["INS"]])
+            ins_pos = "_".join([str(i) for i in x[:2]])
+            ins_seq = "X" * x[4] if isinstance(x[4], int) else x[4]
+            sc = call(m.vapor_simple_ins_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", ins_pos, ins_seq, out_path + "f.png", "+")
+        elif x[-1] in ["a/aa", "aa/a", "aa/aa", "DUP", "TANDUP"]:
+            key = ":".join([str(i) for i in x[:-3]] + ["TANDUP"])
+            sc = call(m.vapor_simple_tandup_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", x[:-3], out_path + "f.png")
+        else:
+            continue
+        rec = {"bed_row": x, "key": key, "scores": sc}
+        if "ok" in sc:
+            res = m.result_organize_ins([key, sc["ok"]])
+            m.write_output_main(out_name, res[0].split(":") + [x[3]] + res[1:])
+            rec["organize"] = res
+        per_locus.append(rec)
+    return per_locus, open(out_name).read()
+
+
+def gen_locus(m):
+    cli = load_cli(m)
+    m.make_event_figure_1 = lambda *a, **k: None   # rendering is out of scope
+    out_cases = []
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_")
+    specs = [
+        ("bed_small_mix", dict(seed=71, n_loci=8, svtypes=("DEL", "TANDUP", "INV", "INS"), span_range=(120, 1500), read_len=4600, n_reads=9)),
+        ("bed_del_short_span", dict(seed=72, n_loci=4, svtypes=("DEL",), span_range=(50, 400), read_len=1800, n_reads=8)),
+        ("bed_few_reads", dict(seed=73, n_loci=3, svtypes=("DEL", "INV", "TANDUP"), span_range=(200, 600), read_len=2400, n_reads=3)),
+        ("bed_hom_alt", dict(seed=74, n_loci=4, svtypes=("DEL", "TANDUP", "INV", "INS"), span_range=(300, 900), read_len=3200, n_reads=8, alt_fraction=1.0)),
+        ("bed_hom_ref", dict(seed=75, n_loci=4, svtypes=("DEL", "TANDUP", "INV", "INS"), span_range=(300, 900), read_len=3200, n_reads=8, alt_fraction=0.0)),
+        ("bed_many_reads", dict(seed=76, n_loci=2, svtypes=("DEL", "INV"), span_range=(300, 700), read_len=2000, n_reads=30)),
+    ]
+    for name, kw in specs:
+        w = synth.make_world(**kw)
+        m.os = ShimOS(w)
+        per_locus, text = run_bed(m, cli, w, tmp)
+        m.os = os
+        out_cases.append({"name": name, "world": world_to_json(w), "bed": synth.bed_text(w),
+                          "per_locus": per_locus, "vapor_text": text})
+        print("  %s: %s" % (name, [len(p["scores"].get("ok", [])) if "ok" in p["scores"] else p["scores"] for p in per_locus]))
+    # long-span fallbacks (>= 10 kb): junction windows only, 1 kb reads
+    w = synth.make_world(seed=77, n_loci=3, svtypes=("DEL", "INV", "TANDUP"), span_range=(10050, 10400), read_len=1500, n_reads=8)
+    m.os = ShimOS(w)
+    per_locus, text = run_bed(m, cli, w, tmp)
+    m.os = os
+    out_cases.append({"name": "bed_long_span", "world": world_to_json(w), "bed": synth.bed_text(w),
+                      "per_locus": per_locus, "vapor_text": text})
+    print("  bed_long_span: %s" % [p["scores"] for p in per_locus])
+    dump("locus_bed.json.gz", {"source": "vapor bed loop vapor_vali/vapor:322-367 + drivers SF:1701-1933 (figures off)",
+                               "cases": out_cases})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    m = load_reference()
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus"]
+    for w in which:
+        print("== " + w)
+        globals()["gen_" + w](m)
+
+
+if __name__ == "__main__":
+    main()

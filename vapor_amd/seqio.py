@@ -1,0 +1,250 @@
+"""Reference/read extraction around an SV window (component #3).
+
+The reference shells out to samtools twice or more per locus and parses the text
+(`ref_seq_readin` SF:1203-1217, `chop_pacbio_read_by_pos` SF:339-354).  Here the same
+text protocol is served by a pluggable backend so that whole shards of loci can be
+prepared in-process before anything goes to the GPU:
+
+* `SamtoolsCLI`     - the real `samtools faidx` / `samtools view` (when installed);
+* `MemorySamtools`  - an in-memory world (`vapor_amd.synth.SynthWorld`) answering the
+                      same two queries with the same line formats.
+
+The trimming rules (POS filter, CIGAR walk, miss_bp cut, 20-read cap) keep the
+reference's semantics exactly; they are host-side integer/string work.
+"""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import subprocess
+from typing import Iterable, List, Optional
+
+_backend = None
+
+
+class SamtoolsCLI:
+    """Runs the samtools binary; raises if it is missing instead of yielding nothing."""
+
+    def __init__(self, exe: str = "samtools") -> None:
+        self.exe = shutil.which(exe)
+        if self.exe is None:
+            raise RuntimeError("samtools not found on PATH; install it or select "
+                               "vapor_amd.seqio.MemorySamtools via set_backend()")
+
+    def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
+        p = subprocess.run([self.exe, "faidx", ref, region], capture_output=True, text=True)
+        return p.stdout.splitlines()
+
+    def view_lines(self, bam: str, region: str) -> Iterable[str]:
+        p = subprocess.run([self.exe, "view", bam, region], capture_output=True, text=True)
+        return p.stdout.splitlines()
+
+    def isfile(self, path: str) -> bool:
+        return os.path.isfile(path)
+
+    def fai_lines(self, ref: str) -> Iterable[str]:
+        with open(ref + ".fai") as f:
+            return f.read().splitlines()
+
+
+class MemorySamtools:
+    """Answers faidx/view from a `SynthWorld`; file names are ignored."""
+
+    def __init__(self, world) -> None:
+        self.world = world
+
+    @staticmethod
+    def _region(region: str):
+        chrom, _, span = region.rpartition(":")
+        if not chrom:
+            return region, None, None
+        a, _, b = span.partition("-")
+        return chrom, int(a), int(b)
+
+    def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
+        chrom, a, b = self._region(region)
+        if a is None:
+            seq = self.world.contigs.get(chrom, "")
+        else:
+            seq = self.world.fetch(chrom, a, b) if chrom in self.world.contigs else ""
+        out = [">" + region]
+        out.extend(seq[i:i + 60] for i in range(0, len(seq), 60))
+        return out
+
+    def view_lines(self, bam: str, region: str) -> Iterable[str]:
+        chrom, a, b = self._region(region)
+        return [r.line() for r in self.world.overlapping(chrom, a, b)]
+
+    def isfile(self, path: str) -> bool:
+        return True
+
+    def fai_lines(self, ref: str) -> Iterable[str]:
+        return ["%s\t%d\t0\t60\t61" % (k, len(v)) for k, v in self.world.contigs.items()]
+
+
+def set_backend(b) -> None:
+    global _backend
+    _backend = b
+
+
+def get_backend():
+    global _backend
+    if _backend is None:
+        _backend = SamtoolsCLI()
+    return _backend
+
+
+# ---------------------------------------------------------------------------
+# reference-named helpers
+# ---------------------------------------------------------------------------
+_COMP = {i: None for i in range(256)}
+_COMP.update({ord(a): b for a, b in zip("ATGCNatgcn", "TACGNtacgn")})
+
+
+def complementary(seq: str) -> str:
+    """SF:471-478 - complements ATGCN/atgcn and silently drops everything else."""
+    return seq.translate(_COMP)
+
+
+def reverse(seq: str) -> str:
+    return seq[::-1]
+
+
+def ref_seq_readin(ref, chrom, start, end, reverse_flag="FALSE") -> str:
+    """SF:1203-1217: `samtools faidx ref chrom:start-end`, header dropped, the first
+    whitespace-separated token of every following line joined, stopping at a blank line."""
+    lines = iter(get_backend().faidx_lines(ref, "%s:%d-%d" % (chrom, int(start), int(end))))
+    next(lines, None)
+    parts: List[str] = []
+    for ln in lines:
+        tok = ln.strip().split()
+        if not tok:
+            break
+        parts.append(tok[0])
+    seq = "".join(parts)
+    if reverse_flag == "FALSE":
+        return seq
+    return reverse(complementary(seq))
+
+
+_CIGAR_RE = re.compile(r"(\d+)([MIDNSHP=X])")
+
+
+def cigar2alignstart_by_pos(cigar: str, align_start: int, start: int, end: int):
+    """SF:309-337: walk the CIGAR until the reference cursor passes `start-1`; returns
+    [offset into the read, miss_bp].  Only S/M/=/I advance the read and M/=/D the
+    reference (N, H, P and X advance nothing, as in the reference)."""
+    q = 0
+    r = align_start
+    last = None
+    for m in _CIGAR_RE.finditer(cigar):
+        n = int(m.group(1))
+        op = m.group(2)
+        if op == "S" or op == "I":
+            q += n
+        elif op == "M" or op == "=":
+            q += n
+            r += n
+        elif op == "D":
+            r += n
+        last = op
+        if r > start - 1:
+            break
+    if last is None:
+        raise IndexError("string index out of range")  # what '' [1] raises in SF:331
+    over = int(r) - start
+    if last in ("M", "="):
+        return [q - over, 0]
+    return [q, over]
+
+
+def chop_pacbio_read_by_pos(bam_in_new, chrom, start, end, flank_length):
+    """SF:339-354."""
+    out = []
+    for line in get_backend().view_lines(bam_in_new, "%s:%d-%d" % (chrom, start, end)):
+        f = line.strip().split()
+        if not f or f[0] == "@":
+            continue
+        if int(f[3]) < start + 1:
+            q0, miss_bp = cigar2alignstart_by_pos(f[5], int(f[3]), start, end)
+            if not miss_bp > flank_length / 2:
+                tail = f[9][q0:]
+                want = end - start - miss_bp
+                if len(tail) > want:
+                    out.append([tail[:want], miss_bp, f[0]])
+    return out
+
+
+def minimize_pacbio_read_list(x, ideal_list_length=20):
+    """SF:1091-1102: keep at most 20 reads, smallest miss_bp first, input order inside
+    one miss_bp value."""
+    if len(x) <= ideal_list_length:
+        return x
+    by_miss = {}
+    for rec in x:
+        by_miss.setdefault(rec[1], []).append(rec)
+    out = []
+    for k in sorted(by_miss):
+        if len(out) < ideal_list_length:
+            out += by_miss[k]
+    return out[:ideal_list_length]
+
+
+def bam_in_decide(bam_in, bps):
+    """SF:69-89: a file, or a per-chromosome pattern with XXX or * in the basename."""
+    be = get_backend()
+    if be.isfile(bam_in):
+        return [bam_in]
+    d = "/".join(bam_in.split("/")[:-1]) + "/"
+    base = bam_in.split("/")[-1]
+    if "XXX" in base:
+        keys = base.split("XXX")
+    elif "*" in base:
+        keys = base.split("*")
+    else:
+        print("Error: invalid name for pacbio files !")
+        raise NameError("bam_in_keys")  # the reference dies on the unbound name (SF:82)
+    ext = bam_in.split(".")[-1]
+    return [d + k for k in os.listdir(d)
+            if k.split(".")[-1] == ext and all(y in k for y in keys)]
+
+
+def simple_del_chop_pacbio_read_simple_short(bam_in, sv_info, flank_length):
+    """SF:1378-1390: reads around the left breakpoint only."""
+    bams = bam_in_decide(bam_in, sv_info)
+    if bams == "":
+        return [[], [], []]
+    x = []
+    for b in bams:
+        x += chop_pacbio_read_by_pos(b, sv_info[0], int(sv_info[1]) - flank_length,
+                                     int(sv_info[1]) + flank_length, flank_length)
+    return minimize_pacbio_read_list(x)
+
+
+def simple_chop_pacbio_read_simple_short(bam_in, sv_info, flank_length):
+    """SF:1392-1401: reads spanning first to last breakpoint."""
+    bams = bam_in_decide(bam_in, sv_info)
+    if bams == "":
+        return [[], [], []]
+    x = []
+    for b in bams:
+        x += chop_pacbio_read_by_pos(b, sv_info[0], int(sv_info[1]) - flank_length,
+                                     int(sv_info[-1]) + flank_length, flank_length)
+    return minimize_pacbio_read_list(x)
+
+
+def chromos_readin(ref) -> List[str]:
+    """SF:356-363: contig names from the .fai."""
+    out = []
+    for ln in get_backend().fai_lines(ref):
+        f = ln.strip().split()
+        if f:
+            out.append(f[0])
+    return out
+
+
+def flank_length_calculate(bps) -> int:
+    """SF:794-802: min(500, last - first breakpoint)."""
+    span = int(bps[-1]) - int(bps[1])
+    return span if span < 500 else 500

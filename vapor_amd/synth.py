@@ -1,0 +1,278 @@
+"""Seeded synthetic genomes, SV loci and PacBio-like reads.
+
+Everything here is the build's own generator: i.i.d. uniform ACGT contigs, SVs
+implanted by string surgery, reads sampled from the ref or alt haplotype with
+CLR-like errors (1 % sub / 8 % ins / 4 % del by default) and a CIGAR that is
+exact up to the left edge of the SV (all the reference ever walks, see
+vapor_vali/Simple_function.pyx:309-337).  The records are served to host code
+through `vapor_amd.seqio.MemorySamtools`, which speaks the two samtools text
+formats the reference parses (SF:339-354, SF:1203-1217).
+
+No reference code is used or needed here.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = {i: None for i in range(256)}
+_COMP.update({ord(a): b for a, b in zip("ACGTNacgtn", "TGCANtgcan")})
+
+
+def random_dna(rng: np.random.Generator, n: int) -> str:
+    return _ACGT[rng.integers(0, 4, size=n)].tobytes().decode("ascii")
+
+
+def revcomp(seq: str) -> str:
+    """Reverse complement over ACGTN/acgtn; other characters are dropped, as the
+    reference's `complementary` does (SF:471-478)."""
+    return seq.translate(_COMP)[::-1]
+
+
+def _rle_cigar(ops: np.ndarray) -> str:
+    # ops: uint8 array of b'M', b'I', b'D'
+    if ops.size == 0:
+        return "*"
+    change = np.flatnonzero(ops[1:] != ops[:-1]) + 1
+    starts = np.concatenate(([0], change))
+    ends = np.concatenate((change, [ops.size]))
+    return "".join("%d%s" % (e - s, chr(ops[s])) for s, e in zip(starts, ends))
+
+
+def mutate(rng: np.random.Generator, seg: str, sub: float = 0.01, ins: float = 0.08,
+           dele: float = 0.04) -> Tuple[str, str]:
+    """Apply CLR-like errors to `seg`; returns (read, cigar relative to seg).
+
+    The first base is always kept as a match so that POS is the first aligned base."""
+    n = len(seg)
+    if n == 0:
+        return "", "*"
+    b = np.frombuffer(seg.encode("ascii"), dtype=np.uint8)
+    u = rng.random(n)
+    is_del = u < dele
+    is_sub = (u >= dele) & (u < dele + sub)
+    is_ins = rng.random(n) < ins
+    is_del[0] = False
+    is_sub[0] = False
+    # substituted bases: rotate within ACGT when the base is ACGT, else keep
+    code = np.full(256, 255, dtype=np.uint8)
+    code[_ACGT] = np.arange(4, dtype=np.uint8)
+    c = code[b]
+    rot = rng.integers(1, 4, size=n).astype(np.uint8)
+    subbed = np.where((c < 4) & is_sub, _ACGT[(c + rot) & 3], b)
+    ins_b = _ACGT[rng.integers(0, 4, size=n)]
+    keep = ~is_del
+    # output layout: for each position p: [base if kept][inserted base if is_ins]
+    cnt = keep.astype(np.int64) + is_ins.astype(np.int64)
+    off = np.concatenate(([0], np.cumsum(cnt)))
+    out = np.empty(off[-1], dtype=np.uint8)
+    out[off[:-1][keep]] = subbed[keep]
+    ins_pos = off[:-1] + keep.astype(np.int64)
+    out[ins_pos[is_ins]] = ins_b[is_ins]
+    # cigar ops: per position M or D, then I
+    opcnt = 1 + is_ins.astype(np.int64)
+    ooff = np.concatenate(([0], np.cumsum(opcnt)))
+    ops = np.empty(ooff[-1], dtype=np.uint8)
+    ops[ooff[:-1]] = np.where(keep, ord("M"), ord("D"))
+    ops[(ooff[:-1] + 1)[is_ins]] = ord("I")
+    return out.tobytes().decode("ascii"), _rle_cigar(ops)
+
+
+@dataclasses.dataclass
+class SamRecord:
+    qname: str
+    rname: str
+    pos: int          # 1-based leftmost aligned base
+    cigar: str
+    seq: str
+    ref_span: int     # reference bases the alignment is taken to cover (for region overlap)
+
+    def line(self) -> str:
+        return "\t".join([self.qname, "0", self.rname, str(self.pos), "60", self.cigar,
+                          "*", "0", "0", self.seq, "*"])
+
+
+@dataclasses.dataclass
+class Locus:
+    """One SV call in a private contig (0-based half-open internals, 1-based text outside)."""
+    chrom: str
+    svtype: str                   # DEL | TANDUP | INV | INS | DISDUP | DUP_INV | DEL_INV
+    start: int                    # as written to BED/VCF column 2
+    end: int                      # column 3
+    svid: str
+    ins_seq: Optional[str] = None
+    extra: Optional[dict] = None  # insert_point etc. for the complex types
+
+
+class SynthWorld:
+    """Contigs + aligned reads, addressable the way samtools addresses them."""
+
+    def __init__(self) -> None:
+        self.contigs: Dict[str, str] = {}
+        self.reads: Dict[str, List[SamRecord]] = {}
+        self.loci: List[Locus] = []
+
+    # -- samtools-like accessors -------------------------------------------------
+    def fetch(self, chrom: str, start: int, end: int) -> str:
+        """1-based inclusive, clipped to the contig like `samtools faidx`."""
+        s = self.contigs[chrom]
+        start = max(int(start), 1)
+        end = min(int(end), len(s))
+        if end < start:
+            return ""
+        return s[start - 1:end]
+
+    def overlapping(self, chrom: str, start: int, end: int) -> List[SamRecord]:
+        out = []
+        for r in self.reads.get(chrom, ()):
+            if r.pos <= end and r.pos + r.ref_span - 1 >= start:
+                out.append(r)
+        return out
+
+
+def apply_sv(ref: str, svtype: str, s: int, e: int, ins_seq: Optional[str] = None,
+             ins_point: Optional[int] = None) -> str:
+    """Alt haplotype of a whole contig. `s`,`e` are the BED columns; the SV block is
+    contig[s:e] in 0-based half-open terms (the reference treats faidx s..e loosely;
+    the generator only has to be self-consistent)."""
+    blk = ref[s:e]
+    if svtype == "DEL":
+        return ref[:s] + ref[e:]
+    if svtype in ("TANDUP", "DUP"):
+        return ref[:e] + blk + ref[e:]
+    if svtype == "INV":
+        return ref[:s] + revcomp(blk) + ref[e:]
+    if svtype == "INS":
+        return ref[:s] + (ins_seq or "") + ref[s:]
+    if svtype == "DISDUP":
+        p = int(ins_point)
+        return ref[:p] + blk + ref[p:]
+    if svtype == "DUP_INV":
+        p = int(ins_point)
+        return ref[:p] + revcomp(blk) + ref[p:]
+    if svtype == "DEL_INV":
+        # delete [s, m) and invert [m, e), m carried in ins_point
+        m = int(ins_point)
+        return ref[:s] + revcomp(ref[m:e]) + ref[e:]
+    raise ValueError(svtype)
+
+
+def make_world(seed: int, n_loci: int, svtypes: Sequence[str] = ("DEL", "TANDUP"),
+               span_range: Tuple[int, int] = (200, 3000), read_len: int = 6000,
+               n_reads: int = 12, alt_fraction: float = 0.5, lead: int = 300,
+               contig_pad: int = 2000, errors: Tuple[float, float, float] = (0.01, 0.08, 0.04),
+               chrom_prefix: str = "c", ins_len_range: Tuple[int, int] = (100, 600)) -> SynthWorld:
+    """Build `n_loci` independent loci, one contig each.
+
+    Reads start 1..`lead` bases left of the scored window's left edge (SV start minus the
+    500 bp flank) so that the reference's POS<=start filter keeps them, and are
+    `read_len` haplotype bases long before errors."""
+    rng = np.random.default_rng(seed)
+    w = SynthWorld()
+    for li in range(n_loci):
+        svtype = svtypes[li % len(svtypes)]
+        span = int(rng.integers(span_range[0], span_range[1] + 1))
+        flank = min(500, span)
+        left = flank + lead + 50
+        clen = left + 3 * span + read_len + contig_pad
+        chrom = "%s%d" % (chrom_prefix, li + 1)
+        ref = random_dna(rng, clen)
+        s = left
+        e = s + span
+        ins_seq = None
+        ins_point = None
+        extra = None
+        if svtype == "INS":
+            ilen = int(rng.integers(ins_len_range[0], ins_len_range[1] + 1))
+            ins_seq = random_dna(rng, ilen)
+            e = s + 1
+            flank = min(500, ilen)
+        elif svtype in ("DISDUP", "DUP_INV"):
+            ins_point = e + int(rng.integers(50, max(51, span)))
+            extra = {"insert_point": ins_point}
+        elif svtype == "DEL_INV":
+            ins_point = s + span // 2
+            extra = {"mid": ins_point}
+        alt = apply_sv(ref, svtype, s, e, ins_seq, ins_point)
+        w.contigs[chrom] = ref
+        recs: List[SamRecord] = []
+        win_left = s - flank  # 1-based coordinate the reference uses as window start
+        for ri in range(n_reads):
+            from_alt = rng.random() < alt_fraction
+            hap = alt if from_alt else ref
+            a = win_left - 1 - int(rng.integers(1, lead + 1))
+            a = max(a, 0)
+            b = min(a + read_len, len(hap))
+            read, cigar = mutate(rng, hap[a:b], *errors)
+            recs.append(SamRecord("r%d_%d%s" % (li + 1, ri, "a" if from_alt else "r"), chrom,
+                                  a + 1, cigar, read, b - a))
+        w.reads[chrom] = recs
+        w.loci.append(Locus(chrom, svtype, s, e, "sv%d" % (li + 1), ins_seq, extra))
+    return w
+
+
+def bed_text(world: SynthWorld) -> str:
+    """5+ column BED as `bed_info_readin` expects it today (vapor_vali/vapor:22-50)."""
+    rows = []
+    for l in world.loci:
+        t = {"TANDUP": "DUP"}.get(l.svtype, l.svtype)
+        if l.svtype == "INS":
+            rows.append("\t".join([l.chrom, str(l.start), str(l.end), l.svid, "INS", l.ins_seq]))
+        elif l.svtype in ("DEL", "TANDUP", "INV"):
+            rows.append("\t".join([l.chrom, str(l.start), str(l.end), l.svid, t]))
+    return "\n".join(rows) + "\n"
+
+
+def vcf_text(world: SynthWorld) -> str:
+    """Minimal VCF with the INFO keys `vcf_list_readin` reads (vapor_vali/vapor:127-202,
+    README.md:79-82 for the complex types)."""
+    out = ["##fileformat=VCFv4.1",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE"]
+    for l in world.loci:
+        info = "SVTYPE=%s;END=%d" % ({"TANDUP": "DUP"}.get(l.svtype, l.svtype), l.end)
+        alt = "<%s>" % l.svtype
+        if l.svtype == "INS":
+            info = "SVTYPE=INS;END=%d;SVLEN=%d" % (l.end, len(l.ins_seq))
+            alt = l.ins_seq
+        elif l.svtype in ("DISDUP", "DUP_INV"):
+            info += ";insert_point=%s:%d" % (l.chrom, l.extra["insert_point"])
+        elif l.svtype == "DEL_INV":
+            m = l.extra["mid"]
+            info += ";del=%s:%d-%d;inv=%s:%d-%d" % (l.chrom, l.start, m, l.chrom, m, l.end)
+        out.append("\t".join([l.chrom, str(l.start), l.svid, "N", alt, ".", "PASS", info,
+                              "GT", "0/1"]))
+    return "\n".join(out) + "\n"
+
+
+# ---------------------------------------------------------------------------
+# kernel-level synthetic shapes (bench / parity at BASELINE sizes)
+# ---------------------------------------------------------------------------
+
+def make_pairs(seed: int, n_alleles: int, reads_per_allele: int, read_len: int, allele_len: int,
+               errors: Tuple[float, float, float] = (0.01, 0.08, 0.04),
+               sv: bool = True) -> Tuple[List[str], List[str], List[Tuple[int, int]]]:
+    """`n_alleles` windows of `allele_len` bases, each with `reads_per_allele` noisy reads of
+    ~`read_len` bases drawn from inside the window (half of the alleles carry a deletion
+    relative to the haplotype the reads come from when `sv`), returning
+    (alleles, reads, [(read_idx, allele_idx)...])."""
+    rng = np.random.default_rng(seed)
+    alleles: List[str] = []
+    reads: List[str] = []
+    pairs: List[Tuple[int, int]] = []
+    for ai in range(n_alleles):
+        a = random_dna(rng, allele_len)
+        alleles.append(a)
+        hap = a
+        if sv and (ai & 1):
+            cut = int(rng.integers(allele_len // 4, allele_len // 2))
+            ln = int(rng.integers(50, 2000))
+            hap = a[:cut] + a[cut + ln:]
+        for _ in range(reads_per_allele):
+            st = int(rng.integers(0, max(1, len(hap) - read_len)))
+            r, _c = mutate(rng, hap[st:st + read_len], *errors)
+            reads.append(r[:read_len])
+            pairs.append((len(reads) - 1, ai))
+    return alleles, reads, pairs
