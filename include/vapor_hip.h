@@ -1,0 +1,152 @@
+/*
+ * vapor_hip.h - C ABI of libvapor_hip.so: VaPoR's recurrence-plot scoring path on MI355X.
+ *
+ * The reference has no FFI layer: its hot path is a set of module-level Python functions in
+ * vapor_vali/Simple_function.pyx ("SF") that the `vapor` script star-imports
+ * (vapor_vali/vapor:303,322,374,470).  Every entry point below names the reference routine(s)
+ * it stands in for; the Python host code in vapor_amd/ keeps the reference's function names
+ * and calls through this ABI with ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions: plain pointers and sizes; all buffers caller-allocated and never retained;
+ * every function returns 0 or a negative VAPOR_E_* code; vapor_last_error() gives a
+ * thread-local message.  One host thread per context.  No exception crosses the boundary.
+ */
+#ifndef VAPOR_HIP_H
+#define VAPOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAPOR_ABI_VERSION 1
+
+/* status codes */
+#define VAPOR_OK 0
+#define VAPOR_E_HIP (-1)       /* a HIP runtime call failed (message in vapor_last_error) */
+#define VAPOR_E_OVERFLOW (-2)  /* caller-supplied output buffer too small; required size reported */
+#define VAPOR_E_KEYERROR (-3)  /* a k-mer of seq1 holds a character invert_base lacks (SF:19-20, SF:1421) */
+#define VAPOR_E_ARG (-4)       /* bad argument: index out of range, unsupported k, sequence too long */
+#define VAPOR_E_NOMEM (-5)
+
+#define VAPOR_MAX_SEQ_LEN 65535 /* positions are packed 16+16 bit on the device */
+
+typedef struct vapor_ctx vapor_ctx;
+typedef struct vapor_seqset vapor_seqset;
+typedef struct vapor_plan vapor_plan;
+
+/* per-sequence upload flags */
+#define VAPOR_SEQ_UPPER 1u /* apply str.upper() before packing (SF:183-184: abs_dis_m1b upper-cases ref and alt) */
+
+/*
+ * One dot plot: dotdata(k, seq1, seq2[off2:]) (SF:545-549 -> kmerhits SF:951-983), i.e. the
+ * reference's call convention dotdata(window_size, read, allele[miss_bp:]) (SF:185-186,
+ * 242-243, 278-279).  seq1/seq2 index a vapor_seqset.  k must be 10, 20, 30 or 40, the only
+ * values window_size_refine can return (SF:2031-2041).
+ */
+typedef struct vapor_pair {
+    int32_t seq1;  /* read (the sequence whose k-mers are also searched reverse-complemented) */
+    int32_t seq2;  /* allele window */
+    int32_t off2;  /* miss_bp: seq2 is used from this offset on */
+    int32_t k;
+    uint32_t flags; /* VAPOR_PF_* */
+} vapor_pair;
+
+#define VAPOR_PF_C1 1u   /* clean_dotdata_diagnal_and_anti_diagnal (SF:432-448) -> ST_C1_* */
+#define VAPOR_PF_C2 2u   /* the two-step cleaning of within_10Perc_m1b (SF:281-288) -> ST_C2_* */
+
+/* int64 statistics record per pair (VAPOR_STATS_STRIDE words) */
+#define VAPOR_STATS_STRIDE 16
+#define VAPOR_ST_N_HITS 0      /* len(dotdata) */
+#define VAPOR_ST_FIRST_J 1     /* dotdata[0][0]  = smallest j, -1 if no hits (SF:187) */
+#define VAPOR_ST_LAST_J 2      /* dotdata[-1][0] = largest j,  -1 if no hits */
+#define VAPOR_ST_C1_KEPT 3     /* dots surviving C1 */
+#define VAPOR_ST_C1_SUM_ABS 4  /* sum |j-i| over them: eu_dis_abs_calcu = this / C1_KEPT (SF:705-708) */
+#define VAPOR_ST_C2_KEPT 5     /* dots surviving the diagonal step or the anti-diagonal step on the rest */
+#define VAPOR_ST_C2_COUNT10 6  /* eu_dis_dots_within_10perc over them (SF:730-733) */
+#define VAPOR_ST_N_DIAG 7      /* dots with j == i (qual_check_repetitive_region SF:1158-1160) */
+#define VAPOR_ST_N_LOWER 8     /* dots with j > i  (SF:1162-1164) */
+#define VAPOR_ST_C2_KEPT_DIAG 9 /* dots kept by the diagonal step alone */
+#define VAPOR_ST_STATUS 15     /* 0, or VAPOR_E_KEYERROR / VAPOR_E_ARG / VAPOR_E_OVERFLOW for this pair */
+
+/* per-hit flag bits returned by vapor_plan_fetch_hits */
+#define VAPOR_HF_C1_KEPT 1u
+#define VAPOR_HF_C2_DIAG 2u
+#define VAPOR_HF_C2_ANTI 4u
+
+/* ---- context --------------------------------------------------------------------------- */
+int vapor_abi_version(void);
+const char* vapor_last_error(void);
+int vapor_init(int device_ordinal, vapor_ctx** ctx);
+int vapor_destroy(vapor_ctx* ctx);
+/* tuning knobs: "reads_per_task" (reads sharing one allele hash table per workgroup) */
+int vapor_set_param(vapor_ctx* ctx, const char* name, int64_t value);
+
+/* ---- sequences: ASCII in, packed bit planes resident in HBM ------------------------------ */
+/*
+ * Uploads n_seqs sequences (blob[off[s] .. off[s]+len[s])), folds IUPAC codes as key_modify
+ * does (SF:908-949), optionally upper-cases, and packs them on the device into a 2-bit base
+ * plane, a 1-bit "not A/C/G/T" plane and a 4-bit symbol plane.
+ * seq_info[2*s] receives the number of symbols outside upper-case ACGT, seq_info[2*s+1] the
+ * number outside invert_base's alphabet (such a seq1 raises KeyError in the reference).
+ */
+int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* blob, const int64_t* off,
+                        const int32_t* len, const uint8_t* flags, int32_t* seq_info,
+                        vapor_seqset** set);
+int vapor_seqset_destroy(vapor_seqset* set);
+
+/* ---- plans: a batch of dot plots resident on the device ---------------------------------- */
+/* Validates and groups the pairs (reads sharing an allele window share its hash table),
+ * uploads the descriptors and sizes the workspace.  The plan can be run any number of times. */
+int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pairs, const vapor_pair* pairs,
+                      vapor_plan** plan);
+int vapor_plan_destroy(vapor_plan* plan);
+/*
+ * The hot path: k-mer hash join (kmerhits SF:951-983), gap clustering and noise cleaning
+ * (dis_cluster SF:551-564, dis_cluster_2 SF:566-580, SF:404-448) and the integer reductions
+ * (SF:705-733, SF:1154-1171) for every pair.  stats: n_pairs * VAPOR_STATS_STRIDE int64.
+ */
+int vapor_plan_run(vapor_plan* plan, int64_t* stats);
+/* device time of the kernels of the last vapor_plan_run, measured with HIP events on the
+ * library's stream: ms[0] = join kernels, ms[1] = clean kernel, ms[2] = whole run incl. copies,
+ * ms[3] = number of join launches, ms[4] = number of retried pairs */
+int vapor_plan_timings(vapor_plan* plan, double* ms, int32_t n);
+/* algorithmic bytes of one run: sum over pairs of packed read + packed allele
+ * + 8 B per hit + 128 B statistics record, using the hit counts of the last run */
+int vapor_plan_algorithmic_bytes(vapor_plan* plan, int64_t* bytes, int64_t* cells);
+/*
+ * Hits of selected pairs after vapor_plan_run: hits_ji receives (j, i) int32 pairs in
+ * unspecified order inside a pair (dotdata's list is these sorted by (j, i)), hit_flags one
+ * VAPOR_HF_* byte per hit (may be NULL), hit_off[n_sel+1] the offsets.  VAPOR_E_OVERFLOW
+ * with hit_off[n_sel] = required capacity if `capacity` (in hits) is too small.
+ */
+int vapor_plan_fetch_hits(vapor_plan* plan, int64_t n_sel, const int64_t* pair_idx,
+                          int32_t* hits_ji, uint8_t* hit_flags, int64_t capacity, int64_t* hit_off);
+
+/* ---- one-shot conveniences over the above -------------------------------------------------- */
+/* dotdata for a batch (create + run + fetch all + destroy). */
+int vapor_dotplot_batch(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pairs, const vapor_pair* pairs,
+                        int32_t* hits_ji, int64_t hits_capacity, int64_t* hit_off, int64_t* stats);
+/* statistics only (create + run + destroy). */
+int vapor_score_batch(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pairs, const vapor_pair* pairs,
+                      int64_t* stats);
+/* Integer part of window_size_refine's quality check (SF:2030-2046, SF:1154-1171): the self dot
+ * plot dotdata(k, seq, seq) of each listed sequence; out[3*t..] = n_hits, n_diag, n_lower. */
+int vapor_selfplot_qc(vapor_ctx* ctx, vapor_seqset* set, int32_t n, const int32_t* seq_idx,
+                      const int32_t* k, int64_t* out);
+
+/*
+ * Cleaning and reductions on caller-supplied dot lists, for callers that hold an explicit
+ * list the way clean_dotdata_diagnal_and_anti_diagnal (SF:432-448) and
+ * clean_dotdata_diagnal_m1b / clean_dotdata_anti_diagnal_m1b (SF:404-430) are called:
+ * list t is hits_ji[2*off[t] .. 2*off[t+1]) as (j, i) pairs, flags[t] VAPOR_PF_* (NULL = both).
+ * stats as in vapor_plan_run; hit_flags (may be NULL) one VAPOR_HF_* byte per dot.
+ */
+int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* hits_ji, const int64_t* off,
+                     const uint32_t* flags, int64_t* stats, uint8_t* hit_flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAPOR_HIP_H */

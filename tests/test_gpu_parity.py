@@ -1,0 +1,181 @@
+"""Parity of the HIP path (through the C ABI) against reference-generated golden vectors and
+against the CPU oracle on seeded inputs.  Bit-exact: this path is integer work throughout."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from vapor_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _sha(h):
+    return hashlib.sha256(np.ascontiguousarray(h, dtype=np.int32).tobytes()).hexdigest()
+
+
+def test_dotdata_golden(eng):
+    cases = load_golden("kmerhits.json.gz")["cases"]
+    seqs, rows = [], []
+    for c in cases:
+        seqs += [c["seq1"], c["seq2"]]
+        rows.append((len(seqs) - 2, len(seqs) - 1, 0, c["k"], 0))
+    ss = eng.seqset(seqs)
+    st, hits = eng.dotplots(ss, eng.make_pairs(rows))
+    for t, c in enumerate(cases):
+        if "error" in c:
+            assert st[t, 15] == -3, c["name"]
+            continue
+        assert st[t, 15] == 0, c["name"]
+        assert st[t, 0] == c["n_hits"], c["name"]
+        assert _sha(hits[t]) == c["sha256"], c["name"]
+        if "hits" in c:
+            assert hits[t].tolist() == c["hits"], c["name"]
+
+
+def test_cleaners_golden(eng, oracle):
+    cases = load_golden("cleaners.json.gz")["cases"]
+    lists = [np.asarray(c["hits"], dtype=np.int32).reshape(-1, 2) for c in cases]
+    st, fl = eng.clean_hits(lists)
+    for t, c in enumerate(cases):
+        h = lists[t]
+        got1 = h[(fl[t] & 1) > 0].tolist()
+        assert got1 == c["c1"]["ok"], c["name"]
+        assert sorted(map(tuple, h[(fl[t] & 2) > 0].tolist())) == sorted(map(tuple, c["c2_diag"]["ok"])), c["name"]
+        assert sorted(map(tuple, h[(fl[t] & 4) > 0].tolist())) == \
+            sorted(map(tuple, c.get("c2_anti_on_left", {"ok": []})["ok"])), c["name"]
+        if "count10" in c:
+            assert st[t, 6] == c["count10"], c["name"]
+        if "meanabs" in c:
+            assert float(st[t, 4]) / float(st[t, 3]) == c["meanabs"], c["name"]
+        assert st[t, 0] == len(h) and st[t, 1] == h[:, 0].min() and st[t, 2] == h[:, 0].max()
+
+
+def _check_stats_vs_oracle(eng, oracle, seqs, upper, rows, tag=""):
+    ss = eng.seqset(seqs, upper)
+    pairs = eng.make_pairs(rows)
+    st = eng.score(ss, pairs)
+    for t, (s1, s2, off2, k, fl) in enumerate(rows):
+        a = seqs[s1].upper() if upper[s1] else seqs[s1]
+        b = seqs[s2].upper() if upper[s2] else seqs[s2]
+        try:
+            exp = oracle.pair_stats(k, a, b[off2:])
+        except KeyError:
+            assert st[t, 15] == -3, (tag, t)
+            continue
+        assert st[t, 15] == 0, (tag, t)
+        got = st[t].copy()
+        if not fl & 1:
+            exp[3] = exp[4] = 0
+        if not fl & 2:
+            exp[5] = exp[6] = exp[9] = 0
+        assert got[:10].tolist() == exp[:10].tolist(), (tag, t, rows[t])
+    return st
+
+
+def test_scorer_inputs_vs_oracle(eng, oracle):
+    """Every (read, allele[miss:]) dot plot the three live scorers evaluate on the golden
+    scorer inputs, with and without abs_dis_m1b's upper-casing."""
+    cases = load_golden("scorers.json.gz")["cases"]
+    seqs, upper, rows = [], [], []
+    for c in cases:
+        base = len(seqs)
+        seqs += [c["read"], c["ref"], c["alt"], c["ref"], c["alt"]]
+        upper += [False, False, False, True, True]
+        for al in (1, 2, 3, 4):
+            rows.append((base, base + al, c["miss"], c["k"], 3))
+    _check_stats_vs_oracle(eng, oracle, seqs, upper, rows, "scorers")
+
+
+def test_selfplot_counts_golden(eng):
+    cases = load_golden("window.json.gz")["cases"]
+    seqs, rows, exp = [], [], []
+    for c in cases:
+        s = "".join(ch for ch in c["seq"] if ch != "X")
+        for step, tr in enumerate(c["qc_trace"]):
+            seqs.append(s)
+            rows.append((len(seqs) - 1, len(seqs) - 1, 0, 10 + 10 * step, 0))
+            exp.append(tr)
+    ss = eng.seqset(seqs)
+    st = eng.score(ss, eng.make_pairs(rows))
+    assert st[:, [0, 7, 8]].tolist() == exp
+
+
+@pytest.mark.parametrize("k", [10, 20, 30, 40])
+def test_random_pairs_vs_oracle(eng, oracle, k):
+    from vapor_amd import synth
+    alleles, reads, pr = synth.make_pairs(1000 + k, 6, 4, 3000, 5000, errors=(0.002, 0.01, 0.005) if k > 10 else (0.01, 0.08, 0.04))
+    seqs = alleles + reads
+    rows = [(len(alleles) + r, a, (7 * r) % 50, k, 3) for r, a in pr]
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "rand%d" % k)
+
+
+def test_general_mode_softmasked_both(eng, oracle):
+    """Both sequences carry lower-case / N symbols -> 4-bit symbol path."""
+    from vapor_amd import synth
+    rng = np.random.default_rng(5)
+    seqs, rows = [], []
+    for t in range(6):
+        a = synth.random_dna(rng, 2500)
+        a = a[:400] + a[400:1100].lower() + a[1100:1500] + "N" * 30 + a[1530:2000] + "n" * 11 + a[2011:]
+        r, _ = synth.mutate(rng, a[100:2300], 0.003, 0.01, 0.01)
+        seqs += [a, r]
+        for k in (10, 20, 30, 40):
+            rows.append((len(seqs) - 1, len(seqs) - 2, 0, k, 3))
+            rows.append((len(seqs) - 2, len(seqs) - 2, 0, k, 3))
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "general")
+
+
+def test_bench_shape_and_multi_tile(eng, oracle):
+    """BASELINE shapes: 10 kb x 20 kb, 15 kb x 20 kb, and 30 kb x 40 kb (two hash-table tiles)."""
+    from vapor_amd import synth
+    seqs, rows = [], []
+    for seed, (lr, la) in enumerate(((10000, 20000), (15000, 20000), (30000, 40000))):
+        alleles, reads, pr = synth.make_pairs(77 + seed, 2, 3, lr, la)
+        base = len(seqs)
+        seqs += alleles + reads
+        rows += [(base + len(alleles) + r, base + a, 0, 10, 3) for r, a in pr]
+    st = _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "bench")
+    assert st[:, 0].min() > 1000
+
+
+def test_overflow_retry_and_hit_fetch(eng, oracle):
+    """Low-complexity input: far more hits than the first-guess slot -> exact-size rerun."""
+    seqs = ["A" * 700, "A" * 900 + "C" * 50, "AT" * 400, "TA" * 450]
+    rows = [(0, 1, 0, 10, 3), (2, 3, 5, 10, 3), (0, 3, 0, 10, 3)]
+    ss = eng.seqset(seqs)
+    st, hits = eng.dotplots(ss, eng.make_pairs(rows))
+    for t, (s1, s2, off2, k, _f) in enumerate(rows):
+        exp = oracle.dotdata_array(k, seqs[s1], seqs[s2][off2:])
+        assert st[t, 0] == len(exp)
+        assert hits[t].tolist() == exp.tolist()
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * 4, rows, "overflow")
+
+
+@pytest.mark.parametrize("rpt", [1, 3, 64])
+def test_reads_per_task_invariance(eng, oracle, rpt):
+    from vapor_amd import synth
+    alleles, reads, pr = synth.make_pairs(31, 3, 9, 1500, 2500)
+    seqs = alleles + reads
+    rows = [(len(alleles) + r, a, 0, 10, 3) for r, a in pr]
+    eng.set_param("reads_per_task", rpt)
+    try:
+        _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "rpt%d" % rpt)
+    finally:
+        eng.set_param("reads_per_task", 8)
+
+
+def test_bad_arguments(eng):
+    ss = eng.seqset(["ACGTACGTACGTACGT", "ACGT"])
+    st = eng.score(ss, eng.make_pairs([(0, 5, 0, 10, 3), (0, 1, 0, 11, 3), (0, 1, 0, 10, 3), (1, 0, 0, 10, 3)]))
+    assert st[0, 15] == -4 and st[1, 15] == -4
+    assert st[2, 15] == 0 and st[2, 0] == 0 and st[2, 1] == -1
+    assert st[3, 15] == 0 and st[3, 0] == 0

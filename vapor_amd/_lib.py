@@ -1,0 +1,87 @@
+"""ctypes binding of libvapor_hip.so (include/vapor_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, every
+entry point raises.  Build with `python -m vapor_amd.build` (or __graft_entry__.build()).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libvapor_hip.so")
+
+PAIR_DTYPE = np.dtype([("seq1", "<i4"), ("seq2", "<i4"), ("off2", "<i4"), ("k", "<i4"), ("flags", "<u4")])
+STATS_STRIDE = 16
+ST_N_HITS, ST_FIRST_J, ST_LAST_J, ST_C1_KEPT, ST_C1_SUM_ABS = 0, 1, 2, 3, 4
+ST_C2_KEPT, ST_C2_COUNT10, ST_N_DIAG, ST_N_LOWER, ST_C2_KEPT_DIAG, ST_STATUS = 5, 6, 7, 8, 9, 15
+PF_C1, PF_C2 = 1, 2
+HF_C1_KEPT, HF_C2_DIAG, HF_C2_ANTI = 1, 2, 4
+SEQ_UPPER = 1
+E_HIP, E_OVERFLOW, E_KEYERROR, E_ARG, E_NOMEM = -1, -2, -3, -4, -5
+MAX_SEQ_LEN = 65535
+
+EXPORTS = [
+    "vapor_abi_version", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
+    "vapor_seqset_create", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
+    "vapor_plan_run", "vapor_plan_timings", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
+    "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
+]
+
+_lib = None
+
+
+class VaporHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libvapor_hip: status %d: %s" % (code, msg))
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library or fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError("%s is missing - the HIP extension has not been built "
+                           "(run `python -m vapor_amd.build`); there is no CPU fallback" % SO_PATH)
+    L = ctypes.CDLL(SO_PATH)
+    vp = ctypes.c_void_p
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    f64p = ctypes.POINTER(ctypes.c_double)
+    L.vapor_abi_version.restype = ctypes.c_int
+    L.vapor_last_error.restype = ctypes.c_char_p
+    L.vapor_init.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.vapor_destroy.argtypes = [vp]
+    L.vapor_set_param.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    L.vapor_seqset_create.argtypes = [vp, ctypes.c_int32, u8p, i64p, i32p, u8p, i32p, ctypes.POINTER(vp)]
+    L.vapor_seqset_destroy.argtypes = [vp]
+    L.vapor_plan_create.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.POINTER(vp)]
+    L.vapor_plan_destroy.argtypes = [vp]
+    L.vapor_plan_run.argtypes = [vp, i64p]
+    L.vapor_plan_timings.argtypes = [vp, f64p, ctypes.c_int32]
+    L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
+    L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]
+    L.vapor_dotplot_batch.argtypes = [vp, vp, ctypes.c_int64, vp, i32p, ctypes.c_int64, i64p, i64p]
+    L.vapor_score_batch.argtypes = [vp, vp, ctypes.c_int64, vp, i64p]
+    L.vapor_selfplot_qc.argtypes = [vp, vp, ctypes.c_int32, i32p, i32p, i64p]
+    L.vapor_clean_hits.argtypes = [vp, ctypes.c_int64, i32p, i64p, u32p, i64p, u8p]
+    for name in EXPORTS:
+        if name not in ("vapor_last_error",):
+            getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise VaporHipError(rc, load().vapor_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))

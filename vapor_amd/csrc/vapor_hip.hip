@@ -1,0 +1,665 @@
+// vapor_hip.hip - host side of libvapor_hip.so: the C ABI declared in include/vapor_hip.h.
+//
+// Build (see vapor_amd/build.py):
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -Iinclude vapor_amd/csrc/vapor_hip.hip
+//
+// Everything the GPU touches is resident in HBM between calls: a vapor_seqset holds the packed
+// bit planes, a vapor_plan holds pair/task descriptors, the hit workspace and the statistics.
+#include "vapor_kernels.h"
+#include "vapor_hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace vapor;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(VAPOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+struct vapor_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int reads_per_task = 8;
+    int64_t max_pair_cap = (int64_t)1 << 28;
+    bool attrs_set = false;
+};
+
+struct vapor_seqset {
+    vapor_ctx* ctx = nullptr;
+    int32_t n = 0;
+    std::vector<SeqDesc> h;        // host copy (with device-computed counts)
+    SeqDesc* d_seqs = nullptr;
+    uint32_t *d_p2 = nullptr, *d_e1 = nullptr, *d_x4 = nullptr;
+    size_t plane_chunks = 0;
+};
+
+struct Launch {
+    int bps, k, task_begin, n_tasks;
+};
+
+struct vapor_plan {
+    vapor_ctx* ctx = nullptr;
+    vapor_seqset* set = nullptr;
+    int64_t n_pairs = 0;
+    std::vector<DPair> hp;
+    std::vector<int32_t> status;
+    std::vector<DTask> tasks;
+    std::vector<int32_t> task_pairs;
+    std::vector<Launch> launches;
+    std::vector<int64_t> last_stats;
+    int range_words_cap = 1;
+    int64_t total_cap = 0;
+    DPair* d_pairs = nullptr;
+    DTask* d_tasks = nullptr;
+    int32_t* d_task_pairs = nullptr;
+    uint32_t* d_hits = nullptr;
+    uint8_t* d_hflags = nullptr;
+    unsigned long long* d_nhits = nullptr;
+    long long* d_stats = nullptr;
+    long long* h_stats = nullptr;  // pinned
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double t_join = 0, t_clean = 0, t_total = 0;
+    int n_retried = 0;
+    bool ran = false;
+};
+
+// ------------------------------------------------------------------------------------------
+extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION; }
+extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
+
+template <int BPS, int K>
+static hipError_t set_join_attr()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<BPS, K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<BPS>());
+}
+
+extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
+{
+    if (!out) return fail(VAPOR_E_ARG, "vapor_init: null out pointer");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(VAPOR_E_ARG, "vapor_init: no such device ordinal");
+    HIPCHK(hipSetDevice(device_ordinal));
+    vapor_ctx* c = new (std::nothrow) vapor_ctx();
+    if (!c) return fail(VAPOR_E_NOMEM, "vapor_init: out of memory");
+    c->device = device_ordinal;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(VAPOR_E_HIP, hipGetErrorString(e)); }
+    hipError_t a[8] = {set_join_attr<2, 10>(), set_join_attr<2, 20>(), set_join_attr<2, 30>(), set_join_attr<2, 40>(),
+                       set_join_attr<4, 10>(), set_join_attr<4, 20>(), set_join_attr<4, 30>(), set_join_attr<4, 40>()};
+    for (hipError_t x : a)
+        if (x != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(join): ") + hipGetErrorString(x)); }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(clean): ") + hipGetErrorString(e)); }
+    *out = c;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_destroy(vapor_ctx* c)
+{
+    if (!c) return VAPOR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
+{
+    if (!c || !name) return fail(VAPOR_E_ARG, "vapor_set_param: null argument");
+    if (!strcmp(name, "reads_per_task")) {
+        if (v < 1 || v > MAX_READS_PER_TASK) return fail(VAPOR_E_ARG, "reads_per_task out of range");
+        c->reads_per_task = (int)v;
+        return VAPOR_OK;
+    }
+    if (!strcmp(name, "max_pair_cap")) {
+        if (v < 1) return fail(VAPOR_E_ARG, "max_pair_cap out of range");
+        c->max_pair_cap = v;
+        return VAPOR_OK;
+    }
+    return fail(VAPOR_E_ARG, std::string("unknown parameter ") + name);
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int vapor_seqset_destroy(vapor_seqset* s)
+{
+    if (!s) return VAPOR_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipFree(s->d_seqs);
+    (void)hipFree(s->d_p2);
+    (void)hipFree(s->d_e1);
+    (void)hipFree(s->d_x4);
+    delete s;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* blob, const int64_t* off,
+                                   const int32_t* len, const uint8_t* flags, int32_t* seq_info, vapor_seqset** out)
+{
+    if (!ctx || !out || n_seqs < 0 || (n_seqs && (!blob || !off || !len)))
+        return fail(VAPOR_E_ARG, "vapor_seqset_create: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    vapor_seqset* s = new (std::nothrow) vapor_seqset();
+    if (!s) return fail(VAPOR_E_NOMEM, "out of memory");
+    s->ctx = ctx;
+    s->n = n_seqs;
+    s->h.resize((size_t)std::max(n_seqs, 1));
+    size_t asc = 0, pl = 0;
+    for (int32_t i = 0; i < n_seqs; ++i) {
+        if (len[i] < 0) { delete s; return fail(VAPOR_E_ARG, "negative sequence length"); }
+        SeqDesc& d = s->h[i];
+        memset(&d, 0, sizeof d);
+        size_t ch = ((size_t)len[i] + 31) / 32;
+        d.asc0 = (uint32_t)asc;
+        d.chunk0 = (uint32_t)pl;
+        d.len = len[i];
+        d.flags = flags ? flags[i] : 0;
+        asc += ch;
+        pl += ch + VP_PAD_CHUNKS;
+        if (pl > 0xFFFFFFF0ull) { delete s; return fail(VAPOR_E_ARG, "sequence set too large"); }
+    }
+    pl += VP_PAD_CHUNKS + 1;
+    s->plane_chunks = pl;
+    const size_t n_asc = asc;
+    // pinned staging: ASCII at 32-byte chunks + chunk -> sequence map
+    uint8_t* h_asc = nullptr;
+    uint32_t* h_map = nullptr;
+    uint8_t* d_asc = nullptr;
+    uint32_t* d_map = nullptr;
+    int rc = VAPOR_OK;
+#define SS_CHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) { rc = fail(VAPOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); goto done; } \
+    } while (0)
+    SS_CHK(hipHostMalloc((void**)&h_asc, std::max<size_t>(n_asc * 32, 32)));
+    SS_CHK(hipHostMalloc((void**)&h_map, std::max<size_t>(n_asc * 4, 4)));
+    for (int32_t i = 0; i < n_seqs; ++i) {
+        const SeqDesc& d = s->h[i];
+        size_t ch = ((size_t)d.len + 31) / 32;
+        uint8_t* dst = h_asc + (size_t)d.asc0 * 32;
+        memcpy(dst, blob + off[i], (size_t)d.len);
+        memset(dst + d.len, 0, ch * 32 - (size_t)d.len);
+        for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
+    }
+    SS_CHK(hipMalloc((void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
+    SS_CHK(hipMalloc((void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
+    SS_CHK(hipMalloc((void**)&s->d_e1, pl * sizeof(uint32_t)));
+    SS_CHK(hipMalloc((void**)&s->d_x4, pl * 4 * sizeof(uint32_t)));
+    SS_CHK(hipMalloc((void**)&d_asc, std::max<size_t>(n_asc * 32, 32)));
+    SS_CHK(hipMalloc((void**)&d_map, std::max<size_t>(n_asc * 4, 4)));
+    SS_CHK(hipMemsetAsync(s->d_p2, 0, pl * 2 * sizeof(uint32_t), ctx->stream));
+    SS_CHK(hipMemsetAsync(s->d_e1, 0, pl * sizeof(uint32_t), ctx->stream));
+    SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
+    SS_CHK(hipMemcpyAsync(s->d_seqs, s->h.data(), sizeof(SeqDesc) * s->h.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (n_asc) {
+        SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 32, hipMemcpyHostToDevice, ctx->stream));
+        SS_CHK(hipMemcpyAsync(d_map, h_map, n_asc * 4, hipMemcpyHostToDevice, ctx->stream));
+        unsigned grid = (unsigned)((n_asc + 255) / 256);
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_asc, s->d_seqs, n_seqs, d_map,
+                           (uint32_t)n_asc, s->d_p2, s->d_e1, s->d_x4);
+        SS_CHK(hipGetLastError());
+    }
+    SS_CHK(hipMemcpyAsync(s->h.data(), s->d_seqs, sizeof(SeqDesc) * s->h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    SS_CHK(hipStreamSynchronize(ctx->stream));
+    if (seq_info)
+        for (int32_t i = 0; i < n_seqs; ++i) {
+            seq_info[2 * i] = s->h[i].n_exc;
+            seq_info[2 * i + 1] = s->h[i].n_invalid;
+        }
+done:
+    if (h_asc) (void)hipHostFree(h_asc);
+    if (h_map) (void)hipHostFree(h_map);
+    if (d_asc) (void)hipFree(d_asc);
+    if (d_map) (void)hipFree(d_map);
+    if (rc != VAPOR_OK) { vapor_seqset_destroy(s); return rc; }
+    *out = s;
+    return VAPOR_OK;
+#undef SS_CHK
+}
+
+// ------------------------------------------------------------------------------------------
+static void plan_free_device(vapor_plan* p)
+{
+    (void)hipFree(p->d_pairs); p->d_pairs = nullptr;
+    (void)hipFree(p->d_tasks); p->d_tasks = nullptr;
+    (void)hipFree(p->d_task_pairs); p->d_task_pairs = nullptr;
+    (void)hipFree(p->d_hits); p->d_hits = nullptr;
+    (void)hipFree(p->d_hflags); p->d_hflags = nullptr;
+    (void)hipFree(p->d_nhits); p->d_nhits = nullptr;
+    (void)hipFree(p->d_stats); p->d_stats = nullptr;
+}
+
+extern "C" int vapor_plan_destroy(vapor_plan* p)
+{
+    if (!p) return VAPOR_OK;
+    (void)hipSetDevice(p->ctx->device);
+    plan_free_device(p);
+    if (p->h_stats) (void)hipHostFree(p->h_stats);
+    for (auto& e : p->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete p;
+    return VAPOR_OK;
+}
+
+static bool k_supported(int k) { return k == 10 || k == 20 || k == 30 || k == 40; }
+
+// lays out the hit workspace from hp[].cap and (re)allocates it
+static int plan_alloc_hits(vapor_plan* p)
+{
+    int64_t tot = 0;
+    for (auto& d : p->hp) {
+        d.hit_off = tot;
+        tot += (int64_t)((d.cap + 3u) & ~3u);
+    }
+    tot += 4;
+    (void)hipFree(p->d_hits); p->d_hits = nullptr;
+    (void)hipFree(p->d_hflags); p->d_hflags = nullptr;
+    HIPCHK(hipMalloc((void**)&p->d_hits, (size_t)tot * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&p->d_hflags, (size_t)tot));
+    p->total_cap = tot;
+    HIPCHK(hipMemcpyAsync(p->d_pairs, p->hp.data(), sizeof(DPair) * p->hp.size(), hipMemcpyHostToDevice, p->ctx->stream));
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pairs, const vapor_pair* pairs,
+                                 vapor_plan** out)
+{
+    if (!ctx || !set || !out || n_pairs < 0 || (n_pairs && !pairs))
+        return fail(VAPOR_E_ARG, "vapor_plan_create: null argument");
+    if (n_pairs > 0x7FFFFFF0LL) return fail(VAPOR_E_ARG, "too many pairs");
+    HIPCHK(hipSetDevice(ctx->device));
+    vapor_plan* p = new (std::nothrow) vapor_plan();
+    if (!p) return fail(VAPOR_E_NOMEM, "out of memory");
+    p->ctx = ctx;
+    p->set = set;
+    p->n_pairs = n_pairs;
+    p->hp.resize((size_t)std::max<int64_t>(n_pairs, 1));
+    memset(p->hp.data(), 0, sizeof(DPair) * p->hp.size());
+    p->status.assign((size_t)n_pairs, 0);
+    std::vector<int32_t> order;
+    order.reserve((size_t)n_pairs);
+    std::vector<uint8_t> mode((size_t)n_pairs, 2);
+    int rw = 1;
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const vapor_pair& a = pairs[i];
+        DPair& d = p->hp[i];
+        d.seq1 = a.seq1; d.seq2 = a.seq2; d.off2 = a.off2; d.k = a.k; d.flags = a.flags; d.cap = 0;
+        if (a.seq1 < 0 || a.seq1 >= set->n || a.seq2 < 0 || a.seq2 >= set->n || a.off2 < 0 || !k_supported(a.k)) {
+            p->status[i] = VAPOR_E_ARG;
+            d.seq1 = d.seq2 = 0;
+            continue;
+        }
+        const SeqDesc& s1 = set->h[a.seq1];
+        const SeqDesc& s2 = set->h[a.seq2];
+        if (s1.len > VAPOR_MAX_SEQ_LEN || s2.len > VAPOR_MAX_SEQ_LEN) { p->status[i] = VAPOR_E_ARG; continue; }
+        if (s1.len - a.k + 1 > 0 && s1.n_invalid > 0) { p->status[i] = VAPOR_E_KEYERROR; continue; }
+        int64_t n1 = s1.len, n2 = std::max(0, s2.len - a.off2);
+        int64_t cap = std::min(n1, n2) + ((n1 * n2) >> 17) + 1024;
+        d.cap = (uint32_t)std::min<int64_t>(cap, ctx->max_pair_cap);
+        mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : 2;
+        rw = std::max(rw, (s1.len + s2.len + 2 + 31) / 32);
+        if (s1.len - a.k + 1 > 0 && s2.len - a.k + 1 > 0) order.push_back((int32_t)i);
+    }
+    p->range_words_cap = rw;
+    // group pairs that share (mode, k, allele) into tasks of at most reads_per_task reads
+    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        const DPair &a = p->hp[x], &b = p->hp[y];
+        if (mode[x] != mode[y]) return mode[x] < mode[y];
+        if (a.k != b.k) return a.k < b.k;
+        if (a.seq2 != b.seq2) return a.seq2 < b.seq2;
+        return x < y;
+    });
+    struct TmpTask { DTask t; int bps; int64_t cost; };
+    std::vector<TmpTask> tmp;
+    for (size_t q = 0; q < order.size();) {
+        size_t e = q;
+        const DPair& a = p->hp[order[q]];
+        int m = mode[order[q]];
+        int64_t cost = set->h[a.seq2].len;
+        while (e < order.size() && (int)(e - q) < ctx->reads_per_task && mode[order[e]] == m &&
+               p->hp[order[e]].k == a.k && p->hp[order[e]].seq2 == a.seq2) {
+            cost += 2 * (int64_t)set->h[p->hp[order[e]].seq1].len;
+            ++e;
+        }
+        TmpTask t;
+        t.t.seq2 = a.seq2; t.t.k = a.k; t.t.n_reads = (int32_t)(e - q); t.t.first = (int32_t)q;
+        t.bps = m; t.cost = cost;
+        tmp.push_back(t);
+        q = e;
+    }
+    // one launch per (mode, k); inside a launch the longest tasks go first
+    std::stable_sort(tmp.begin(), tmp.end(), [](const TmpTask& a, const TmpTask& b) {
+        if (a.bps != b.bps) return a.bps < b.bps;
+        if (a.t.k != b.t.k) return a.t.k < b.t.k;
+        return a.cost > b.cost;
+    });
+    p->task_pairs = order;
+    p->tasks.reserve(tmp.size());
+    for (size_t q = 0; q < tmp.size(); ++q) {
+        if (q == 0 || tmp[q].bps != tmp[q - 1].bps || tmp[q].t.k != tmp[q - 1].t.k)
+            p->launches.push_back(Launch{tmp[q].bps, tmp[q].t.k, (int)q, 0});
+        p->launches.back().n_tasks++;
+        p->tasks.push_back(tmp[q].t);
+    }
+    int rc = VAPOR_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    chk(hipMalloc((void**)&p->d_pairs, sizeof(DPair) * p->hp.size()), "hipMalloc pairs");
+    chk(hipMalloc((void**)&p->d_tasks, sizeof(DTask) * std::max<size_t>(p->tasks.size(), 1)), "hipMalloc tasks");
+    chk(hipMalloc((void**)&p->d_task_pairs, sizeof(int32_t) * std::max<size_t>(order.size(), 1)), "hipMalloc task_pairs");
+    chk(hipMalloc((void**)&p->d_nhits, sizeof(unsigned long long) * p->hp.size()), "hipMalloc nhits");
+    chk(hipMalloc((void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
+    chk(hipHostMalloc((void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
+    for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
+    if (rc == VAPOR_OK && !p->tasks.empty())
+        chk(hipMemcpyAsync(p->d_tasks, p->tasks.data(), sizeof(DTask) * p->tasks.size(), hipMemcpyHostToDevice, ctx->stream), "copy tasks");
+    if (rc == VAPOR_OK && !order.empty())
+        chk(hipMemcpyAsync(p->d_task_pairs, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, ctx->stream), "copy task_pairs");
+    if (rc == VAPOR_OK) rc = plan_alloc_hits(p);
+    if (rc == VAPOR_OK) chk(hipStreamSynchronize(ctx->stream), "sync");
+    if (rc != VAPOR_OK) { vapor_plan_destroy(p); return rc; }
+    p->last_stats.assign((size_t)n_pairs * 16, 0);
+    *out = p;
+    return VAPOR_OK;
+}
+
+template <int BPS, int K>
+static void launch_join(vapor_plan* p, const Launch& L)
+{
+    const vapor_seqset* s = p->set;
+    hipLaunchKernelGGL((join_kernel<BPS, K>), dim3((unsigned)L.n_tasks), dim3(JOIN_THREADS), join_lds_bytes<BPS>(),
+                       p->ctx->stream, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
+                       p->d_task_pairs, p->d_hits, p->d_nhits);
+}
+
+static size_t clean_lds_bytes(int range_words_cap)
+{
+    size_t groups = (size_t)range_words_cap * 32 / 10 + 8;
+    return sizeof(uint32_t) * ((size_t)range_words_cap * 3 + groups);
+}
+
+static int plan_run_once(vapor_plan* p)
+{
+    vapor_ctx* c = p->ctx;
+    hipStream_t st = c->stream;
+    HIPCHK(hipEventRecord(p->ev[0], st));
+    HIPCHK(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), st));
+    for (const Launch& L : p->launches) {
+        if (L.bps == 2) {
+            if (L.k == 10) launch_join<2, 10>(p, L);
+            else if (L.k == 20) launch_join<2, 20>(p, L);
+            else if (L.k == 30) launch_join<2, 30>(p, L);
+            else launch_join<2, 40>(p, L);
+        } else {
+            if (L.k == 10) launch_join<4, 10>(p, L);
+            else if (L.k == 20) launch_join<4, 20>(p, L);
+            else if (L.k == 30) launch_join<4, 30>(p, L);
+            else launch_join<4, 40>(p, L);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(p->ev[1], st));
+    if (p->n_pairs > 0) {
+        size_t lds = clean_lds_bytes(p->range_words_cap);
+        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st, p->set->d_seqs,
+                           p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
+                           p->range_words_cap);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(p->ev[2], st));
+    if (p->n_pairs > 0)
+        HIPCHK(hipMemcpyAsync(p->h_stats, p->d_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->ev[3], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float a = 0, b = 0, t = 0;
+    HIPCHK(hipEventElapsedTime(&a, p->ev[0], p->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, p->ev[1], p->ev[2]));
+    HIPCHK(hipEventElapsedTime(&t, p->ev[0], p->ev[3]));
+    p->t_join = a; p->t_clean = b; p->t_total = t;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
+{
+    if (!p || (p->n_pairs && !stats)) return fail(VAPOR_E_ARG, "vapor_plan_run: null argument");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    p->n_retried = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        int rc = plan_run_once(p);
+        if (rc != VAPOR_OK) return rc;
+        // pairs whose hit count exceeded their slot: enlarge to the exact count and rerun
+        int64_t grow = 0;
+        for (int64_t i = 0; i < p->n_pairs; ++i) {
+            const long long* s = p->h_stats + 16 * i;
+            if (s[15] == VAPOR_E_OVERFLOW && s[0] <= p->ctx->max_pair_cap && (uint32_t)s[0] > p->hp[i].cap) {
+                p->hp[i].cap = (uint32_t)s[0];
+                ++grow;
+            }
+        }
+        if (!grow) break;
+        p->n_retried += (int)grow;
+        rc = plan_alloc_hits(p);
+        if (rc != VAPOR_OK) return rc;
+    }
+    for (int64_t i = 0; i < p->n_pairs; ++i) {
+        long long* s = p->h_stats + 16 * i;
+        if (p->status[i] != 0) {
+            for (int t = 0; t < 16; ++t) s[t] = 0;
+            s[1] = s[2] = -1;
+            s[15] = p->status[i];
+        }
+    }
+    memcpy(p->last_stats.data(), p->h_stats, sizeof(int64_t) * 16 * (size_t)p->n_pairs);
+    memcpy(stats, p->h_stats, sizeof(int64_t) * 16 * (size_t)p->n_pairs);
+    p->ran = true;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
+{
+    if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
+    double v[5] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried};
+    for (int i = 0; i < n && i < 5; ++i) ms[i] = v[i];
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_algorithmic_bytes(vapor_plan* p, int64_t* bytes, int64_t* cells)
+{
+    if (!p || !bytes || !cells) return fail(VAPOR_E_ARG, "null argument");
+    int64_t b = 0, c = 0;
+    for (int64_t i = 0; i < p->n_pairs; ++i) {
+        if (p->status[i] != 0) continue;
+        int64_t n1 = p->set->h[p->hp[i].seq1].len;
+        int64_t n2 = std::max<int64_t>(0, (int64_t)p->set->h[p->hp[i].seq2].len - p->hp[i].off2);
+        int64_t nh = p->ran ? p->last_stats[16 * i] : 0;
+        b += (3 * n1 + 7) / 8 + (3 * n2 + 7) / 8 + 8 * nh + 128;
+        c += n1 * n2;
+    }
+    *bytes = b;
+    *cells = c;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_fetch_hits(vapor_plan* p, int64_t n_sel, const int64_t* pair_idx, int32_t* hits_ji,
+                                     uint8_t* hit_flags, int64_t capacity, int64_t* hit_off)
+{
+    if (!p || n_sel < 0 || (n_sel && (!pair_idx || !hit_off))) return fail(VAPOR_E_ARG, "vapor_plan_fetch_hits: null argument");
+    if (!p->ran) return fail(VAPOR_E_ARG, "vapor_plan_fetch_hits: plan has not been run");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    std::vector<long long> off((size_t)n_sel + 1, 0), sel((size_t)std::max<int64_t>(n_sel, 1), 0);
+    for (int64_t q = 0; q < n_sel; ++q) {
+        int64_t i = pair_idx[q];
+        if (i < 0 || i >= p->n_pairs) return fail(VAPOR_E_ARG, "pair index out of range");
+        sel[q] = i;
+        int64_t n = (p->last_stats[16 * i + 15] == 0) ? p->last_stats[16 * i] : 0;
+        off[q + 1] = off[q] + n;
+    }
+    for (int64_t q = 0; q <= n_sel; ++q) hit_off[q] = off[q];
+    if (off[n_sel] > capacity) return fail(VAPOR_E_OVERFLOW, "hit buffer too small");
+    if (n_sel == 0 || off[n_sel] == 0) return VAPOR_OK;
+    if (!hits_ji) return fail(VAPOR_E_ARG, "null hit buffer");
+    long long *d_sel = nullptr, *d_off = nullptr;
+    int32_t* d_ji = nullptr;
+    uint8_t* d_fl = nullptr;
+    int rc = VAPOR_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    hipStream_t st = p->ctx->stream;
+    chk(hipMalloc((void**)&d_sel, sizeof(long long) * sel.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_off, sizeof(long long) * off.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_ji, sizeof(int32_t) * 2 * (size_t)off[n_sel]), "hipMalloc");
+    if (hit_flags) chk(hipMalloc((void**)&d_fl, (size_t)off[n_sel]), "hipMalloc");
+    if (rc == VAPOR_OK) {
+        chk(hipMemcpyAsync(d_sel, sel.data(), sizeof(long long) * sel.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, st), "copy");
+    }
+    if (rc == VAPOR_OK) {
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, p->d_pairs, d_sel, d_off, p->d_hits,
+                           p->d_hflags, d_ji, d_fl);
+        chk(hipGetLastError(), "gather launch");
+        chk(hipMemcpyAsync(hits_ji, d_ji, sizeof(int32_t) * 2 * (size_t)off[n_sel], hipMemcpyDeviceToHost, st), "copy");
+        if (hit_flags) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)off[n_sel], hipMemcpyDeviceToHost, st), "copy");
+        chk(hipStreamSynchronize(st), "sync");
+    }
+    (void)hipFree(d_sel); (void)hipFree(d_off); (void)hipFree(d_ji); (void)hipFree(d_fl);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int vapor_score_batch(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pairs, const vapor_pair* pairs,
+                                 int64_t* stats)
+{
+    vapor_plan* p = nullptr;
+    int rc = vapor_plan_create(ctx, set, n_pairs, pairs, &p);
+    if (rc != VAPOR_OK) return rc;
+    rc = vapor_plan_run(p, stats);
+    vapor_plan_destroy(p);
+    return rc;
+}
+
+extern "C" int vapor_dotplot_batch(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pairs, const vapor_pair* pairs,
+                                   int32_t* hits_ji, int64_t hits_capacity, int64_t* hit_off, int64_t* stats)
+{
+    if (!hit_off) return fail(VAPOR_E_ARG, "vapor_dotplot_batch: null hit_off");
+    vapor_plan* p = nullptr;
+    int rc = vapor_plan_create(ctx, set, n_pairs, pairs, &p);
+    if (rc != VAPOR_OK) return rc;
+    std::vector<int64_t> st((size_t)std::max<int64_t>(n_pairs, 1) * 16);
+    rc = vapor_plan_run(p, st.data());
+    if (rc == VAPOR_OK) {
+        std::vector<int64_t> idx((size_t)n_pairs);
+        std::iota(idx.begin(), idx.end(), 0);
+        rc = vapor_plan_fetch_hits(p, n_pairs, idx.data(), hits_ji, nullptr, hits_capacity, hit_off);
+        if (stats) memcpy(stats, st.data(), sizeof(int64_t) * 16 * (size_t)n_pairs);
+    }
+    vapor_plan_destroy(p);
+    return rc;
+}
+
+extern "C" int vapor_selfplot_qc(vapor_ctx* ctx, vapor_seqset* set, int32_t n, const int32_t* seq_idx, const int32_t* k,
+                                 int64_t* out)
+{
+    if (n < 0 || (n && (!seq_idx || !k || !out))) return fail(VAPOR_E_ARG, "vapor_selfplot_qc: null argument");
+    std::vector<vapor_pair> pr((size_t)n);
+    for (int32_t t = 0; t < n; ++t) pr[t] = vapor_pair{seq_idx[t], seq_idx[t], 0, k[t], 0u};
+    std::vector<int64_t> st((size_t)std::max(n, 1) * 16);
+    int rc = vapor_score_batch(ctx, set, n, pr.data(), st.data());
+    if (rc != VAPOR_OK) return rc;
+    for (int32_t t = 0; t < n; ++t) {
+        if (st[16 * t + 15] != 0) return fail((int)st[16 * t + 15], "vapor_selfplot_qc: pair failed");
+        out[3 * t] = st[16 * t];
+        out[3 * t + 1] = st[16 * t + 7];
+        out[3 * t + 2] = st[16 * t + 8];
+    }
+    return VAPOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Cleaning and reductions on caller-supplied hit lists: what clean_dotdata_diagnal_and_anti_diagnal
+// (SF:432-448), clean_dotdata_diagnal_m1b / clean_dotdata_anti_diagnal_m1b (SF:404-430) and the
+// eu_dis_* reductions do when handed an explicit dot list instead of a fresh dotdata() result.
+extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* hits_ji, const int64_t* off,
+                                const uint32_t* flags, int64_t* stats, uint8_t* hit_flags)
+{
+    if (!ctx || n_lists < 0 || (n_lists && (!off || !stats))) return fail(VAPOR_E_ARG, "vapor_clean_hits: null argument");
+    if (n_lists == 0) return VAPOR_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t tot = off[n_lists];
+    if (tot && !hits_ji) return fail(VAPOR_E_ARG, "vapor_clean_hits: null hit list");
+    std::vector<SeqDesc> sd((size_t)n_lists * 2);
+    std::vector<DPair> dp((size_t)n_lists);
+    std::vector<unsigned long long> nh((size_t)n_lists);
+    std::vector<uint32_t> packed((size_t)std::max<int64_t>(tot, 1));
+    int rw = 1;
+    for (int64_t t = 0; t < n_lists; ++t) {
+        int mi = 0, mj = 0;
+        for (int64_t h = off[t]; h < off[t + 1]; ++h) {
+            int j = hits_ji[2 * h], i = hits_ji[2 * h + 1];
+            if (j < 0 || i < 0 || j > VAPOR_MAX_SEQ_LEN || i > VAPOR_MAX_SEQ_LEN)
+                return fail(VAPOR_E_ARG, "vapor_clean_hits: coordinate out of range");
+            mi = std::max(mi, i); mj = std::max(mj, j);
+            packed[h] = ((uint32_t)j << 16) | (uint32_t)i;
+        }
+        memset(&sd[2 * t], 0, 2 * sizeof(SeqDesc));
+        sd[2 * t].len = mi + 1;
+        sd[2 * t + 1].len = mj + 1;
+        DPair& d = dp[t];
+        d.seq1 = (int32_t)(2 * t); d.seq2 = (int32_t)(2 * t + 1); d.off2 = 0; d.k = 10;
+        d.flags = flags ? flags[t] : 3u;
+        d.cap = (uint32_t)(off[t + 1] - off[t]);
+        d.hit_off = off[t];
+        nh[t] = (unsigned long long)(off[t + 1] - off[t]);
+        rw = std::max(rw, (mi + mj + 4 + 31) / 32);
+    }
+    SeqDesc* d_sd = nullptr; DPair* d_dp = nullptr; unsigned long long* d_nh = nullptr;
+    uint32_t* d_hits = nullptr; uint8_t* d_fl = nullptr; long long* d_st = nullptr;
+    int rc = VAPOR_OK;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    hipStream_t st = ctx->stream;
+    chk(hipMalloc((void**)&d_sd, sizeof(SeqDesc) * sd.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_dp, sizeof(DPair) * dp.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_nh, sizeof(unsigned long long) * nh.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_hits, sizeof(uint32_t) * packed.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_fl, packed.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_st, sizeof(long long) * 16 * (size_t)n_lists), "hipMalloc");
+    if (rc == VAPOR_OK) {
+        chk(hipMemcpyAsync(d_sd, sd.data(), sizeof(SeqDesc) * sd.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemcpyAsync(d_dp, dp.data(), sizeof(DPair) * dp.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemcpyAsync(d_nh, nh.data(), sizeof(unsigned long long) * nh.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice, st), "copy");
+    }
+    if (rc == VAPOR_OK) {
+        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw), st, d_sd, d_dp,
+                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw);
+        chk(hipGetLastError(), "clean launch");
+        chk(hipMemcpyAsync(stats, d_st, sizeof(long long) * 16 * (size_t)n_lists, hipMemcpyDeviceToHost, st), "copy");
+        if (hit_flags && tot) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)tot, hipMemcpyDeviceToHost, st), "copy");
+        chk(hipStreamSynchronize(st), "sync");
+    }
+    (void)hipFree(d_sd); (void)hipFree(d_dp); (void)hipFree(d_nh); (void)hipFree(d_hits); (void)hipFree(d_fl); (void)hipFree(d_st);
+    return rc;
+}

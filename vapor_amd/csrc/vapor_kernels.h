@@ -1,0 +1,578 @@
+// vapor_kernels.h - device code of libvapor_hip.so (gfx950 / CDNA4 only).
+//
+// Three kernels, all integer/bit work (no MFMA: there is no dense contraction on this path):
+//
+//   pack_kernel   ASCII -> bit planes in HBM (2-bit bases, 1-bit "not ACGT", 4-bit symbols)
+//   join_kernel   kmerhits (SF:951-983) as an LDS hash join.  One workgroup owns one allele
+//                 window: it builds a chained hash table of the window's k-mers in LDS once
+//                 and streams up to `reads_per_task` reads through it, each lane owning one
+//                 read position and probing with the k-mer and its reverse complement.
+//   clean_kernel  dis_cluster / dis_cluster_2 (SF:551-580) as occupancy bitmaps + ranked group
+//                 counters in LDS, then the integer reductions of SF:705-733 and SF:1154-1171.
+//
+// SF = /root/reference/vapor_vali/Simple_function.pyx.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vapor {
+
+// ------------------------------------------------------------------------------------------
+// device-side records
+// ------------------------------------------------------------------------------------------
+struct SeqDesc {       // 32 B
+    uint32_t chunk0;   // first 32-base chunk of this sequence in the planes
+    int32_t len;
+    int32_t n_exc;     // symbols outside upper-case ACGT
+    int32_t n_invalid; // symbols outside invert_base's alphabet (after IUPAC folding)
+    uint32_t asc0;     // first 32-byte chunk in the ASCII staging blob (pack only)
+    uint32_t flags;
+    uint32_t pad[2];
+};
+
+struct DPair {         // 32 B
+    int32_t seq1, seq2, off2, k;
+    uint32_t flags, cap;
+    int64_t hit_off;
+};
+
+struct DTask {         // 16 B
+    int32_t seq2, k, n_reads, first;
+};
+
+// plane geometry: every sequence starts on a 32-base chunk; a chunk is 2 words of the 2-bit
+// plane, 1 word of the exception plane, 4 words of the 4-bit plane.
+#define VP_P2_WORDS_PER_CHUNK 2
+#define VP_X4_WORDS_PER_CHUNK 4
+#define VP_PAD_CHUNKS 3  // zeroed chunks after each sequence: window reads may run this far
+
+constexpr int TA_LOG2 = 15;            // allele k-mer positions per hash-table tile
+constexpr int TA = 1 << TA_LOG2;
+constexpr int NB_LOG2 = 14;            // hash buckets
+constexpr int NB = 1 << NB_LOG2;
+constexpr int JOIN_THREADS = 1024;
+constexpr int MAX_READS_PER_TASK = 64;
+constexpr int CLEAN_THREADS = 256;
+constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
+
+// per-hit working flags inside clean_kernel (upper nibble) and the public ones (lower)
+#define HF_C1 1u
+#define HF_C2D 2u
+#define HF_C2A 4u
+#define WF_D1 16u
+#define WF_A1 32u
+
+// ------------------------------------------------------------------------------------------
+// symbol codes (pack): 0-3 ACGT, 4-7 acgt, 8 N (and folded IUPAC), 9 n, 15 anything else
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sym_code(uint32_t c, bool upper)
+{
+    uint32_t lower = (c >= 'a' && c <= 'z') ? 1u : 0u;
+    uint32_t u = lower ? c - 32u : c;
+    uint32_t base;
+    switch (u) {
+    case 'A': base = 0; break;
+    case 'C': base = 1; break;
+    case 'G': base = 2; break;
+    case 'T': base = 3; break;
+    case 'N': case 'R': case 'Y': case 'S': case 'W': case 'K': case 'M': case 'B': case 'D': case 'H': case 'V':
+        base = 8; break;
+    default:
+        return 15u;
+    }
+    if (lower && !upper) return base < 4 ? base + 4u : 9u;
+    return base;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ ascii, SeqDesc* seqs,
+                                                  int n_seqs, const uint32_t* __restrict__ chunk_seq,
+                                                  uint32_t n_chunks, uint32_t* __restrict__ p2,
+                                                  uint32_t* __restrict__ e1, uint32_t* __restrict__ x4)
+{
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;   // ASCII chunk index
+    if (c >= n_chunks) return;
+    uint32_t s = chunk_seq[c];
+    SeqDesc sd = seqs[s];
+    uint32_t local = c - sd.asc0;                // chunk inside the sequence
+    int base = (int)local * 32;
+    int valid = sd.len - base;
+    if (valid > 32) valid = 32;
+    const uint4* src = reinterpret_cast<const uint4*>(ascii + (size_t)c * 32);
+    uint4 q0 = src[0], q1 = src[1];
+    uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    bool upper = sd.flags & 1u;
+    uint32_t o2[2] = {0, 0}, oe = 0, o4[4] = {0, 0, 0, 0};
+    int nexc = 0, ninv = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        uint32_t ch = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
+        uint32_t code = (t < valid) ? sym_code(ch, upper) : 0u;
+        bool real = t < valid;
+        o4[t >> 3] |= code << ((t & 7) * 4);
+        o2[t >> 4] |= ((code < 8u) ? (code & 3u) : 0u) << ((t & 15) * 2);
+        if (real && code >= 4u) { oe |= 1u << t; ++nexc; }
+        if (real && code == 15u) ++ninv;
+    }
+    size_t pc = (size_t)sd.chunk0 + local;
+    p2[pc * 2] = o2[0];
+    p2[pc * 2 + 1] = o2[1];
+    e1[pc] = oe;
+    uint4 o;
+    o.x = o4[0]; o.y = o4[1]; o.z = o4[2]; o.w = o4[3];
+    reinterpret_cast<uint4*>(x4)[pc] = o;
+    if (nexc) atomicAdd(&seqs[s].n_exc, nexc);
+    if (ninv) atomicAdd(&seqs[s].n_invalid, ninv);
+}
+
+// ------------------------------------------------------------------------------------------
+// k-mer keys
+// ------------------------------------------------------------------------------------------
+template <int BPS, int K>
+struct KeyT {
+    static constexpr int BITS = BPS * K;
+    static constexpr int NW = (BITS + 31) / 32;
+    static constexpr int TOPBITS = BITS - 32 * (NW - 1);
+    static constexpr uint32_t TOPMASK = TOPBITS == 32 ? 0xFFFFFFFFu : ((1u << TOPBITS) - 1u);
+    uint32_t w[NW];
+    __device__ __forceinline__ bool operator==(const KeyT& o) const
+    {
+        bool e = true;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) e = e && (w[t] == o.w[t]);
+        return e;
+    }
+};
+
+// window of K symbols starting at symbol `pos` of a packed plane (LDS or global)
+template <int BPS, int K, typename P>
+__device__ __forceinline__ KeyT<BPS, K> extract_key(P plane, uint32_t pos)
+{
+    using KT = KeyT<BPS, K>;
+    uint32_t bit = pos * BPS;
+    uint32_t wi = bit >> 5, sh = bit & 31u;
+    uint32_t raw[KT::NW + 1];
+#pragma unroll
+    for (int t = 0; t <= KT::NW; ++t) raw[t] = plane[wi + t];
+    KT k;
+#pragma unroll
+    for (int t = 0; t < KT::NW; ++t) k.w[t] = __builtin_amdgcn_alignbit(raw[t + 1], raw[t], sh);
+    k.w[KT::NW - 1] &= KT::TOPMASK;
+    return k;
+}
+
+template <int BPS>
+__device__ __forceinline__ uint32_t rev_syms(uint32_t x)
+{
+    x = __brev(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    if (BPS == 4) x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    return x;
+}
+
+// reverse complement of a key: invert_base (SF:19-20) applied to the reversed k-mer (SF:1421)
+template <int BPS, int K>
+__device__ __forceinline__ KeyT<BPS, K> revcomp_key(const KeyT<BPS, K>& k)
+{
+    using KT = KeyT<BPS, K>;
+    constexpr int SH = 32 * KT::NW - KT::BITS;
+    uint32_t tmp[KT::NW + 1];
+#pragma unroll
+    for (int t = 0; t < KT::NW; ++t) tmp[t] = rev_syms<BPS>(k.w[KT::NW - 1 - t]);
+    tmp[KT::NW] = 0;
+    KT r;
+#pragma unroll
+    for (int t = 0; t < KT::NW; ++t) {
+        uint32_t v = SH ? __builtin_amdgcn_alignbit(tmp[t + 1], tmp[t], SH) : tmp[t];
+        if (BPS == 2) {
+            v = ~v;
+        } else {
+            uint32_t m = (v >> 3) & 0x11111111u;       // N / n / invalid keep their code
+            v ^= 0x33333333u & ~(m * 3u);
+        }
+        r.w[t] = v;
+    }
+    r.w[KT::NW - 1] &= KT::TOPMASK;
+    return r;
+}
+
+template <int BPS, int K>
+__device__ __forceinline__ uint32_t hash_key(const KeyT<BPS, K>& k)
+{
+    using KT = KeyT<BPS, K>;
+    uint32_t x = k.w[0] * 0x9E3779B1u;
+    if (KT::NW > 1) x ^= k.w[1] * 0x85EBCA77u;
+    if (KT::NW > 2) x ^= k.w[2] * 0xC2B2AE3Du;
+    if (KT::NW > 3) x ^= k.w[3] * 0x27D4EB2Fu;
+    if (KT::NW > 4) x ^= k.w[4] * 0x165667B1u;
+    if (KT::NW > 1) { x ^= x >> 15; x *= 0x2C1B3C6Du; }
+    return x >> (32 - NB_LOG2);
+}
+
+// any nibble == 15 (a symbol that matches nothing; such allele k-mers are left out of the table)
+template <int BPS, int K>
+__device__ __forceinline__ bool key_has_invalid(const KeyT<BPS, K>& k)
+{
+    uint32_t any = 0;
+#pragma unroll
+    for (int t = 0; t < KeyT<BPS, K>::NW; ++t) {
+        uint32_t x = k.w[t];
+        any |= x & (x >> 1) & (x >> 2) & (x >> 3) & 0x11111111u;
+    }
+    return any != 0;
+}
+
+// any exception bit in [pos, pos+K) of a 1-bit plane
+template <int K, typename P>
+__device__ __forceinline__ bool any_exc(P plane, uint32_t pos)
+{
+    uint32_t wi = pos >> 5, sh = pos & 31u;
+    uint32_t w0 = plane[wi], w1 = plane[wi + 1], w2 = plane[wi + 2];
+    uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+    uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    if (K <= 32) return (lo & (K == 32 ? 0xFFFFFFFFu : ((1u << (K & 31)) - 1u))) != 0;
+    return (lo | (hi & ((1u << ((K - 32) & 31)) - 1u))) != 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// join kernel
+// ------------------------------------------------------------------------------------------
+template <int BPS>
+__host__ __device__ constexpr int tile_words() { return ((TA + 64) * BPS) / 32 + 8; }
+constexpr int etile_words() { return (TA + 64) / 32 + 8; }
+
+template <int BPS>
+constexpr size_t join_lds_bytes()
+{
+    return sizeof(uint32_t) * NB + sizeof(uint16_t) * TA + sizeof(uint32_t) * tile_words<BPS>() +
+           (BPS == 2 ? sizeof(uint32_t) * etile_words() : 0) + sizeof(unsigned long long) * MAX_READS_PER_TASK;
+}
+
+template <int BPS, int K>
+__global__ __launch_bounds__(JOIN_THREADS) void join_kernel(
+    const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
+    const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
+    const int32_t* __restrict__ task_pairs, uint32_t* __restrict__ hits, unsigned long long* __restrict__ n_hits)
+{
+    using KT = KeyT<BPS, K>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* head = lds;                                                   // NB
+    uint32_t* tile = head + NB;                                             // tile_words
+    uint32_t* etile = tile + tile_words<BPS>();                             // etile_words (BPS 2)
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + (BPS == 2 ? etile_words() : 0));
+    uint16_t* next = reinterpret_cast<uint16_t*>(cnt + MAX_READS_PER_TASK); // TA
+
+    const int tid = threadIdx.x;
+    const DTask task = tasks[blockIdx.x];
+    const SeqDesc s2 = seqs[task.seq2];
+    const int nk2 = s2.len - K + 1;
+    const uint32_t* plane = (BPS == 2) ? p2 : x4;
+    constexpr int WPC = (BPS == 2) ? VP_P2_WORDS_PER_CHUNK : VP_X4_WORDS_PER_CHUNK;
+    const bool exc2 = (BPS == 2) && s2.n_exc > 0;
+
+    if (tid < MAX_READS_PER_TASK) cnt[tid] = 0ULL;
+
+    for (int ts = 0; ts < nk2; ts += TA) {
+        const int tn = min(TA, nk2 - ts);
+        __syncthreads();                       // previous tile fully probed
+        for (int x = tid; x < NB; x += JOIN_THREADS) head[x] = EMPTY32;
+        {
+            const uint32_t* src = plane + (size_t)s2.chunk0 * WPC + (((size_t)ts * BPS) >> 5);
+            const int nw = ((tn + K - 1) * BPS + 31) / 32 + 2;
+            for (int x = tid; x < nw; x += JOIN_THREADS) tile[x] = src[x];
+            if (exc2) {
+                const uint32_t* es = e1 + (size_t)s2.chunk0 + (ts >> 5);
+                const int ne = (tn + K - 1 + 31) / 32 + 3;
+                for (int x = tid; x < ne; x += JOIN_THREADS) etile[x] = es[x];
+            }
+        }
+        __syncthreads();
+        // ---- build: chained hash table of the tile's k-mers ------------------------------
+        for (int p = tid; p < tn; p += JOIN_THREADS) {
+            KT key = extract_key<BPS, K>(tile, (uint32_t)p);
+            bool ok;
+            if (BPS == 2) ok = !(exc2 && any_exc<K>(etile, (uint32_t)p));
+            else ok = !key_has_invalid<BPS, K>(key);
+            if (ok) {
+                uint32_t old = atomicExch(&head[hash_key<BPS, K>(key)], (uint32_t)p);
+                next[p] = (uint16_t)old;       // EMPTY32 -> 0xFFFF
+            }
+        }
+        __syncthreads();
+        // ---- probe: every read of the task, forward and reverse-complement k-mers -----------
+        for (int r = 0; r < task.n_reads; ++r) {
+            const DPair pr = pairs[task_pairs[task.first + r]];
+            const SeqDesc s1 = seqs[pr.seq1];
+            const int nk1 = s1.len - K + 1;
+            const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
+            const uint32_t* re = e1 + (size_t)s1.chunk0;
+            const bool exc1 = (BPS == 2) && s1.n_exc > 0;
+            uint32_t* out = hits + pr.hit_off;
+            for (int i = tid; i < nk1; i += JOIN_THREADS) {
+                if (exc1 && any_exc<K>(re, (uint32_t)i)) continue;
+                KT kf = extract_key<BPS, K>(rplane, (uint32_t)i);
+                KT kr = revcomp_key<BPS, K>(kf);
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    const KT& key = o ? kr : kf;
+                    uint32_t e = head[hash_key<BPS, K>(key)];
+                    while (e != EMPTY32) {
+                        KT a = extract_key<BPS, K>(tile, e);
+                        if (a == key) {
+                            int jf = ts + (int)e;
+                            if (jf >= pr.off2) {
+                                unsigned long long slot = atomicAdd(&cnt[r], 1ULL);
+                                if (slot < (unsigned long long)pr.cap)
+                                    out[slot] = ((uint32_t)(jf - pr.off2) << 16) | (uint32_t)i;
+                            }
+                        }
+                        uint32_t nx = next[e];
+                        e = (nx == 0xFFFFu) ? EMPTY32 : nx;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < task.n_reads) n_hits[task_pairs[task.first + tid]] = cnt[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// clean kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+struct CleanShared {
+    int min_j, max_j, n_diag, n_lower;
+    int c1_kept, c2_kept, c2_count10, c2_kept_diag;
+    unsigned long long c1_sum_abs;
+    unsigned int n_groups, max_group, scan_carry;
+    unsigned int wave_tot[4];
+};
+
+// One pass of 1-D gap clustering (dis_cluster SF:551-564 / dis_cluster_2 SF:566-580) over the
+// hits selected by (flags & need_clear) == 0, on value v = AXIS_A ? i + j : i - j + vbias.
+// Values closer than 10 to their sorted predecessor join its group; gid(v) is the rank of the
+// group's first occupied bin.  Afterwards, for every selected hit, set_gt10 is OR-ed into its
+// flag byte when its group has more than 10 members, and set_rule when the group passes
+// dis_cluster's rule (more than 50 members, or maximal size when no group has more than 50).
+template <bool AXIS_A>
+__device__ void cluster_axis(const uint32_t* __restrict__ hits, uint8_t* __restrict__ hflags, long long n,
+                             int vbias, int range_words, uint32_t* bm, uint32_t* sb, uint32_t* wrank,
+                             uint32_t* gcnt, CleanShared* sh, uint32_t need_clear, uint32_t set_gt10,
+                             uint32_t set_rule)
+{
+    const int tid = threadIdx.x;
+    for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
+    if (tid == 0) { sh->max_group = 0; }
+    __syncthreads();
+    // 1. occupancy bitmap
+    for (long long h = tid; h < n; h += CLEAN_THREADS) {
+        if (need_clear && (hflags[h] & need_clear)) continue;
+        uint32_t x = hits[h];
+        int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+        int v = AXIS_A ? (i + j) : (i - j + vbias);
+        atomicOr(&bm[v >> 5], 1u << (v & 31));
+    }
+    __syncthreads();
+    // 2. group starts: occupied bins with no occupied bin among the 9 below
+    int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
+    int w0 = tid * per, w1 = min(w0 + per, range_words);
+    uint32_t local = 0;
+    for (int w = w0; w < w1; ++w) {
+        uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
+        unsigned long long y = ((unsigned long long)cur << 32) | prev;
+        unsigned long long sm = (y << 1) | (y << 2) | (y << 3) | (y << 4) | (y << 5) | (y << 6) | (y << 7) |
+                                (y << 8) | (y << 9);
+        uint32_t st = cur & ~(uint32_t)(sm >> 32);
+        sb[w] = st;
+        local += __popc(st);
+    }
+    // exclusive scan of `local` over the block
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) sh->wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int q = 0; q < (tid >> 6); ++q) base += sh->wave_tot[q];
+    uint32_t run = base + incl - local;
+    for (int w = w0; w < w1; ++w) {
+        wrank[w] = run;
+        run += __popc(sb[w]);
+    }
+    if (tid == CLEAN_THREADS - 1) sh->n_groups = base + incl;
+    __syncthreads();
+    const uint32_t ng = sh->n_groups;
+    for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) gcnt[g] = 0;
+    __syncthreads();
+    // 3. group sizes
+    for (long long h = tid; h < n; h += CLEAN_THREADS) {
+        if (need_clear && (hflags[h] & need_clear)) continue;
+        uint32_t x = hits[h];
+        int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+        int v = AXIS_A ? (i + j) : (i - j + vbias);
+        uint32_t g = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+        atomicAdd(&gcnt[g], 1u);
+    }
+    __syncthreads();
+    if (set_rule) {
+        uint32_t m = 0;
+        for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) m = max(m, gcnt[g]);
+        m = (uint32_t)wave_max_i32((int)m);
+        if ((tid & 63) == 0) atomicMax(&sh->max_group, m);
+        __syncthreads();
+    }
+    const uint32_t mx = sh->max_group;
+    // 4. flags
+    for (long long h = tid; h < n; h += CLEAN_THREADS) {
+        uint32_t f = hflags[h];
+        if (need_clear && (f & need_clear)) continue;
+        uint32_t x = hits[h];
+        int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+        int v = AXIS_A ? (i + j) : (i - j + vbias);
+        uint32_t g = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+        uint32_t c = gcnt[g];
+        if (set_gt10 && c > 10u) f |= set_gt10;
+        if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
+        hflags[h] = (uint8_t)f;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
+    const SeqDesc* __restrict__ seqs, const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
+    const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
+    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ CleanShared sh;
+    const int tid = threadIdx.x;
+    const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
+    const DPair pr = pairs[p];
+    long long* st = stats + (size_t)p * 16;
+    const unsigned long long nh = n_hits[p];
+    if (nh > (unsigned long long)pr.cap || nh == 0ULL) {
+        if (tid < 16) {
+            long long v = 0;
+            if (tid == 0) v = (long long)nh;
+            if (tid == 1 || tid == 2) v = -1;
+            if (tid == 15 && nh) v = -2;      // VAPOR_E_OVERFLOW: rerun with cap >= n_hits
+            st[tid] = v;
+        }
+        return;
+    }
+    const long long n = (long long)nh;
+    const uint32_t* hits = hits_all + pr.hit_off;
+    uint8_t* hflags = hflags_all + pr.hit_off;
+    const int len1 = seqs[pr.seq1].len, len2 = seqs[pr.seq2].len;
+    const int range = len1 + len2 + 2;
+    const int range_words = min((range + 31) >> 5, range_words_cap);
+    uint32_t* bm = lds;
+    uint32_t* sb = bm + range_words_cap;
+    uint32_t* wrank = sb + range_words_cap;
+    uint32_t* gcnt = wrank + range_words_cap;
+
+    if (tid == 0) {
+        sh.min_j = 0x7FFFFFFF; sh.max_j = -1; sh.n_diag = 0; sh.n_lower = 0;
+        sh.c1_kept = 0; sh.c2_kept = 0; sh.c2_count10 = 0; sh.c2_kept_diag = 0; sh.c1_sum_abs = 0ULL;
+    }
+    __syncthreads();
+    // pass 0: first/last j, diagonal and lower-triangle counts; clear the flag bytes
+    {
+        int mn = 0x7FFFFFFF, mx = -1, nd = 0, nl = 0;
+        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+            uint32_t x = hits[h];
+            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            mn = min(mn, j); mx = max(mx, j);
+            nd += (j == i); nl += (j > i);
+            hflags[h] = 0;
+        }
+        mn = wave_min_i32(mn); mx = wave_max_i32(mx); nd = wave_sum_i32(nd); nl = wave_sum_i32(nl);
+        if ((tid & 63) == 0) {
+            atomicMin(&sh.min_j, mn); atomicMax(&sh.max_j, mx);
+            atomicAdd(&sh.n_diag, nd); atomicAdd(&sh.n_lower, nl);
+        }
+    }
+    __syncthreads();
+    const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u;
+    if (c1 || c2)   // i - j over all dots: C1's diagonal groups (>10) and C2's diagonal step
+        cluster_axis<false>(hits, hflags, n, len2, range_words, bm, sb, wrank, gcnt, &sh, 0u,
+                            c1 ? WF_D1 : 0u, c2 ? HF_C2D : 0u);
+    if (c1)         // i + j over all dots: C1's anti-diagonal groups
+        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, &sh, 0u, WF_A1, 0u);
+    if (c2)         // i + j over the dots the diagonal step left: C2's anti-diagonal step
+        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, &sh, HF_C2D, 0u, HF_C2A);
+    // final pass: reductions and public flags
+    {
+        int k1 = 0, k2 = 0, c10 = 0, kd = 0;
+        long long sabs = 0;
+        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+            uint32_t f = hflags[h];
+            uint32_t x = hits[h];
+            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            int ad = j > i ? j - i : i - j;
+            uint32_t pub = f & (HF_C2D | HF_C2A);
+            if (f & (WF_D1 | WF_A1)) { pub |= HF_C1; ++k1; sabs += ad; }
+            if (f & (HF_C2D | HF_C2A)) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
+            kd += (f & HF_C2D) ? 1 : 0;
+            hflags[h] = (uint8_t)pub;
+        }
+        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
+        sabs = wave_sum_i64(sabs);
+        if ((tid & 63) == 0) {
+            atomicAdd(&sh.c1_kept, k1); atomicAdd(&sh.c2_kept, k2); atomicAdd(&sh.c2_count10, c10);
+            atomicAdd(&sh.c2_kept_diag, kd); atomicAdd(&sh.c1_sum_abs, (unsigned long long)sabs);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st[0] = n; st[1] = sh.min_j; st[2] = sh.max_j; st[3] = sh.c1_kept; st[4] = (long long)sh.c1_sum_abs;
+        st[5] = sh.c2_kept; st[6] = sh.c2_count10; st[7] = sh.n_diag; st[8] = sh.n_lower; st[9] = sh.c2_kept_diag;
+        st[10] = 0; st[11] = 0; st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0;
+    }
+}
+
+// copies the hits (unpacked to int32 j, i) and flag bytes of selected pairs to a dense buffer
+__global__ __launch_bounds__(256) void gather_kernel(const DPair* __restrict__ pairs, const long long* __restrict__ sel,
+                                                    const long long* __restrict__ out_off,
+                                                    const uint32_t* __restrict__ hits, const uint8_t* __restrict__ hflags,
+                                                    int32_t* __restrict__ out_ji, uint8_t* __restrict__ out_flags)
+{
+    const long long p = sel[blockIdx.x];
+    const DPair pr = pairs[p];
+    const long long o = out_off[blockIdx.x], n = out_off[blockIdx.x + 1] - o;
+    for (long long h = threadIdx.x; h < n; h += blockDim.x) {
+        uint32_t x = hits[pr.hit_off + h];
+        out_ji[2 * (o + h)] = (int32_t)(x >> 16);
+        out_ji[2 * (o + h) + 1] = (int32_t)(x & 0xFFFFu);
+        if (out_flags) out_flags[o + h] = hflags[pr.hit_off + h];
+    }
+}
+
+}  // namespace vapor

@@ -1,0 +1,181 @@
+"""Thin object layer over the C ABI: contexts, resident sequence sets and plans.
+
+Device memory stays inside libvapor_hip.so; numpy arrays cross the boundary.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _as_bytes(s) -> bytes:
+    return s if isinstance(s, (bytes, bytearray)) else s.encode("latin-1", "replace")
+
+
+class SeqSet:
+    """Sequences packed on the device.  `n_exc[s]` = symbols outside upper-case ACGT,
+    `n_invalid[s]` = symbols outside invert_base's alphabet after IUPAC folding."""
+
+    def __init__(self, engine: "Engine", seqs: Sequence, upper: Optional[Sequence[bool]] = None):
+        self.engine = engine
+        bs = [_as_bytes(s) for s in seqs]
+        self.n = len(bs)
+        self.lens = np.array([len(b) for b in bs], dtype=np.int32)
+        off = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum(self.lens, out=off[1:])
+        blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
+        flags = np.zeros(max(self.n, 1), dtype=np.uint8)
+        if upper is not None:
+            flags[:self.n] = np.asarray(upper, dtype=bool).astype(np.uint8) * L.SEQ_UPPER
+        info = np.zeros(2 * max(self.n, 1), dtype=np.int32)
+        h = ctypes.c_void_p()
+        lib = L.load()
+        L.check(lib.vapor_seqset_create(engine._ctx, self.n, L.ptr(blob, ctypes.c_uint8), L.ptr(off, ctypes.c_int64),
+                                        L.ptr(self.lens if self.n else np.zeros(1, np.int32), ctypes.c_int32),
+                                        L.ptr(flags, ctypes.c_uint8), L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+        self._h = h
+        self.n_exc = info[0::2][:self.n].copy()
+        self.n_invalid = info[1::2][:self.n].copy()
+
+    def close(self) -> None:
+        if self._h:
+            L.load().vapor_seqset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    def __init__(self, engine: "Engine", seqset: SeqSet, pairs: np.ndarray):
+        self.engine = engine
+        self.seqset = seqset
+        self.pairs = np.ascontiguousarray(pairs, dtype=L.PAIR_DTYPE)
+        self.n = len(self.pairs)
+        h = ctypes.c_void_p()
+        L.check(L.load().vapor_plan_create(engine._ctx, seqset._h, self.n, self.pairs.ctypes.data_as(ctypes.c_void_p),
+                                           ctypes.byref(h)))
+        self._h = h
+        self.stats = np.zeros((max(self.n, 1), L.STATS_STRIDE), dtype=np.int64)
+
+    def run(self) -> np.ndarray:
+        """One pass of the hot path; returns the (n_pairs, 16) int64 statistics."""
+        L.check(L.load().vapor_plan_run(self._h, L.ptr(self.stats, ctypes.c_int64)))
+        return self.stats[:self.n]
+
+    def timings(self) -> dict:
+        ms = np.zeros(5, dtype=np.float64)
+        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 5))
+        return {"join_ms": ms[0], "clean_ms": ms[1], "total_ms": ms[2], "join_launches": int(ms[3]),
+                "retried_pairs": int(ms[4])}
+
+    def algorithmic(self) -> Tuple[int, int]:
+        b = ctypes.c_int64()
+        c = ctypes.c_int64()
+        L.check(L.load().vapor_plan_algorithmic_bytes(self._h, ctypes.byref(b), ctypes.byref(c)))
+        return b.value, c.value
+
+    def fetch_hits(self, idx: Iterable[int], want_flags: bool = True):
+        """(hits (m,2) int32 [j,i], flags (m,) uint8 or None, off (len(idx)+1,) int64)."""
+        idx = np.ascontiguousarray(list(idx), dtype=np.int64)
+        off = np.zeros(len(idx) + 1, dtype=np.int64)
+        if len(idx) == 0:
+            return np.zeros((0, 2), np.int32), (np.zeros(0, np.uint8) if want_flags else None), off
+        tot = int(self.stats[idx, L.ST_N_HITS][self.stats[idx, L.ST_STATUS] == 0].sum())
+        hits = np.zeros((max(tot, 1), 2), dtype=np.int32)
+        flags = np.zeros(max(tot, 1), dtype=np.uint8) if want_flags else None
+        L.check(L.load().vapor_plan_fetch_hits(self._h, len(idx), L.ptr(idx, ctypes.c_int64), L.ptr(hits, ctypes.c_int32),
+                                               L.ptr(flags, ctypes.c_uint8) if want_flags else None, tot,
+                                               L.ptr(off, ctypes.c_int64)))
+        return hits[:tot], (flags[:tot] if want_flags else None), off
+
+    def close(self) -> None:
+        if self._h:
+            L.load().vapor_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One HIP context (device + stream).  Raises if the library or the GPU is missing."""
+
+    def __init__(self, device: int = 0):
+        lib = L.load()
+        self._ctx = ctypes.c_void_p()
+        L.check(lib.vapor_init(device, ctypes.byref(self._ctx)))
+        self.device = device
+
+    def set_param(self, name: str, value: int) -> None:
+        L.check(L.load().vapor_set_param(self._ctx, name.encode(), int(value)))
+
+    def seqset(self, seqs: Sequence, upper: Optional[Sequence[bool]] = None) -> SeqSet:
+        return SeqSet(self, seqs, upper)
+
+    def plan(self, seqset: SeqSet, pairs: np.ndarray) -> Plan:
+        return Plan(self, seqset, pairs)
+
+    @staticmethod
+    def make_pairs(rows: Sequence[Tuple[int, int, int, int, int]]) -> np.ndarray:
+        a = np.zeros(len(rows), dtype=L.PAIR_DTYPE)
+        for t, r in enumerate(rows):
+            a[t] = tuple(r)
+        return a
+
+    def score(self, seqset: SeqSet, pairs: np.ndarray) -> np.ndarray:
+        p = Plan(self, seqset, pairs)
+        try:
+            return p.run().copy()
+        finally:
+            p.close()
+
+    def dotplots(self, seqset: SeqSet, pairs: np.ndarray) -> Tuple[np.ndarray, List[np.ndarray]]:
+        """Statistics plus, per pair, the (n,2) [j,i] hit array sorted the way dotdata() lists it."""
+        p = Plan(self, seqset, pairs)
+        try:
+            st = p.run().copy()
+            hits, _f, off = p.fetch_hits(range(p.n), want_flags=False)
+        finally:
+            p.close()
+        out = []
+        for t in range(len(off) - 1):
+            h = hits[off[t]:off[t + 1]]
+            out.append(h[np.lexsort((h[:, 1], h[:, 0]))])
+        return st, out
+
+    def clean_hits(self, lists: Sequence[np.ndarray], flags: Optional[Sequence[int]] = None):
+        """Cleaning + reductions on explicit dot lists -> (stats (n,16), [flag bytes per list])."""
+        n = len(lists)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 2) for a in lists]
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(a) for a in arrs], out=off[1:])
+        allh = np.concatenate(arrs + [np.zeros((1, 2), np.int32)])
+        fl = np.asarray(flags if flags is not None else [3] * n, dtype=np.uint32)
+        st = np.zeros((max(n, 1), 16), dtype=np.int64)
+        hf = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+        L.check(L.load().vapor_clean_hits(self._ctx, n, L.ptr(allh, ctypes.c_int32), L.ptr(off, ctypes.c_int64),
+                                          L.ptr(fl if n else np.zeros(1, np.uint32), ctypes.c_uint32),
+                                          L.ptr(st, ctypes.c_int64), L.ptr(hf, ctypes.c_uint8)))
+        return st[:n], [hf[off[t]:off[t + 1]] for t in range(n)]
+
+    def close(self) -> None:
+        if self._ctx:
+            L.load().vapor_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
