@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the recurrence-plot scoring hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic loci whose packed
+sequences and pair descriptors are already resident in HBM:
+    join kernel(s) -> clean kernel -> statistics to host -> float64 finish to
+    VaPoR_QS / VaPoR_GS / VaPoR_GT per locus (-> all-gather of the per-locus records, N > 1).
+Weak scaling: every rank processes its own batch of the same shape.
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is measured live with HIP
+events on the library's own stream (vapor_plan_timings); `cpu_baseline` times the CPU oracle
+(oracle/, a restatement: kind "port") on a bounded sample of the same pairs, 1 thread.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--reads-per-task", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from vapor_amd import workload as wl
+    from vapor_amd.engine import Engine
+
+    spec = wl.WORKLOADS[args.workload]
+    w = wl.make_workload(args.workload, seed=1000 + rank, **spec)
+    eng = Engine(local)
+    if args.reads_per_task:
+        eng.set_param("reads_per_task", args.reads_per_task)
+    t0 = time.perf_counter()
+    ss = eng.seqset(w.seqs)
+    upload_s = time.perf_counter() - t0
+    plan = eng.plan(ss, w.pairs)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = [None]
+
+    def step():
+        st = plan.run()
+        rec = wl.finish_workload(w, st)
+        if dist is not None:
+            t = torch.from_numpy(rec).cuda()
+            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t)
+            gathered[0] = out
+        else:
+            gathered[0] = rec
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    join_ms = clean_ms = dev_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = plan.timings()
+        join_ms += tm["join_ms"]
+        clean_ms += tm["clean_ms"]
+        dev_ms += tm["total_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = plan.stats[:plan.n]
+    alg_bytes, cells = plan.algorithmic()
+    n_pairs = len(w.pairs)
+    steps = max(args.steps, 1)
+    join_avg, clean_avg = join_ms / steps, clean_ms / steps
+    launches = plan.timings()["join_launches"]
+    ms_per_step = elapsed / steps * 1e3
+    loci_s = w.n_loci * world * steps / elapsed
+    cells_s = cells * world * steps / elapsed
+    dom = "join_kernel" if join_avg >= clean_avg else "clean_kernel"
+    dom_ms = max(join_avg, clean_avg)
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import oracle as orc
+        orc.build()
+        done = 0
+        c_cells = 0
+        t0 = time.perf_counter()
+        while done < n_pairs and time.perf_counter() - t0 < args.cpu_seconds:
+            p = w.pairs[done]
+            exp = orc.pair_stats(int(p["k"]), w.seqs[p["seq1"]], w.seqs[p["seq2"]][int(p["off2"]):])
+            if not int(p["flags"]) & 1:
+                exp[3] = exp[4] = 0
+            if not int(p["flags"]) & 2:
+                exp[5] = exp[6] = exp[9] = 0
+            assert exp[:10].tolist() == st[done, :10].tolist(), "GPU/oracle mismatch on pair %d" % done
+            c_cells += len(w.seqs[p["seq1"]]) * (len(w.seqs[p["seq2"]]) - int(p["off2"]))
+            done += 1
+        ct = time.perf_counter() - t0
+        pairs_per_locus = n_pairs / w.n_loci
+        cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "kind": "port",
+               "sample": "first %d of %d (read, allele) dot plots of the same batch (fill + C1/C2 clean + counts, "
+                         "oracle/vapor_oracle.c, gcc -O2, 1 thread, %.1f s); each checked equal to the GPU record"
+                         % (done, n_pairs, ct),
+               "cells_per_s": round(c_cells / ct, 1)}
+
+    if rank == 0:
+        out = {
+            "metric": "SV loci validated/sec",
+            "value": round(loci_s, 3),
+            "unit": "loci/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d loci/GPU x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s"
+                                   % (args.workload, w.n_loci, spec["reads_per_locus"], spec["read_len"],
+                                      spec["allele_len"], "/".join(sorted(set(w.svtypes)))),
+                       "pairs_per_step_per_gpu": n_pairs, "parallelism": "loci sharded over %d GPU(s)" % world},
+            "cells_per_s": round(cells_s, 1),
+            "hits_per_step": int(st[:, 0].sum()),
+            "loci_with_scores": int(np.isfinite(gathered[0].reshape(-1, 5)[:, 0].cpu().numpy() if hasattr(gathered[0], "cpu")
+                                                else gathered[0][:, 0]).sum()),
+            "kernel_ms": {"join": round(join_avg, 4), "clean": round(clean_avg, 4), "device_total": round(dev_ms / steps, 4),
+                          "join_launches": launches},
+            "upload_pack_s": round(upload_s, 4),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

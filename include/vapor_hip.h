@@ -55,6 +55,8 @@ typedef struct vapor_pair {
 
 #define VAPOR_PF_C1 1u   /* clean_dotdata_diagnal_and_anti_diagnal (SF:432-448) -> ST_C1_* */
 #define VAPOR_PF_C2 2u   /* the two-step cleaning of within_10Perc_m1b (SF:281-288) -> ST_C2_* */
+#define VAPOR_PF_DIR 4u  /* with PF_C1: dis_to_diagnal_most_abundant_defined (SF:582-591) and
+                            eu_dis_dir_calcu (SF:718-722) over the C1-kept dots -> ST_DIR_* */
 
 /* int64 statistics record per pair (VAPOR_STATS_STRIDE words) */
 #define VAPOR_STATS_STRIDE 16
@@ -68,6 +70,10 @@ typedef struct vapor_pair {
 #define VAPOR_ST_N_DIAG 7      /* dots with j == i (qual_check_repetitive_region SF:1158-1160) */
 #define VAPOR_ST_N_LOWER 8     /* dots with j > i  (SF:1162-1164) */
 #define VAPOR_ST_C2_KEPT_DIAG 9 /* dots kept by the diagonal step alone */
+#define VAPOR_ST_DIR_C2X 10     /* 2*c, c = the redefined diagonal intercept (a multiple of 0.5; 0 when not unique) */
+#define VAPOR_ST_DIR_N 11       /* kept dots (x,y) = (j+c, i) with abs(x-y)/abs(x) > 0.1 (eu_dis_single_dot SF:710-716) */
+#define VAPOR_ST_DIR_SUM2 12    /* 2 * sum(x - y) over them: eu_dis_dir_calcu = SUM2 / 2 / N, or 0.0001 when N == 0 */
+#define VAPOR_ST_DIR_LISTS 13   /* number of longest sub-bins found (c is a median only when this is 1) */
 #define VAPOR_ST_STATUS 15     /* 0, or VAPOR_E_KEYERROR / VAPOR_E_ARG / VAPOR_E_OVERFLOW for this pair */
 
 /* per-hit flag bits returned by vapor_plan_fetch_hits */

@@ -44,8 +44,12 @@ def test_dotdata_golden(eng):
 def test_cleaners_golden(eng, oracle):
     cases = load_golden("cleaners.json.gz")["cases"]
     lists = [np.asarray(c["hits"], dtype=np.int32).reshape(-1, 2) for c in cases]
-    st, fl = eng.clean_hits(lists)
+    st, fl = eng.clean_hits(lists, flags=[7] * len(lists))
+    from vapor_amd import finish
     for t, c in enumerate(cases):
+        if "r4" in c and "ok" in c["r4"]:
+            assert st[t, 10] == int(round(2 * float(c["r4"]["ok"]))), c["name"]
+            assert float(finish._dir_value(st[t])) == float(c["dir"]["ok"]), c["name"]
         h = lists[t]
         got1 = h[(fl[t] & 1) > 0].tolist()
         assert got1 == c["c1"]["ok"], c["name"]
@@ -78,6 +82,14 @@ def _check_stats_vs_oracle(eng, oracle, seqs, upper, rows, tag=""):
         if not fl & 2:
             exp[5] = exp[6] = exp[9] = 0
         assert got[:10].tolist() == exp[:10].tolist(), (tag, t, rows[t])
+        if fl & 4 and exp[3] > 0:
+            _st, h, k1, _k2 = oracle.pair_stats(k, a, b[off2:], want_hits=True)
+            kept = [(int(x), int(y)) for x, y in h[k1 > 0]]
+            c = oracle.dis_to_diagnal_most_abundant_defined(list(kept))
+            far = [d for d in ([x + c, y] for x, y in kept) if oracle.eu_dis_single_dot(d) > 0.1]
+            assert got[10] == int(round(2 * float(c))), (tag, t, "c", got[10], c)
+            assert got[11] == len(far), (tag, t, "dir_n")
+            assert got[12] == int(round(2 * sum(d[0] - d[1] for d in far))), (tag, t, "dir_sum")
     return st
 
 
@@ -91,8 +103,40 @@ def test_scorer_inputs_vs_oracle(eng, oracle):
         seqs += [c["read"], c["ref"], c["alt"], c["ref"], c["alt"]]
         upper += [False, False, False, True, True]
         for al in (1, 2, 3, 4):
-            rows.append((base, base + al, c["miss"], c["k"], 3))
+            rows.append((base, base + al, c["miss"], c["k"], 7))
     _check_stats_vs_oracle(eng, oracle, seqs, upper, rows, "scorers")
+
+
+def test_scorers_golden_end_to_end(eng):
+    """Device statistics + host float64 finishing == the reference's three scorers, exactly."""
+    from vapor_amd import finish
+    cases = [c for c in load_golden("scorers.json.gz")["cases"]]
+    seqs, upper, rows = [], [], []
+    for c in cases:
+        base = len(seqs)
+        seqs += [c["read"], c["ref"], c["alt"], c["ref"], c["alt"]]
+        upper += [False, False, False, True, True]
+        for al in (1, 2, 3, 4):
+            rows.append((base, base + al, c["miss"], c["k"], 7))
+    ss = eng.seqset(seqs, upper)
+    st = eng.score(ss, eng.make_pairs(rows))
+    for t, c in enumerate(cases):
+        r, a, ru, au = st[4 * t], st[4 * t + 1], st[4 * t + 2], st[4 * t + 3]
+        lr, la = len(c["ref"]), len(c["alt"])
+        if "error" in c["s1"]:
+            assert r[15] == -3 and au[15] == -3
+            continue
+        got = {"s1": finish.score_abs_dis_m1b(ru, au, lr, la),
+               "s2": finish.score_within_10Perc_m1b(r, a, lr, la),
+               "s3": finish.score_directed_dis_m1b_redefine_diagnal(r, a, lr, la)}
+        for key in ("s1", "s2", "s3"):
+            assert [float(v) for v in got[key]] == [float(v) for v in c[key]["ok"]], (c["name"], key)
+        kind = np.array([1, 2, 3])
+        va, vb, valid = finish.batch_scores(kind, np.stack([ru, r, r]), np.stack([au, a, a]),
+                                            np.array([lr] * 3), np.array([la] * 3))
+        for q, key in enumerate(("s1", "s2", "s3")):
+            assert [va[q], vb[q]] == [float(v) for v in c[key]["ok"]], (c["name"], key, "batch")
+            assert bool(valid[q]) == (0 not in c[key]["ok"])
 
 
 def test_selfplot_counts_golden(eng):
@@ -114,7 +158,7 @@ def test_random_pairs_vs_oracle(eng, oracle, k):
     from vapor_amd import synth
     alleles, reads, pr = synth.make_pairs(1000 + k, 6, 4, 3000, 5000, errors=(0.002, 0.01, 0.005) if k > 10 else (0.01, 0.08, 0.04))
     seqs = alleles + reads
-    rows = [(len(alleles) + r, a, (7 * r) % 50, k, 3) for r, a in pr]
+    rows = [(len(alleles) + r, a, (7 * r) % 50, k, 7) for r, a in pr]
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "rand%d" % k)
 
 
@@ -129,8 +173,8 @@ def test_general_mode_softmasked_both(eng, oracle):
         r, _ = synth.mutate(rng, a[100:2300], 0.003, 0.01, 0.01)
         seqs += [a, r]
         for k in (10, 20, 30, 40):
-            rows.append((len(seqs) - 1, len(seqs) - 2, 0, k, 3))
-            rows.append((len(seqs) - 2, len(seqs) - 2, 0, k, 3))
+            rows.append((len(seqs) - 1, len(seqs) - 2, 0, k, 7))
+            rows.append((len(seqs) - 2, len(seqs) - 2, 0, k, 7))
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "general")
 
 
@@ -142,7 +186,7 @@ def test_bench_shape_and_multi_tile(eng, oracle):
         alleles, reads, pr = synth.make_pairs(77 + seed, 2, 3, lr, la)
         base = len(seqs)
         seqs += alleles + reads
-        rows += [(base + len(alleles) + r, base + a, 0, 10, 3) for r, a in pr]
+        rows += [(base + len(alleles) + r, base + a, 0, 10, 7) for r, a in pr]
     st = _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "bench")
     assert st[:, 0].min() > 1000
 

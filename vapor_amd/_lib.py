@@ -17,7 +17,8 @@ PAIR_DTYPE = np.dtype([("seq1", "<i4"), ("seq2", "<i4"), ("off2", "<i4"), ("k", 
 STATS_STRIDE = 16
 ST_N_HITS, ST_FIRST_J, ST_LAST_J, ST_C1_KEPT, ST_C1_SUM_ABS = 0, 1, 2, 3, 4
 ST_C2_KEPT, ST_C2_COUNT10, ST_N_DIAG, ST_N_LOWER, ST_C2_KEPT_DIAG, ST_STATUS = 5, 6, 7, 8, 9, 15
-PF_C1, PF_C2 = 1, 2
+ST_DIR_C2X, ST_DIR_N, ST_DIR_SUM2, ST_DIR_LISTS = 10, 11, 12, 13
+PF_C1, PF_C2, PF_DIR = 1, 2, 4
 HF_C1_KEPT, HF_C2_DIAG, HF_C2_ANTI = 1, 2, 4
 SEQ_UPPER = 1
 E_HIP, E_OVERFLOW, E_KEYERROR, E_ARG, E_NOMEM = -1, -2, -3, -4, -5

@@ -108,7 +108,7 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
                        set_join_attr<4, 10>(), set_join_attr<4, 20>(), set_join_attr<4, 30>(), set_join_attr<4, 40>()};
     for (hipError_t x : a)
         if (x != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(join): ") + hipGetErrorString(x)); }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(clean): ") + hipGetErrorString(e)); }
     *out = c;
     return VAPOR_OK;

@@ -465,6 +465,142 @@ __device__ void cluster_axis(const uint32_t* __restrict__ hits, uint8_t* __restr
     __syncthreads();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// dis_to_diagnal_most_abundant_defined (SF:582-591) and eu_dis_dir_calcu (SF:718-722) on the
+// C1-kept dots of one pair.  number_cluster (SF:1104-1118) puts a value v into bin b-1 for the
+// first edge index b in 1..10 with v < edge[b], and into the last (11th) list when there is none;
+// edges are min + t*float(max-min)/10.0 in float64, evaluated here with the same three IEEE
+// operations.  The longest bin(s) are re-binned the same way over their own min..max; only when
+// exactly one sub-bin is the longest overall is its median the new intercept c, else c = 0.
+// Outputs: c2x = 2*c (c is a multiple of 0.5), and over dots (x, y) = (j + c, i) with
+// abs(x-y)/abs(x) > 0.1 (x == 0: y/1 > 0.1) the count and the doubled sum of x - y.
+struct R4Shared {
+    double e1[11], e2[11];
+    int cnt1[11], min1[11], max1[11];
+    int cnt[11], vmin[11], vmax[11];
+    int lo, hi, n_lists, win_bin, win_sub, win_lo, win_hi, win_n, c2x, dir_n;
+    long long dir_sum2;
+};
+
+__device__ __forceinline__ int r4_bin(int v, const double* e)
+{
+    const double x = (double)v;
+    int b = 1;
+    for (; b < 11; ++b)
+        if (x < e[b]) break;
+    return b - 1;   // 10 = the list that takes what is left (dis_clu[-1])
+}
+
+__device__ void directed_stats(const uint32_t* __restrict__ hits, const uint8_t* __restrict__ hflags, long long n,
+                               uint32_t* counters, R4Shared* r)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        r->lo = 0x7FFFFFFF; r->hi = -0x7FFFFFFF; r->n_lists = 0; r->win_bin = -1; r->win_sub = -1;
+        r->win_lo = 0; r->win_hi = -1; r->win_n = 0; r->c2x = 0; r->dir_n = 0; r->dir_sum2 = 0;
+    }
+    if (tid < 11) { r->cnt1[tid] = 0; r->min1[tid] = 0x7FFFFFFF; r->max1[tid] = -0x7FFFFFFF; }
+    __syncthreads();
+    {
+        int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+            if (!(hflags[h] & HF_C1)) continue;
+            uint32_t x = hits[h];
+            int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+            lo = min(lo, d); hi = max(hi, d);
+        }
+        lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+        if ((tid & 63) == 0) { atomicMin(&r->lo, lo); atomicMax(&r->hi, hi); }
+    }
+    __syncthreads();
+    if (r->hi < r->lo) return;                     // no kept dots (uniform)
+    if (tid < 11) r->e1[tid] = (double)r->lo + ((double)tid * (double)(r->hi - r->lo)) / 10.0;
+    __syncthreads();
+    for (long long h = tid; h < n; h += CLEAN_THREADS) {
+        if (!(hflags[h] & HF_C1)) continue;
+        uint32_t x = hits[h];
+        int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+        int b = r4_bin(d, r->e1);
+        atomicAdd(&r->cnt1[b], 1); atomicMin(&r->min1[b], d); atomicMax(&r->max1[b], d);
+    }
+    __syncthreads();
+    int best1 = 0;
+    for (int b = 0; b < 11; ++b) best1 = max(best1, r->cnt1[b]);
+    for (int w = 0; w < 11; ++w) {
+        if (r->cnt1[w] != best1) continue;         // uniform: LDS value, no writer in this loop
+        if (tid < 11) {
+            r->cnt[tid] = 0; r->vmin[tid] = 0x7FFFFFFF; r->vmax[tid] = -0x7FFFFFFF;
+            r->e2[tid] = (double)r->min1[w] + ((double)tid * (double)(r->max1[w] - r->min1[w])) / 10.0;
+        }
+        __syncthreads();
+        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+            if (!(hflags[h] & HF_C1)) continue;
+            uint32_t x = hits[h];
+            int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+            if (r4_bin(d, r->e1) != w) continue;
+            int b = r4_bin(d, r->e2);
+            atomicAdd(&r->cnt[b], 1); atomicMin(&r->vmin[b], d); atomicMax(&r->vmax[b], d);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int m2 = 0;
+            for (int b = 0; b < 11; ++b) m2 = max(m2, r->cnt[b]);
+            for (int b = 0; b < 11; ++b)
+                if (r->cnt[b] == m2) {
+                    r->n_lists++;
+                    r->win_bin = w; r->win_sub = b;
+                    r->win_lo = r->vmin[b]; r->win_hi = r->vmax[b]; r->win_n = m2;
+                }
+        }
+        __syncthreads();
+    }
+    if (r->n_lists == 1) {
+        // median of the single longest sub-bin: per-value counters over its value span
+        const int w = r->win_bin, sb = r->win_sub, vlo = r->win_lo, width = r->win_hi - r->win_lo + 1, m = r->win_n;
+        if (tid < 11) r->e2[tid] = (double)r->min1[w] + ((double)tid * (double)(r->max1[w] - r->min1[w])) / 10.0;
+        for (int q = tid; q < width; q += CLEAN_THREADS) counters[q] = 0;
+        __syncthreads();
+        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+            if (!(hflags[h] & HF_C1)) continue;
+            uint32_t x = hits[h];
+            int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+            if (r4_bin(d, r->e1) != w || r4_bin(d, r->e2) != sb) continue;
+            atomicAdd(&counters[d - vlo], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // order statistics (m-1)/2 and m/2, 0-based: np.median is their mean
+            int k0 = (m - 1) / 2, k1 = m / 2, acc = 0, v0 = 0, v1 = 0;
+            bool g0 = false, g1 = false;
+            for (int q = 0; q < width && !g1; ++q) {
+                acc += (int)counters[q];
+                if (!g0 && acc > k0) { v0 = vlo + q; g0 = true; }
+                if (!g1 && acc > k1) { v1 = vlo + q; g1 = true; }
+            }
+            r->c2x = v0 + v1;
+        }
+    }
+    __syncthreads();
+    {
+        const int c2x = r->c2x;
+        int cn = 0;
+        long long cs = 0;
+        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+            if (!(hflags[h] & HF_C1)) continue;
+            uint32_t x = hits[h];
+            int i = (int)(x & 0xFFFFu), j = (int)(x >> 16);
+            long long X = 2LL * j + c2x, Y = 2LL * i;
+            long long df = X - Y, adf = df < 0 ? -df : df, aX = X < 0 ? -X : X;
+            bool far = (X == 0) ? (i >= 1) : (10 * adf > aX);
+            if (far) { ++cn; cs += df; }
+        }
+        cn = wave_sum_i32(cn); cs = wave_sum_i64(cs);
+        if ((tid & 63) == 0) { atomicAdd(&r->dir_n, cn); atomicAdd((unsigned long long*)&r->dir_sum2, (unsigned long long)cs); }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
     const SeqDesc* __restrict__ seqs, const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
@@ -472,6 +608,7 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
+    __shared__ R4Shared r4;
     const int tid = threadIdx.x;
     const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
     const DPair pr = pairs[p];
@@ -551,10 +688,13 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
         }
     }
     __syncthreads();
+    const bool s3 = (pr.flags & 4u) && c1;
+    if (s3) directed_stats(hits, hflags, n, gcnt, &r4);
     if (tid == 0) {
         st[0] = n; st[1] = sh.min_j; st[2] = sh.max_j; st[3] = sh.c1_kept; st[4] = (long long)sh.c1_sum_abs;
         st[5] = sh.c2_kept; st[6] = sh.c2_count10; st[7] = sh.n_diag; st[8] = sh.n_lower; st[9] = sh.c2_kept_diag;
-        st[10] = 0; st[11] = 0; st[12] = 0; st[13] = 0; st[14] = 0; st[15] = 0;
+        st[10] = s3 ? r4.c2x : 0; st[11] = s3 ? r4.dir_n : 0; st[12] = s3 ? r4.dir_sum2 : 0; st[13] = s3 ? r4.n_lists : 0;
+        st[14] = 0; st[15] = 0;
     }
 }
 

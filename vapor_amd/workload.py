@@ -1,0 +1,124 @@
+"""Kernel-level synthetic workloads at the BASELINE.json shapes and the
+vectorised per-locus finish used by bench.py and the batch pipeline.
+
+A workload is a set of loci; each locus has a ref and an alt allele window and a list of
+reads, every read is scored against both windows with the scorer(s) its SV type uses in the
+reference's drivers:  DEL -> abs_dis_m1b and within_10Perc_m1b (min of the
+two, SF:1718-1726), TANDUP -> directed_dis_m1b_redefine_diagnal (SF:1761), INV / INS ->
+abs_dis_m1b (SF:1910, SF:1879).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from . import finish, synth
+
+SCORER_FLAGS = {"DEL": L.PF_C1 | L.PF_C2, "TANDUP": L.PF_C1 | L.PF_DIR, "INV": L.PF_C1, "INS": L.PF_C1}
+
+
+@dataclasses.dataclass
+class Workload:
+    name: str
+    seqs: List[str]              # alleles and reads, one device sequence each
+    pairs: np.ndarray            # PAIR_DTYPE, ref pair then alt pair for every read
+    read_locus: np.ndarray       # locus index of every read
+    read_kind: np.ndarray        # 0 DEL (S1+S2), 1 S1 only, 3 S3
+    len_ref: np.ndarray          # per read: full length of its locus' ref / alt window
+    len_alt: np.ndarray
+    n_loci: int
+    svtypes: List[str]
+
+
+def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], read_len: int, allele_len: int,
+                  reads_per_locus: int, k: int = 10) -> Workload:
+    rng = np.random.default_rng(seed)
+    seqs: List[str] = []
+    rows = []
+    read_locus, read_kind, len_ref, len_alt, types = [], [], [], [], []
+    for li in range(n_loci):
+        t = svtypes[li % len(svtypes)]
+        types.append(t)
+        ref = synth.random_dna(rng, allele_len)
+        span = int(rng.integers(300, 3000))
+        s = int(rng.integers(allele_len // 4, allele_len // 2))
+        if t == "DEL":
+            alt = ref[:s] + ref[s + span:]
+        elif t == "TANDUP":
+            alt = ref[:s + span] + ref[s:s + span] + ref[s + span:]
+        elif t == "INV":
+            alt = ref[:s] + synth.revcomp(ref[s:s + span]) + ref[s + span:]
+        else:
+            alt = ref[:s] + synth.random_dna(rng, span) + ref[s:]
+        ri, ai = len(seqs), len(seqs) + 1
+        seqs += [ref, alt]
+        kind = {"DEL": 0, "TANDUP": 3}.get(t, 1)
+        for _ in range(reads_per_locus):
+            hap = alt if rng.random() < 0.5 else ref
+            lo = max(0, s + span + 500 - read_len)
+            hi = max(lo, min(s - 200, len(hap) - read_len))
+            st = int(rng.integers(lo, hi + 1))
+            rd, _c = synth.mutate(rng, hap[st:st + read_len + read_len // 8])
+            seqs.append(rd[:read_len])
+            q = len(seqs) - 1
+            rows.append((q, ri, 0, k, SCORER_FLAGS[t]))
+            rows.append((q, ai, 0, k, SCORER_FLAGS[t]))
+            read_locus.append(li)
+            read_kind.append(kind)
+            len_ref.append(len(ref))
+            len_alt.append(len(alt))
+    pairs = np.zeros(len(rows), dtype=L.PAIR_DTYPE)
+    for i, r in enumerate(rows):
+        pairs[i] = r
+    return Workload(name, seqs, pairs, np.asarray(read_locus), np.asarray(read_kind), np.asarray(len_ref),
+                    np.asarray(len_alt), n_loci, types)
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 100 simple DEL/DUP loci, 10 kb reads at 20x, 20 kb windows
+    "cfg2": dict(n_loci=100, svtypes=("DEL", "TANDUP"), read_len=10000, allele_len=20000, reads_per_locus=20),
+    # configs[2]: 1000 mixed DEL/DUP/INV/INS loci, 15 kb reads at 40x
+    "cfg3": dict(n_loci=1000, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), read_len=15000, allele_len=20000,
+                 reads_per_locus=40),
+    "tiny": dict(n_loci=8, svtypes=("DEL", "TANDUP", "INV", "INS"), read_len=1500, allele_len=3000, reads_per_locus=6),
+}
+
+
+def finish_workload(w: Workload, stats: np.ndarray) -> np.ndarray:
+    """Per-locus records [QS, GS, GT index, GQ, n_scored] (float64; NaN row = 'NA') from the
+    statistics of one pass (L1 -> L2 -> L3)."""
+    st_ref, st_alt = stats[0::2], stats[1::2]
+    kind = w.read_kind
+    k1 = np.where(kind == 3, 3, 1)
+    a1, b1, v1 = finish.batch_scores(k1, st_ref, st_alt, w.len_ref, w.len_alt)
+    s1 = finish.read_scores(a1, b1)
+    is_del = kind == 0
+    score = s1.copy()
+    valid = v1.copy()
+    if is_del.any():
+        a2, b2, v2 = finish.batch_scores(np.where(is_del, 2, 0), st_ref, st_alt, w.len_ref, w.len_alt)
+        s2 = finish.read_scores(a2, b2)
+        both = is_del & v1 & v2
+        score[both] = np.minimum(s1[both], s2[both])
+        only2 = is_del & ~v1 & v2
+        score[only2] = s2[only2]
+        valid = np.where(is_del, v1 | v2, v1)
+    out = np.full((w.n_loci, 5), np.nan, dtype=np.float64)
+    loc = w.read_locus[valid]
+    sc = score[valid]
+    n = np.bincount(loc, minlength=w.n_loci)
+    pos = sc > 0
+    npos = np.bincount(loc[pos], minlength=w.n_loci)
+    spos = np.bincount(loc[pos], weights=sc[pos], minlength=w.n_loci)
+    nonpos_r = np.bincount(loc[finish.rounded_nonpositive(sc)], minlength=w.n_loci)
+    for li in np.flatnonzero(n):
+        gs = float(npos[li]) / float(n[li])
+        qs = spos[li] / npos[li] if npos[li] else 0.0
+        idx, gq = finish._gt_from_counts(int(n[li]), int(nonpos_r[li]))
+        if idx == 0 and gs > .15:
+            idx = 1
+        out[li] = (qs, gs, idx, gq, n[li])
+    return out
