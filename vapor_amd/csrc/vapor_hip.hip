@@ -65,6 +65,7 @@ struct vapor_plan {
     std::vector<Launch> launches;
     std::vector<int64_t> last_stats;
     int range_words_cap = 1;
+    int hcap_want = 4096;
     int64_t total_cap = 0;
     DPair* d_pairs = nullptr;
     DTask* d_tasks = nullptr;
@@ -300,6 +301,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     order.reserve((size_t)n_pairs);
     std::vector<uint8_t> mode((size_t)n_pairs, 2);
     int rw = 1;
+    int64_t hwant = 1024;
     for (int64_t i = 0; i < n_pairs; ++i) {
         const vapor_pair& a = pairs[i];
         DPair& d = p->hp[i];
@@ -318,9 +320,11 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         d.cap = (uint32_t)std::min<int64_t>(cap, ctx->max_pair_cap);
         mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : 2;
         rw = std::max(rw, (s1.len + s2.len + 2 + 31) / 32);
+        hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 2 + ((n1 * n2) >> 19) + 256);
         if (s1.len - a.k + 1 > 0 && s2.len - a.k + 1 > 0) order.push_back((int32_t)i);
     }
     p->range_words_cap = rw;
+    p->hcap_want = (int)std::min<int64_t>(hwant, 16384);
     // group pairs that share (mode, k, allele) into tasks of at most reads_per_task reads
     std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
         const DPair &a = p->hp[x], &b = p->hp[y];
@@ -393,10 +397,20 @@ static void launch_join(vapor_plan* p, const Launch& L)
                        p->d_task_pairs, p->d_hits, p->d_nhits);
 }
 
-static size_t clean_lds_bytes(int range_words_cap)
+static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 / 10 + 8; }
+
+// hits of a pair are cleaned out of LDS when they fit next to the clustering arrays
+static int clean_hcap(int range_words_cap, int want)
 {
-    size_t groups = (size_t)range_words_cap * 32 / 10 + 8;
-    return sizeof(uint32_t) * ((size_t)range_words_cap * 3 + groups);
+    size_t fixed = sizeof(uint32_t) * ((size_t)range_words_cap * 3 + (size_t)clean_groups_cap(range_words_cap));
+    size_t room = fixed + 4096 < 150 * 1024 ? 150 * 1024 - fixed : 0;
+    int cap = (int)std::min<size_t>(room / 5, (size_t)want);
+    return cap & ~3;
+}
+
+static size_t clean_lds_bytes(int range_words_cap, int hcap)
+{
+    return sizeof(uint32_t) * ((size_t)range_words_cap * 3 + (size_t)clean_groups_cap(range_words_cap)) + (size_t)hcap * 5;
 }
 
 static int plan_run_once(vapor_plan* p)
@@ -421,10 +435,11 @@ static int plan_run_once(vapor_plan* p)
     }
     HIPCHK(hipEventRecord(p->ev[1], st));
     if (p->n_pairs > 0) {
-        size_t lds = clean_lds_bytes(p->range_words_cap);
+        int hcap = clean_hcap(p->range_words_cap, p->hcap_want);
+        size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st, p->set->d_seqs,
                            p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
-                           p->range_words_cap);
+                           p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(p->ev[2], st));
@@ -653,8 +668,9 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice, st), "copy");
     }
     if (rc == VAPOR_OK) {
-        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw), st, d_sd, d_dp,
-                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw);
+        int hcap = clean_hcap(rw, 4096);
+        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_sd, d_dp,
+                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), hcap);
         chk(hipGetLastError(), "clean launch");
         chk(hipMemcpyAsync(stats, d_st, sizeof(long long) * 16 * (size_t)n_lists, hipMemcpyDeviceToHost, st), "copy");
         if (hit_flags && tot) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)tot, hipMemcpyDeviceToHost, st), "copy");

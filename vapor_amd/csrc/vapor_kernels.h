@@ -52,7 +52,8 @@ constexpr int NB_LOG2 = 14;            // hash buckets
 constexpr int NB = 1 << NB_LOG2;
 constexpr int JOIN_THREADS = 1024;
 constexpr int MAX_READS_PER_TASK = 64;
-constexpr int CLEAN_THREADS = 256;
+constexpr int CLEAN_THREADS = 512;
+constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
 constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 
 // per-hit working flags inside clean_kernel (upper nibble) and the public ones (lower)
@@ -368,38 +369,86 @@ struct CleanShared {
     int min_j, max_j, n_diag, n_lower;
     int c1_kept, c2_kept, c2_count10, c2_kept_diag;
     unsigned long long c1_sum_abs;
-    unsigned int n_groups, max_group, scan_carry;
-    unsigned int wave_tot[4];
+    unsigned int n_groups, max_group;
+    unsigned int wave_tot[CLEAN_WAVES];
+    // directed-distance scratch (dis_to_diagnal_most_abundant_defined)
+    int cnt1[11], cnt2[11];
+    int kd_lo, kd_hi, bin_lo, bin_hi, n_lists, win_w, win_b, win_lo2, win_r2, win_n, c2x, dir_n;
+    long long dir_sum2;
 };
+
+#define INACTIVE_KEY 0xFFFFFFFFu
+
+// Lanes of a wave hold `key` for consecutive hits.  For every maximal run of equal keys the
+// run's first lane gets the run length, every other lane 0 (runs of INACTIVE_KEY get 0 too), so
+// one LDS atomic per run replaces one per lane: dots on one diagonal come in long runs, and
+// same-address LDS atomics serialise.  Must be called by all 64 lanes.
+__device__ __forceinline__ int run_head_len(uint32_t key)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t prev = __shfl_up(key, 1, 64);
+    bool head = (lane == 0) || (key != prev);
+    unsigned long long m = __ballot(head);
+    unsigned long long above = (lane == 63) ? 0ULL : (m >> (lane + 1));
+    int len = above ? __ffsll((long long)above) : (64 - lane);
+    return (head && key != INACTIVE_KEY) ? len : 0;
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanShared* sh, uint32_t* total)
+{
+    const int tid = threadIdx.x;
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) sh->wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < CLEAN_WAVES; ++q) {
+        uint32_t w = sh->wave_tot[q];
+        if (q < (tid >> 6)) base += w;
+        tot += w;
+    }
+    *total = tot;
+    return base + incl - local;
+}
 
 // One pass of 1-D gap clustering (dis_cluster SF:551-564 / dis_cluster_2 SF:566-580) over the
 // hits selected by (flags & need_clear) == 0, on value v = AXIS_A ? i + j : i - j + vbias.
-// Values closer than 10 to their sorted predecessor join its group; gid(v) is the rank of the
-// group's first occupied bin.  Afterwards, for every selected hit, set_gt10 is OR-ed into its
-// flag byte when its group has more than 10 members, and set_rule when the group passes
-// dis_cluster's rule (more than 50 members, or maximal size when no group has more than 50).
-template <bool AXIS_A>
-__device__ void cluster_axis(const uint32_t* __restrict__ hits, uint8_t* __restrict__ hflags, long long n,
-                             int vbias, int range_words, uint32_t* bm, uint32_t* sb, uint32_t* wrank,
-                             uint32_t* gcnt, CleanShared* sh, uint32_t need_clear, uint32_t set_gt10,
-                             uint32_t set_rule)
+// Values closer than 10 to their sorted predecessor join its group: an occupancy bitmap over the
+// value range, group starts = occupied bins with no occupied bin among the 9 below, gid(v) = rank
+// of the group's start.  Afterwards, for every selected hit, set_gt10 is OR-ed into its flag byte
+// when its group has more than 10 members, and set_rule when the group passes dis_cluster's rule
+// (more than 50 members, or maximal size when no group has more than 50).
+template <bool AXIS_A, typename HP, typename FP>
+__device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
+                                             uint32_t* sb, uint32_t* wrank, uint32_t* gcnt, CleanShared* sh,
+                                             uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule)
 {
     const int tid = threadIdx.x;
     for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
-    if (tid == 0) { sh->max_group = 0; }
+    if (tid == 0) sh->max_group = 0;
     __syncthreads();
-    // 1. occupancy bitmap
-    for (long long h = tid; h < n; h += CLEAN_THREADS) {
-        if (need_clear && (hflags[h] & need_clear)) continue;
-        uint32_t x = hits[h];
-        int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-        int v = AXIS_A ? (i + j) : (i - j + vbias);
-        atomicOr(&bm[v >> 5], 1u << (v & 31));
+    // 1. occupancy bitmap (one atomic per run of equal values)
+    for (int base = 0; base < n; base += CLEAN_THREADS) {
+        const int h = base + tid;
+        bool act = h < n;
+        if (act && need_clear) act = !(hflags[h] & need_clear);
+        uint32_t v = INACTIVE_KEY;
+        if (act) {
+            uint32_t x = hits[h];
+            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            v = (uint32_t)(AXIS_A ? (i + j) : (i - j + vbias));
+        }
+        if (run_head_len(v)) atomicOr(&bm[v >> 5], 1u << (v & 31));
     }
     __syncthreads();
-    // 2. group starts: occupied bins with no occupied bin among the 9 below
-    int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
-    int w0 = tid * per, w1 = min(w0 + per, range_words);
+    // 2. group starts and their ranks
+    const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
+    const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
     uint32_t local = 0;
     for (int w = w0; w < w1; ++w) {
         uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
@@ -410,35 +459,28 @@ __device__ void cluster_axis(const uint32_t* __restrict__ hits, uint8_t* __restr
         sb[w] = st;
         local += __popc(st);
     }
-    // exclusive scan of `local` over the block
-    uint32_t incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += t;
-    }
-    if ((tid & 63) == 63) sh->wave_tot[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int q = 0; q < (tid >> 6); ++q) base += sh->wave_tot[q];
-    uint32_t run = base + incl - local;
+    uint32_t ng;
+    uint32_t run = block_exclusive_scan(local, sh, &ng);
     for (int w = w0; w < w1; ++w) {
         wrank[w] = run;
         run += __popc(sb[w]);
     }
-    if (tid == CLEAN_THREADS - 1) sh->n_groups = base + incl;
-    __syncthreads();
-    const uint32_t ng = sh->n_groups;
     for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) gcnt[g] = 0;
     __syncthreads();
-    // 3. group sizes
-    for (long long h = tid; h < n; h += CLEAN_THREADS) {
-        if (need_clear && (hflags[h] & need_clear)) continue;
-        uint32_t x = hits[h];
-        int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-        int v = AXIS_A ? (i + j) : (i - j + vbias);
-        uint32_t g = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
-        atomicAdd(&gcnt[g], 1u);
+    // 3. group sizes (one atomic per run of equal group ids)
+    for (int base = 0; base < n; base += CLEAN_THREADS) {
+        const int h = base + tid;
+        bool act = h < n;
+        if (act && need_clear) act = !(hflags[h] & need_clear);
+        uint32_t g = INACTIVE_KEY;
+        if (act) {
+            uint32_t x = hits[h];
+            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            int v = AXIS_A ? (i + j) : (i - j + vbias);
+            g = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+        }
+        int len = run_head_len(g);
+        if (len) atomicAdd(&gcnt[g], (uint32_t)len);
     }
     __syncthreads();
     if (set_rule) {
@@ -450,7 +492,7 @@ __device__ void cluster_axis(const uint32_t* __restrict__ hits, uint8_t* __restr
     }
     const uint32_t mx = sh->max_group;
     // 4. flags
-    for (long long h = tid; h < n; h += CLEAN_THREADS) {
+    for (int h = tid; h < n; h += CLEAN_THREADS) {
         uint32_t f = hflags[h];
         if (need_clear && (f & need_clear)) continue;
         uint32_t x = hits[h];
@@ -465,108 +507,112 @@ __device__ void cluster_axis(const uint32_t* __restrict__ hits, uint8_t* __restr
     __syncthreads();
 }
 
-
 // ------------------------------------------------------------------------------------------
 // dis_to_diagnal_most_abundant_defined (SF:582-591) and eu_dis_dir_calcu (SF:718-722) on the
-// C1-kept dots of one pair.  number_cluster (SF:1104-1118) puts a value v into bin b-1 for the
-// first edge index b in 1..10 with v < edge[b], and into the last (11th) list when there is none;
-// edges are min + t*float(max-min)/10.0 in float64, evaluated here with the same three IEEE
-// operations.  The longest bin(s) are re-binned the same way over their own min..max; only when
-// exactly one sub-bin is the longest overall is its median the new intercept c, else c = 0.
+// C1-kept dots of one pair.
+//
+// number_cluster (SF:1104-1118) puts a value v into list b-1 for the first edge index b in 1..10
+// with v < edge[b], edge[b] = min + b*float(max-min)/10.0, and into the 11th list when there is
+// none.  With integer data this is exact integer arithmetic: b*(max-min)/10 is either an integer
+// (then every float64 step is exact) or at least 0.1 away from one (then rounding cannot move it
+// across an integer), so   v < edge[b]  <=>  10*(v-min) < b*(max-min),   i.e.
+//     list(v) = max > min ? 10*(v-min) / (max-min) : 10          (integer division).
+// The longest list(s) are re-binned the same way over their own min..max; only when exactly one
+// sub-list is the longest overall is its median the new intercept c, else c = 0.
 // Outputs: c2x = 2*c (c is a multiple of 0.5), and over dots (x, y) = (j + c, i) with
 // abs(x-y)/abs(x) > 0.1 (x == 0: y/1 > 0.1) the count and the doubled sum of x - y.
-struct R4Shared {
-    double e1[11], e2[11];
-    int cnt1[11], min1[11], max1[11];
-    int cnt[11], vmin[11], vmax[11];
-    int lo, hi, n_lists, win_bin, win_sub, win_lo, win_hi, win_n, c2x, dir_n;
-    long long dir_sum2;
-};
-
-__device__ __forceinline__ int r4_bin(int v, const double* e)
+__device__ __forceinline__ int r4_bin(int v, int lo, int range)
 {
-    const double x = (double)v;
-    int b = 1;
-    for (; b < 11; ++b)
-        if (x < e[b]) break;
-    return b - 1;   // 10 = the list that takes what is left (dis_clu[-1])
+    return range > 0 ? (int)((unsigned)(10 * (v - lo)) / (unsigned)range) : 10;
 }
 
-__device__ void directed_stats(const uint32_t* __restrict__ hits, const uint8_t* __restrict__ hflags, long long n,
-                               uint32_t* counters, R4Shared* r)
+// kd_lo / kd_hi (min and max of i-j over the kept dots) must already be in *sh.
+template <typename HP, typename FP>
+__device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32_t* counters, CleanShared* sh)
 {
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        r->lo = 0x7FFFFFFF; r->hi = -0x7FFFFFFF; r->n_lists = 0; r->win_bin = -1; r->win_sub = -1;
-        r->win_lo = 0; r->win_hi = -1; r->win_n = 0; r->c2x = 0; r->dir_n = 0; r->dir_sum2 = 0;
-    }
-    if (tid < 11) { r->cnt1[tid] = 0; r->min1[tid] = 0x7FFFFFFF; r->max1[tid] = -0x7FFFFFFF; }
+    if (tid == 0) { sh->n_lists = 0; sh->c2x = 0; sh->dir_n = 0; sh->dir_sum2 = 0; sh->win_w = -1; }
+    if (tid < 11) sh->cnt1[tid] = 0;
     __syncthreads();
-    {
-        int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
-        for (long long h = tid; h < n; h += CLEAN_THREADS) {
-            if (!(hflags[h] & HF_C1)) continue;
+    const int lo1 = sh->kd_lo, range1 = sh->kd_hi - sh->kd_lo;
+    if (range1 < 0) return;                        // no kept dots (uniform)
+    // level 1: sizes of the eleven lists
+    for (int base = 0; base < n; base += CLEAN_THREADS) {
+        const int h = base + tid;
+        uint32_t key = INACTIVE_KEY;
+        if (h < n && (hflags[h] & HF_C1)) {
             uint32_t x = hits[h];
-            int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-            lo = min(lo, d); hi = max(hi, d);
+            key = (uint32_t)r4_bin((int)(x & 0xFFFFu) - (int)(x >> 16), lo1, range1);
         }
-        lo = wave_min_i32(lo); hi = wave_max_i32(hi);
-        if ((tid & 63) == 0) { atomicMin(&r->lo, lo); atomicMax(&r->hi, hi); }
-    }
-    __syncthreads();
-    if (r->hi < r->lo) return;                     // no kept dots (uniform)
-    if (tid < 11) r->e1[tid] = (double)r->lo + ((double)tid * (double)(r->hi - r->lo)) / 10.0;
-    __syncthreads();
-    for (long long h = tid; h < n; h += CLEAN_THREADS) {
-        if (!(hflags[h] & HF_C1)) continue;
-        uint32_t x = hits[h];
-        int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-        int b = r4_bin(d, r->e1);
-        atomicAdd(&r->cnt1[b], 1); atomicMin(&r->min1[b], d); atomicMax(&r->max1[b], d);
+        int len = run_head_len(key);
+        if (len) atomicAdd(&sh->cnt1[key], len);
     }
     __syncthreads();
     int best1 = 0;
-    for (int b = 0; b < 11; ++b) best1 = max(best1, r->cnt1[b]);
+    for (int b = 0; b < 11; ++b) best1 = max(best1, sh->cnt1[b]);
     for (int w = 0; w < 11; ++w) {
-        if (r->cnt1[w] != best1) continue;         // uniform: LDS value, no writer in this loop
-        if (tid < 11) {
-            r->cnt[tid] = 0; r->vmin[tid] = 0x7FFFFFFF; r->vmax[tid] = -0x7FFFFFFF;
-            r->e2[tid] = (double)r->min1[w] + ((double)tid * (double)(r->max1[w] - r->min1[w])) / 10.0;
+        if (sh->cnt1[w] != best1) continue;        // uniform (LDS, no writer inside the loop)
+        // min / max of list w, then the sizes of its eleven sub-lists
+        if (tid == 0) { sh->bin_lo = 0x7FFFFFFF; sh->bin_hi = -0x7FFFFFFF; }
+        if (tid < 11) sh->cnt2[tid] = 0;
+        __syncthreads();
+        {
+            int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+            for (int h = tid; h < n; h += CLEAN_THREADS) {
+                if (!(hflags[h] & HF_C1)) continue;
+                uint32_t x = hits[h];
+                int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+                if (r4_bin(d, lo1, range1) != w) continue;
+                lo = min(lo, d); hi = max(hi, d);
+            }
+            lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+            if ((tid & 63) == 0) { atomicMin(&sh->bin_lo, lo); atomicMax(&sh->bin_hi, hi); }
         }
         __syncthreads();
-        for (long long h = tid; h < n; h += CLEAN_THREADS) {
-            if (!(hflags[h] & HF_C1)) continue;
-            uint32_t x = hits[h];
-            int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-            if (r4_bin(d, r->e1) != w) continue;
-            int b = r4_bin(d, r->e2);
-            atomicAdd(&r->cnt[b], 1); atomicMin(&r->vmin[b], d); atomicMax(&r->vmax[b], d);
+        const int lo2 = sh->bin_lo, range2 = sh->bin_hi - sh->bin_lo;
+        for (int base = 0; base < n; base += CLEAN_THREADS) {
+            const int h = base + tid;
+            uint32_t key = INACTIVE_KEY;
+            if (h < n && (hflags[h] & HF_C1)) {
+                uint32_t x = hits[h];
+                int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+                if (r4_bin(d, lo1, range1) == w) key = (uint32_t)r4_bin(d, lo2, range2);
+            }
+            int len = run_head_len(key);
+            if (len) atomicAdd(&sh->cnt2[key], len);
         }
         __syncthreads();
         if (tid == 0) {
             int m2 = 0;
-            for (int b = 0; b < 11; ++b) m2 = max(m2, r->cnt[b]);
+            for (int b = 0; b < 11; ++b) m2 = max(m2, sh->cnt2[b]);
             for (int b = 0; b < 11; ++b)
-                if (r->cnt[b] == m2) {
-                    r->n_lists++;
-                    r->win_bin = w; r->win_sub = b;
-                    r->win_lo = r->vmin[b]; r->win_hi = r->vmax[b]; r->win_n = m2;
+                if (sh->cnt2[b] == m2) {
+                    sh->n_lists++;
+                    sh->win_w = w; sh->win_b = b; sh->win_lo2 = lo2; sh->win_r2 = range2; sh->win_n = m2;
                 }
         }
         __syncthreads();
     }
-    if (r->n_lists == 1) {
-        // median of the single longest sub-bin: per-value counters over its value span
-        const int w = r->win_bin, sb = r->win_sub, vlo = r->win_lo, width = r->win_hi - r->win_lo + 1, m = r->win_n;
-        if (tid < 11) r->e2[tid] = (double)r->min1[w] + ((double)tid * (double)(r->max1[w] - r->min1[w])) / 10.0;
+    if (sh->n_lists == 1) {
+        // median of the single longest sub-list: per-value counters over its value span
+        const int w = sh->win_w, b = sh->win_b, lo2 = sh->win_lo2, range2 = sh->win_r2, m = sh->win_n;
+        // values of sub-list b: 10*(v-lo2) in [b*range2, (b+1)*range2)  ->  v in [vlo, vhi]
+        const int vlo = range2 > 0 ? lo2 + (b * range2 + 9) / 10 : lo2;
+        const int vhi = range2 > 0 ? min(lo2 + range2, lo2 + ((b + 1) * range2 + 9) / 10 - 1) : lo2;
+        const int width = vhi - vlo + 1;
         for (int q = tid; q < width; q += CLEAN_THREADS) counters[q] = 0;
         __syncthreads();
-        for (long long h = tid; h < n; h += CLEAN_THREADS) {
-            if (!(hflags[h] & HF_C1)) continue;
-            uint32_t x = hits[h];
-            int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-            if (r4_bin(d, r->e1) != w || r4_bin(d, r->e2) != sb) continue;
-            atomicAdd(&counters[d - vlo], 1u);
+        for (int base = 0; base < n; base += CLEAN_THREADS) {
+            const int h = base + tid;
+            uint32_t key = INACTIVE_KEY;
+            if (h < n && (hflags[h] & HF_C1)) {
+                uint32_t x = hits[h];
+                int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+                if (d >= vlo && d <= vhi && r4_bin(d, lo1, range1) == w && r4_bin(d, lo2, range2) == b)
+                    key = (uint32_t)(d - vlo);
+            }
+            int len = run_head_len(key);
+            if (len) atomicAdd(&counters[key], (uint32_t)len);
         }
         __syncthreads();
         if (tid == 0) {
@@ -578,37 +624,87 @@ __device__ void directed_stats(const uint32_t* __restrict__ hits, const uint8_t*
                 if (!g0 && acc > k0) { v0 = vlo + q; g0 = true; }
                 if (!g1 && acc > k1) { v1 = vlo + q; g1 = true; }
             }
-            r->c2x = v0 + v1;
+            sh->c2x = v0 + v1;
         }
     }
     __syncthreads();
     {
-        const int c2x = r->c2x;
+        const int c2x = sh->c2x;
         int cn = 0;
         long long cs = 0;
-        for (long long h = tid; h < n; h += CLEAN_THREADS) {
+        for (int h = tid; h < n; h += CLEAN_THREADS) {
             if (!(hflags[h] & HF_C1)) continue;
             uint32_t x = hits[h];
             int i = (int)(x & 0xFFFFu), j = (int)(x >> 16);
-            long long X = 2LL * j + c2x, Y = 2LL * i;
-            long long df = X - Y, adf = df < 0 ? -df : df, aX = X < 0 ? -X : X;
+            int X = 2 * j + c2x, Y = 2 * i;
+            int df = X - Y, adf = df < 0 ? -df : df, aX = X < 0 ? -X : X;
             bool far = (X == 0) ? (i >= 1) : (10 * adf > aX);
             if (far) { ++cn; cs += df; }
         }
         cn = wave_sum_i32(cn); cs = wave_sum_i64(cs);
-        if ((tid & 63) == 0) { atomicAdd(&r->dir_n, cn); atomicAdd((unsigned long long*)&r->dir_sum2, (unsigned long long)cs); }
+        if ((tid & 63) == 0) { atomicAdd(&sh->dir_n, cn); atomicAdd((unsigned long long*)&sh->dir_sum2, (unsigned long long)cs); }
     }
     __syncthreads();
 }
 
+// everything after the hits are in place (LDS copy or global), for one pair
+template <typename HP, typename FP>
+__device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPair& pr, int len2, int range_words,
+                                           uint32_t* bm, uint32_t* sb, uint32_t* wrank, uint32_t* gcnt,
+                                           CleanShared* sh, long long* st)
+{
+    const int tid = threadIdx.x;
+    const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u, s3 = (pr.flags & 4u) && c1;
+    if (c1 || c2)   // i - j over all dots: C1's diagonal groups (>10) and C2's diagonal step
+        cluster_axis<false>(hits, hflags, n, len2, range_words, bm, sb, wrank, gcnt, sh, 0u, c1 ? WF_D1 : 0u,
+                            c2 ? HF_C2D : 0u);
+    if (c1)         // i + j over all dots: C1's anti-diagonal groups
+        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, sh, 0u, WF_A1, 0u);
+    if (c2)         // i + j over the dots the diagonal step left: C2's anti-diagonal step
+        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
+    // final pass: reductions and public flags
+    {
+        int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
+        long long sabs = 0;
+        for (int h = tid; h < n; h += CLEAN_THREADS) {
+            uint32_t f = hflags[h];
+            uint32_t x = hits[h];
+            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            int ad = j > i ? j - i : i - j;
+            uint32_t pub = f & (HF_C2D | HF_C2A);
+            if (f & (WF_D1 | WF_A1)) { pub |= HF_C1; ++k1; sabs += ad; dlo = min(dlo, i - j); dhi = max(dhi, i - j); }
+            if (f & (HF_C2D | HF_C2A)) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
+            kd += (f & HF_C2D) ? 1 : 0;
+            hflags[h] = (uint8_t)pub;
+        }
+        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
+        sabs = wave_sum_i64(sabs); dlo = wave_min_i32(dlo); dhi = wave_max_i32(dhi);
+        if ((tid & 63) == 0) {
+            atomicAdd(&sh->c1_kept, k1); atomicAdd(&sh->c2_kept, k2); atomicAdd(&sh->c2_count10, c10);
+            atomicAdd(&sh->c2_kept_diag, kd); atomicAdd(&sh->c1_sum_abs, (unsigned long long)sabs);
+            atomicMin(&sh->kd_lo, dlo); atomicMax(&sh->kd_hi, dhi);
+        }
+    }
+    __syncthreads();
+    if (s3) directed_stats(hits, hflags, n, gcnt, sh);
+    if (tid == 0) {
+        st[0] = n; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
+        st[5] = sh->c2_kept; st[6] = sh->c2_count10; st[7] = sh->n_diag; st[8] = sh->n_lower; st[9] = sh->c2_kept_diag;
+        st[10] = s3 ? sh->c2x : 0; st[11] = s3 ? sh->dir_n : 0; st[12] = s3 ? sh->dir_sum2 : 0; st[13] = s3 ? sh->n_lists : 0;
+        st[14] = 0; st[15] = 0;
+    }
+}
+
+// One workgroup per pair.  Dynamic LDS: bm | sb | wrank (range_words_cap words each) | gcnt
+// (groups_cap words) | hit copy (hcap words) | flag bytes (hcap).  Pairs with at most hcap hits
+// are cleaned entirely out of LDS; larger ones stream their hits from L2/HBM on every pass.
 __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
     const SeqDesc* __restrict__ seqs, const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
-    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap)
+    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
-    __shared__ R4Shared r4;
     const int tid = threadIdx.x;
     const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
     const DPair pr = pairs[p];
@@ -624,31 +720,35 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
         }
         return;
     }
-    const long long n = (long long)nh;
-    const uint32_t* hits = hits_all + pr.hit_off;
-    uint8_t* hflags = hflags_all + pr.hit_off;
+    const int n = (int)nh;                     // cap < 2^31
+    const uint32_t* ghits = hits_all + pr.hit_off;
+    uint8_t* gflags = hflags_all + pr.hit_off;
     const int len1 = seqs[pr.seq1].len, len2 = seqs[pr.seq2].len;
-    const int range = len1 + len2 + 2;
-    const int range_words = min((range + 31) >> 5, range_words_cap);
+    const int range_words = min((len1 + len2 + 2 + 31) >> 5, range_words_cap);
     uint32_t* bm = lds;
     uint32_t* sb = bm + range_words_cap;
     uint32_t* wrank = sb + range_words_cap;
     uint32_t* gcnt = wrank + range_words_cap;
+    uint32_t* lhits = gcnt + groups_cap;
+    uint8_t* lflags = reinterpret_cast<uint8_t*>(lhits + hcap);
+    const bool in_lds = n <= hcap;
 
     if (tid == 0) {
         sh.min_j = 0x7FFFFFFF; sh.max_j = -1; sh.n_diag = 0; sh.n_lower = 0;
         sh.c1_kept = 0; sh.c2_kept = 0; sh.c2_count10 = 0; sh.c2_kept_diag = 0; sh.c1_sum_abs = 0ULL;
+        sh.kd_lo = 0x7FFFFFFF; sh.kd_hi = -0x7FFFFFFF;
     }
     __syncthreads();
-    // pass 0: first/last j, diagonal and lower-triangle counts; clear the flag bytes
+    // pass 0: first/last j, diagonal and lower-triangle counts; stage the hits, clear the flags
     {
         int mn = 0x7FFFFFFF, mx = -1, nd = 0, nl = 0;
-        for (long long h = tid; h < n; h += CLEAN_THREADS) {
-            uint32_t x = hits[h];
+        for (int h = tid; h < n; h += CLEAN_THREADS) {
+            uint32_t x = ghits[h];
             int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
             mn = min(mn, j); mx = max(mx, j);
             nd += (j == i); nl += (j > i);
-            hflags[h] = 0;
+            if (in_lds) { lhits[h] = x; lflags[h] = 0; }
+            else gflags[h] = 0;
         }
         mn = wave_min_i32(mn); mx = wave_max_i32(mx); nd = wave_sum_i32(nd); nl = wave_sum_i32(nl);
         if ((tid & 63) == 0) {
@@ -657,44 +757,12 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
         }
     }
     __syncthreads();
-    const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u;
-    if (c1 || c2)   // i - j over all dots: C1's diagonal groups (>10) and C2's diagonal step
-        cluster_axis<false>(hits, hflags, n, len2, range_words, bm, sb, wrank, gcnt, &sh, 0u,
-                            c1 ? WF_D1 : 0u, c2 ? HF_C2D : 0u);
-    if (c1)         // i + j over all dots: C1's anti-diagonal groups
-        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, &sh, 0u, WF_A1, 0u);
-    if (c2)         // i + j over the dots the diagonal step left: C2's anti-diagonal step
-        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, &sh, HF_C2D, 0u, HF_C2A);
-    // final pass: reductions and public flags
-    {
-        int k1 = 0, k2 = 0, c10 = 0, kd = 0;
-        long long sabs = 0;
-        for (long long h = tid; h < n; h += CLEAN_THREADS) {
-            uint32_t f = hflags[h];
-            uint32_t x = hits[h];
-            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            int ad = j > i ? j - i : i - j;
-            uint32_t pub = f & (HF_C2D | HF_C2A);
-            if (f & (WF_D1 | WF_A1)) { pub |= HF_C1; ++k1; sabs += ad; }
-            if (f & (HF_C2D | HF_C2A)) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
-            kd += (f & HF_C2D) ? 1 : 0;
-            hflags[h] = (uint8_t)pub;
-        }
-        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
-        sabs = wave_sum_i64(sabs);
-        if ((tid & 63) == 0) {
-            atomicAdd(&sh.c1_kept, k1); atomicAdd(&sh.c2_kept, k2); atomicAdd(&sh.c2_count10, c10);
-            atomicAdd(&sh.c2_kept_diag, kd); atomicAdd(&sh.c1_sum_abs, (unsigned long long)sabs);
-        }
-    }
-    __syncthreads();
-    const bool s3 = (pr.flags & 4u) && c1;
-    if (s3) directed_stats(hits, hflags, n, gcnt, &r4);
-    if (tid == 0) {
-        st[0] = n; st[1] = sh.min_j; st[2] = sh.max_j; st[3] = sh.c1_kept; st[4] = (long long)sh.c1_sum_abs;
-        st[5] = sh.c2_kept; st[6] = sh.c2_count10; st[7] = sh.n_diag; st[8] = sh.n_lower; st[9] = sh.c2_kept_diag;
-        st[10] = s3 ? r4.c2x : 0; st[11] = s3 ? r4.dir_n : 0; st[12] = s3 ? r4.dir_sum2 : 0; st[13] = s3 ? r4.n_lists : 0;
-        st[14] = 0; st[15] = 0;
+    if (in_lds) {
+        clean_body((const uint32_t*)lhits, lflags, n, pr, len2, range_words, bm, sb, wrank, gcnt, &sh, st);
+        __syncthreads();
+        for (int h = tid; h < n; h += CLEAN_THREADS) gflags[h] = lflags[h];
+    } else {
+        clean_body(ghits, gflags, n, pr, len2, range_words, bm, sb, wrank, gcnt, &sh, st);
     }
 }
 
