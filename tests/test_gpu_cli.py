@@ -1,0 +1,54 @@
+"""`vapor bed` end to end on the GPU: table identical to the reference's, byte for byte."""
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+LOCUS = load_golden("locus_bed.json.gz")["cases"]
+
+
+@pytest.mark.parametrize("case", [c for c in LOCUS if not any("error" in p["scores"] for p in c["per_locus"])],
+                         ids=lambda c: c["name"])
+def test_bed_cli_rows_gpu(case, tmp_path):
+    from vapor_amd import cli, pipeline, seqio, synth
+    pipeline.set_engine(None)
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
+    try:
+        bed = tmp_path / "in.bed"
+        bed.write_text(case["bed"])
+        out = tmp_path / "out.vapor"
+        rc = cli.main(["bed", "--sv-input", str(bed), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                       "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"])
+        assert rc == 0
+        assert out.read_text() == case["vapor_text"]
+    finally:
+        seqio.set_backend(None)
+
+
+def test_reference_named_functions_gpu():
+    from vapor_amd import pipeline
+    from vapor_vali.Simple_function import dotdata, window_size_refine, clean_dotdata_diagnal_and_anti_diagnal
+    pipeline.set_engine(None)
+    kat = "ACGTACGTACGTTTGACCA"
+    assert dotdata(10, kat, kat) == [(0, 0), (0, 2), (1, 1), (1, 1), (2, 0), (2, 2), (3, 3), (4, 4), (5, 5), (6, 6),
+                                      (7, 7), (8, 8), (9, 9)]
+    with pytest.raises(KeyError):
+        dotdata(10, "ACGTACGTACGTXACGT", kat)
+    assert window_size_refine("ACGTAC") == ["Error", "Error"]
+    dots = [(t, t) for t in range(11)]
+    assert clean_dotdata_diagnal_and_anti_diagnal(dots) == dots
+    assert clean_dotdata_diagnal_and_anti_diagnal(dots[:10]) == []
+
+
+def test_figures_render(tmp_path):
+    from vapor_amd import drivers, figures, pipeline, synth
+    import numpy as np
+    pipeline.set_engine(None)
+    rng = np.random.default_rng(4)
+    ref = synth.random_dna(rng, 1500)
+    alt = ref[:500] + ref[-500:]
+    read, _ = synth.mutate(rng, alt)
+    out = tmp_path / "x.DEL.c1__1__2__DEL.png"
+    figures.make_event_figure_1(drivers.Figure([0.5], [read[:990], 0, "r"], 10, ref, alt, str(out)))
+    assert out.exists() and out.stat().st_size > 1000

@@ -1,0 +1,355 @@
+"""`vapor bed | vcf | ins` - the reference's command line (vapor_vali/vapor:287-496) on the HIP path.
+
+Same sub-commands, same flags, same output files and rows.  What differs is the schedule: the
+reference scores one locus at a time; here every locus becomes a driver generator
+(vapor_amd.drivers) and `pipeline.run_batch` sends the pending dot plots of a whole chunk of loci
+to the GPU together.  With more than one rank (torchrun), loci are sharded across the GPUs of
+the node and the per-locus rows are all-gathered (vapor_amd.dist).
+
+Extra flags (not in the reference): --no-figures (skip the recurrence-plot PNGs),
+--chunk (loci per device batch).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from typing import List, Optional
+
+from . import dist as vdist
+from . import drivers, pipeline
+from . import simple_function as SF
+from .finish import result_organize_ins
+
+
+# ------------------------------------------------------------------------------------------
+# input parsers (SURVEY.md component #10)
+# ------------------------------------------------------------------------------------------
+
+def bed_info_readin(bed_input, out_path):
+    """vapor_vali/vapor:22-50: rows are chr start end SVID TYPE [INS sequence]."""
+    out_path = SF.path_modify(out_path)
+    SF.path_mkdir(out_path)
+    out = []
+    with open(bed_input) as fin:
+        for line in fin:
+            pin = line.strip().split()
+            t = pin[4]
+            if 'DUP' in t or 'duplication' in t:
+                out.append([pin[0]] + [int(i) for i in pin[1:3]] + [pin[3]] + ['a/a', 'a/aa'])
+            elif 'DEL' in t or 'deletion' in t:
+                out.append([pin[0]] + [int(i) for i in pin[1:3]] + [pin[3]] + ['a/a', '/a'])
+            elif 'INV' in t or 'inversion' in t:
+                out.append([pin[0]] + [int(i) for i in pin[1:3]] + [pin[3]] + ['a/a', 'a/a^'])
+            elif 'INS' in t or 'ALU' in t or 'HERVK' in t or 'LINE1' in t or 'SVA' in t or 'insertion' in t:
+                if len(pin) > 5:
+                    out.append([pin[0], int(pin[1]), int(pin[2]), pin[3], pin[5], 'INS'])
+                elif '_' in t:
+                    v = t.split('_')[1]
+                    out.append([pin[0], int(pin[1]), int(pin[2]), pin[3], int(v) if v.isdigit() else v, 'INS'])
+    return out
+
+
+def block_reorganize(block_hash):
+    """vapor_vali/vapor:83-97: blocks of one chromosome ordered by start, duplicates dropped."""
+    if len(block_hash) == 1:
+        for k1 in block_hash:
+            start = [i[1] for i in block_hash[k1]]
+            order = [start.index(i) for i in sorted(start)]
+            out = []
+            for b in [block_hash[k1][i] for i in order]:
+                if b not in out:
+                    out.append(b)
+            return out
+    return 'error'
+
+
+def del_inv_interprete(pin):
+    """vapor_vali/vapor:99-111: del=chr:s-e / inv=chr:s-e INFO entries."""
+    out = {}
+    for x in pin[7].split(';'):
+        for tag, name in (('del=', 'del'), ('DEL=', 'del'), ('inv=', 'inv'), ('INV=', 'inv')):
+            if tag in x:
+                v = x.split('=')[1]
+                blk = [v.split(':')[0]] + [int(i) for i in v.split(':')[1].split('-')]
+                out.setdefault(blk[0], []).append(blk + [name])
+                break
+    return block_reorganize(out)
+
+
+def dup_inv_interprete(pin):
+    """vapor_vali/vapor:113-125."""
+    seg = [pin[0], int(pin[1])]
+    ins = []
+    for x in pin[7].split(';'):
+        if 'END=' in x:
+            seg.append(int(x.split('=')[1]))
+        if 'insert_point' in x or 'INSERT_POINT' in x:
+            ins = x.split('=')[1].split(':')
+    if len(ins) > 1:
+        return seg + [ins[0], int(ins[1])]
+    return 'error'
+
+
+def vcf_list_readin(file_in):
+    """vapor_vali/vapor:127-202: records bucketed by type in first-seen order, plus
+    {file line index: key} for the INFO rewrite."""
+    out = {}
+    rec_hash = {}
+    rec = -1
+    with open(file_in) as fin:
+        for line in fin:
+            rec += 1
+            pin = line.strip().split()
+            if pin[0][0] == '#':
+                continue
+            pin[7] = pin[7].replace('MERGE_TYPE=', 'SVTYPE=')
+            t = SF.svtype_extract(pin)
+            pos = SF.chr_start_end_extract(pin)
+
+            if t in ['del', 'DEL', 'deletion']:
+                out.setdefault('DEL', [])
+                if pos not in out['DEL']:
+                    out['DEL'].append(pos)
+                    rec_hash[rec] = ':'.join([str(i) for i in pos] + ['DEL'])
+            elif t in ['inv', 'INV', 'inversion']:
+                out.setdefault('INV', [])
+                if pos not in out['INV']:
+                    out['INV'].append(pos)
+                    rec_hash[rec] = ':'.join([str(i) for i in pos] + ['INV'])
+            elif t in ['ins', 'INS', 'insertion', 'LINE1', 'SVA', 'ALU', 'HERVK']:
+                sv_len = int(SF.sv_len_extract(pin))
+                seq = SF.sv_seq_extract(pin)
+                if sv_len > 0:
+                    out.setdefault('INS', [])
+                    if pos not in out['INS']:
+                        out['INS'].append(pos[:2] + [sv_len, seq])
+                        rec_hash[rec] = ':'.join([str(i) for i in pos[:2] + [sv_len]] + ['INS'])
+            elif t in ['disdup', 'DISDUP', 'dis-dup']:
+                ip = SF.sv_insert_point_define(pin)
+                out.setdefault('DISDUP', [])
+                if pos not in out['DISDUP']:
+                    out['DISDUP'].append(pos + ip)
+                    rec_hash[rec] = ':'.join([str(i) for i in pos + ip] + ['DISDUP'])
+            elif t in ['DEL_INV', 'del_inv']:
+                out.setdefault('DEL_INV', [])
+                info = del_inv_interprete(pin)
+                if not info == 'error' and info not in out['DEL_INV']:
+                    out['DEL_INV'].append(info)
+                    rec_hash[rec] = ':'.join(['_'.join([str(i) for i in j]) for j in info] + ['DEL_INV'])
+            elif t in ['DUP_INV', 'dup_inv']:
+                out.setdefault('DUP_INV', [])
+                info = dup_inv_interprete(pin)
+                if not info == 'error' and info not in out['DUP_INV']:
+                    out['DUP_INV'].append(info)
+                    rec_hash[rec] = ':'.join([str(i) for i in info + ['DUP_INV']])
+            elif t in ['tandup', 'TANDUP', 'DUP']:
+                out.setdefault('TANDUP', [])
+                if pos not in out['TANDUP']:
+                    out['TANDUP'].append(pos)
+                    rec_hash[rec] = ':'.join([str(i) for i in pos] + ['TANDUP'])
+            elif t in ['CNV', 'CSV', 'CPX']:
+                continue
+            else:
+                if 'Other=' in pin[7]:
+                    info = [i for i in pin[7].split(';') if i[:6] == 'Other=']
+                elif 'OTHER=' in pin[7]:
+                    info = [i for i in pin[7].split(';') if i[:6] == 'OTHER=']
+                else:
+                    continue
+                o = info[0].split('=')[1].split('_')
+                item = ['_'.join(i.split('/')) for i in o[:2]] + o[2].split(':')
+                out.setdefault('Other', [])
+                if item not in out['Other']:
+                    out['Other'].append(item)
+                    rec_hash[rec] = ':'.join([str(i) for i in item + ['CANNOT_CLASSIFY']])
+    return [out, rec_hash]
+
+
+# ------------------------------------------------------------------------------------------
+# jobs
+# ------------------------------------------------------------------------------------------
+
+class Job:
+    """One output row: how to score it (a driver generator factory, or fixed scores) and how to
+    write it."""
+    __slots__ = ("key", "make", "fixed", "row_prefix", "label")
+
+    def __init__(self, key, make=None, fixed=None, row_prefix=None, label=None):
+        self.key, self.make, self.fixed, self.row_prefix, self.label = key, make, fixed, row_prefix, label
+
+
+def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> List[Job]:
+    """The loop of vapor_vali/vapor:334-367."""
+    jobs = []
+    plt_li = 0
+    for x in bed_info:
+        tag = x[-1]
+        if tag in ['a/', '/a', '/', 'DEL']:
+            key = ':'.join([str(i) for i in x[:-3]] + ['DEL'])
+            fn, name = drivers.vapor_simple_del, 'DEL'
+        elif tag in ['a/a^', 'a^/a', 'a^/a^', 'INV']:
+            key = ':'.join([str(i) for i in x[:-3]] + ['INV'])
+            fn, name = drivers.vapor_simple_inv, 'INV'
+        elif tag in ['INS']:
+            key = ':'.join([str(i) for i in x[:-3] + ['INS']])
+            plt_li += 1
+            ins_pos = '_'.join([str(i) for i in x[:2]])
+            ins_seq = ''.join(['X' for _ in range(x[4])]) if type(x[4]) == type(4) else x[4]
+            fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
+            jobs.append(Job(key, (lambda p=plt_li, a=ins_pos, s=ins_seq, f=fig:
+                                  drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, f, '+')),
+                            row_prefix=x[3], label=x))
+            continue
+        elif tag in ['a/aa', 'aa/a', 'aa/aa', 'DUP', 'TANDUP']:
+            key = ':'.join([str(i) for i in x[:-3]] + ['TANDUP'])
+            fn, name = drivers.vapor_simple_tandup, 'TANDUP'
+        else:
+            print(x)
+            continue
+        plt_li += 1
+        fig = out_path + sample_name + '.' + name + '.' + key.replace(':', '__') + '.png'
+        jobs.append(Job(key, (lambda p=plt_li, f=fn, info=x[:-3], g=fig: f(num_reads_cff, p, bam_in, ref, info, g)),
+                        row_prefix=x[3], label=x))
+    return jobs
+
+
+def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> List[Job]:
+    """The loop of vapor_vali/vapor:387-465 (TANDUP is bucketed but never scored there either)."""
+    jobs = []
+    plt_li = 0
+    for x in list(vcf_list.keys()):
+        if x not in ('DEL', 'INV', 'INS', 'DISDUP', 'DEL_INV', 'DUP_INV', 'Other'):
+            print(x)
+            continue
+        for y in vcf_list[x]:
+            if 'NA' in y:
+                continue
+            print(y)
+            plt_li += 1
+            if x in ('DEL', 'INV'):
+                if y[2] - y[1] < 50:        # both branches label the row DEL (vapor_vali/vapor:394, 407)
+                    jobs.append(Job(':'.join([str(i) for i in y] + ['DEL']), fixed=[]))
+                    continue
+                key = ':'.join([str(i) for i in y] + [x])
+                fn = drivers.vapor_simple_del if x == 'DEL' else drivers.vapor_simple_inv
+                fig = out_path + sample_name + '.' + x + '.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, f=fn, info=y, g=fig: f(num_reads_cff, p, bam_in, ref, info, g))))
+            elif x == 'INS':
+                key = ':'.join([str(i) for i in y[:3] + ['INS']])
+                ins_pos = '_'.join([str(i) for i in y[:2]])
+                ins_seq = y[-1] if len(y) == 4 else ''.join(['X' for _ in range(y[2])])
+                fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, a=ins_pos, s=ins_seq, g=fig:
+                                      drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, '+'))))
+            elif x == 'DISDUP':
+                key = ':'.join([str(i) for i in y + ['DISDUP']])
+                fig = out_path + sample_name + '.DISDUP.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
+                                      drivers.vapor_simple_disdup(num_reads_cff, p, bam_in, ref, info, g))))
+            elif x == 'DEL_INV':
+                key = ':'.join(['_'.join([str(i) for i in j]) for j in y] + ['DEL_INV'])
+                fig = out_path + sample_name + '.DEL_INV.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
+                                      drivers.vapor_del_inv(num_reads_cff, p, bam_in, ref, info, g))))
+            elif x == 'DUP_INV':
+                key = ':'.join([str(i) for i in y + ['DUP_INV']])
+                fig = out_path + sample_name + '.DUP_INV.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
+                                      drivers.vapor_dup_inv(num_reads_cff, p, bam_in, ref, info, g))))
+            elif x == 'Other':
+                raise NotImplementedError("records with an Other= structure (vapor_CANNOT_CLASSIFY_VapoR, SF:1490) "
+                                          "are not scored by this build yet: %s" % (y,))
+    return jobs
+
+
+def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
+    """Score every job (sharded over ranks, batched on each GPU); returns per job the list of read
+    scores, in job order, identical on every rank."""
+    mine = vdist.my_share(len(jobs))
+    local: dict = {}
+    for a in range(0, len(mine), max(chunk, 1)):
+        part = mine[a:a + chunk]
+        todo = [t for t in part if jobs[t].make is not None]
+        res = pipeline.run_batch([jobs[t].make() for t in todo], figure_fn=figure_fn)
+        for t, r in zip(todo, res):
+            local[t] = r
+        for t in part:
+            if jobs[t].make is None:
+                local[t] = jobs[t].fixed
+    allres = vdist.gather_results(local, len(jobs))
+    for r in allres:
+        if isinstance(r, BaseException):
+            raise r
+    return allres
+
+
+# ------------------------------------------------------------------------------------------
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="vapor", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument('--sv-input', required=True, help='input file of SV calls')
+    p.add_argument('--reference', required=True, help='reference sequences')
+    p.add_argument('--pacbio-input', required=True, help='input pacbio sequences in bam format')
+    p.add_argument('--output-path', required=True, help='path of output VaPoR figures')
+    p.add_argument('--output-file', required=True, help='name of output file')
+    p.add_argument('--PB-supp', required=False, help='minimum number of evaluable PacBio reads')
+    p.add_argument('--no-figures', action='store_true', help='do not render recurrence-plot PNGs')
+    p.add_argument('--chunk', type=int, default=2048, help='loci per device batch')
+    return p
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) < 1:
+        from . import prep
+        prep.print_read_me()
+        return 0
+    mode = argv[0]
+    if len(argv) == 1:
+        from . import prep
+        {'bed': prep.readme_bed, 'vcf': prep.readme_vcf, 'ins': prep.readme_melt}.get(mode, prep.print_read_me)()
+        return 0
+    args = build_parser().parse_args(argv[1:])
+    num_reads_cff = int(args.PB_supp) if args.PB_supp else 3
+    figure_fn = None
+    if not args.no_figures:
+        from . import figures
+        figure_fn = figures.make_event_figure_1
+    vdist.init_from_env()
+    out_path = SF.path_modify(args.output_path)
+    SF.path_mkdir(out_path)
+    sample_name = '.'.join(args.sv_input.split('/')[-1].split('.')[:-1])
+    bam_in, ref = args.pacbio_input, args.reference
+    if mode == 'bed':
+        bed_info = bed_info_readin(args.sv_input, out_path)
+        jobs = bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name)
+        scores = score_jobs(jobs, args.chunk, figure_fn)
+        if vdist.rank() == 0:
+            SF.write_output_initiate(args.output_file)
+            with open(args.output_file, 'a') as fo:
+                for j, sc in zip(jobs, scores):
+                    res = result_organize_ins([j.key, sc])
+                    print(SF.format_output_row(res[0].split(':') + [j.row_prefix] + res[1:]), file=fo)
+                    print(res)
+    elif mode == 'vcf':
+        vcf_list, rec_hash = vcf_list_readin(args.sv_input)
+        rec_new = SF.vcf_rec_hash_modify(rec_hash)
+        jobs = vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name)
+        scores = score_jobs(jobs, args.chunk, figure_fn)
+        if vdist.rank() == 0:
+            SF.write_output_initiate(args.sv_input + '.vapor')
+            with open(args.sv_input + '.vapor', 'a') as fo:
+                for j, sc in zip(jobs, scores):
+                    print(SF.format_output_row(result_organize_ins([j.key, sc])), file=fo)
+            SF.vcf_vapor_modify(args.sv_input, rec_new)
+    elif mode == 'ins':
+        from . import melt
+        melt.run(args.sv_input, out_path, sample_name.split('.')[0], bam_in, ref, num_reads_cff, args.chunk, figure_fn)
+    else:
+        raise SystemExit("vapor: unknown mode %r (bed | vcf | ins)" % mode)
+    vdist.finalize()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

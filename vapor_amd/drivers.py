@@ -1,0 +1,396 @@
+"""Locus drivers: allele-string construction, read selection and scorer choice per SV type
+(component #2; reference SF:1490-1933).
+
+Each driver is a generator.  It does its host-side string work itself and *yields* the two
+kinds of device work the reference does inline -
+
+    Window(seq)                             -> window_size_refine(seq)            (SF:2030-2046)
+    Score(kind, ref_seq, alt_seq, reads, k) -> [calcu_vapor_single_read_score_*(ref, alt, x, k)
+                                                for x in reads]
+
+- and receives the results back through send().  Run one generator at a time
+(`pipeline.run_sync`) and it behaves like the reference's function of the same name; run many
+in lockstep (`pipeline.run_batch`) and the pending requests of all loci go to the GPU as one
+batch.  The control flow, fallbacks and quirks of the reference are kept, including the places
+where it raises (cited inline).
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+from . import seqio
+
+default_flank_length = 500       # SF:21-22
+default_max_sv_test = 10000      # SF:25-26
+
+
+class Window:
+    __slots__ = ("seq",)
+
+    def __init__(self, seq: str):
+        self.seq = seq
+
+
+class Score:
+    """kind: 's1' abs_dis_m1b, 's2' within_10Perc_m1b, 's3' directed_dis_m1b_redefine_diagnal,
+    'del' = s1 and s2 for the same reads (result: (list_s1, list_s2))."""
+    __slots__ = ("kind", "ref_seq", "alt_seq", "reads", "k")
+
+    def __init__(self, kind, ref_seq, alt_seq, reads, k):
+        self.kind, self.ref_seq, self.alt_seq, self.reads, self.k = kind, ref_seq, alt_seq, reads, k
+
+
+class Figure:
+    """make_event_figure_1 (SF:1072-1089) request; executors may render it or drop it."""
+    __slots__ = ("scores", "best_read", "k", "ref_seq", "alt_seq", "name")
+
+    def __init__(self, scores, best_read, k, ref_seq, alt_seq, name):
+        self.scores, self.best_read, self.k = scores, best_read, k
+        self.ref_seq, self.alt_seq, self.name = ref_seq, alt_seq, name
+
+
+def _ratio(ab) -> float:
+    return 1 - float(ab[1]) / float(ab[0])
+
+
+def _collect(results, reads, scores: List[float], nan_guard: bool = False, keep=None):
+    """The per-read loop every driver repeats (e.g. SF:1909-1915): a read counts when neither
+    scorer output is 0; returns the read with the best score so far (ties: the later read)."""
+    best = ""
+    it = iter(results)
+    for x in reads:
+        if keep is not None and not keep(x):
+            continue
+        ab = next(it)
+        if 0 in ab:
+            continue
+        if nan_guard and (math.isnan(ab[0]) or math.isnan(ab[1])):
+            continue
+        scores.append(_ratio(ab))
+        if scores[-1] == max(scores):
+            best = x
+    return best
+
+
+def _window(seq):
+    res = yield Window(seq)
+    return res[0]
+
+
+def _rc(seq: str) -> str:
+    return seqio.reverse(seqio.complementary(seq))
+
+
+# ------------------------------------------------------------------------------------------
+def vapor_simple_del(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_simple_del_Vapor, SF:1701-1745."""
+    flank = seqio.flank_length_calculate(sv_info)
+    scores: List[float] = []
+    if sv_info[2] - sv_info[1] < default_max_sv_test:
+        reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
+        if len(reads) > num_reads_cff:
+            ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[2] + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                alt_seq = ref_seq[:flank] + ref_seq[-flank:]
+                r1, r2 = yield Score("del", ref_seq, alt_seq, reads, k)
+                best = ""
+                for x, a, b in zip(reads, r1, r2):
+                    if not 0 in a and not 0 in b:
+                        scores.append(min([_ratio(a), _ratio(b)]))
+                    elif not 0 in a:
+                        scores.append(_ratio(a))
+                    elif not 0 in b:
+                        scores.append(_ratio(b))
+                    else:
+                        continue
+                    if scores[-1] == max(scores):
+                        best = x
+                yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    else:
+        reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
+        if len(reads) > num_reads_cff:
+            ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1] + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                alt_seq = (seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1])
+                           + seqio.ref_seq_readin(ref, sv_info[0], sv_info[2], sv_info[2] + flank))
+                k = yield from _window(alt_seq)
+                if not k == "Error":
+                    res = yield Score("s2", ref_seq, alt_seq, reads, k)
+                    best = _collect(res, reads, scores)
+                    yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_simple_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_simple_inv_Vapor, SF:1895-1933."""
+    flank = seqio.flank_length_calculate(sv_info)
+    scores: List[float] = []
+    if sv_info[2] - sv_info[1] < default_max_sv_test:
+        ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[2] + flank)
+        k = yield from _window(ref_seq)
+        if not k == "Error":
+            alt_seq = ref_seq[:flank] + _rc(ref_seq[flank:(-flank)]) + ref_seq[-flank:]
+            k = yield from _window(alt_seq)
+            if not k == "Error":
+                reads = seqio.simple_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
+                if len(reads) > num_reads_cff:
+                    res = yield Score("s1", ref_seq, alt_seq, reads, k)
+                    best = _collect(res, reads, scores)
+                    yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+                    return scores
+    ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1] + flank)
+    k = yield from _window(ref_seq)
+    if not k == "Error":
+        alt_seq = ref_seq[:flank] + seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2], "TRUE")
+        k = yield from _window(alt_seq)
+        if not k == "Error":
+            reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
+            if len(reads) > num_reads_cff:
+                res = yield Score("s2", ref_seq, alt_seq, reads, k)
+                best = _collect(res, reads, scores)
+                yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_simple_tandup(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_simple_tandup_Vapor, SF:1747-1784."""
+    flank = seqio.flank_length_calculate(sv_info)
+    scores: List[float] = []
+    if sv_info[2] - sv_info[1] < default_max_sv_test:
+        ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[2] + flank)
+        k = yield from _window(ref_seq)
+        if not k == "Error":
+            mid = ref_seq[flank:(-flank)]
+            alt_seq = ref_seq[:flank] + mid + mid + ref_seq[-flank:]
+            k = yield from _window(alt_seq)
+            if not k == "Error":
+                reads = seqio.simple_chop_pacbio_read_simple_short(
+                    bam_in, sv_info[:2] + [sv_info[1] + 2 * (sv_info[2] - sv_info[1])], flank)
+                if len(reads) > num_reads_cff:
+                    res = yield Score("s3", ref_seq, alt_seq, reads, k)
+                    best = _collect(res, reads, scores)
+                    yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+                    return scores
+    ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2] + flank)
+    k = yield from _window(ref_seq)
+    if not k == "Error":
+        alt_seq = (seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2])
+                   + seqio.ref_seq_readin(ref, sv_info[0], sv_info[1], sv_info[1] + flank))
+        k = yield from _window(alt_seq)
+        if not k == "Error":
+            reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, [sv_info[0], sv_info[2]], flank)
+            if len(reads) > num_reads_cff:
+                res = yield Score("s2", ref_seq, alt_seq, reads, k)
+                best = _collect(res, reads, scores)
+                yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_simple_ins(num_reads_cff, plt_li, bam_in, ref, ins_pos, ins_seq, out_figure_name, POLARITY):
+    """vapor_simple_ins_Vapor, SF:1856-1893.  ins_pos is 'chrom_pos'."""
+    if POLARITY == "+":
+        ins_seq_2 = ins_seq
+    elif POLARITY == "-":
+        ins_seq_2 = _rc(ins_seq)
+    else:
+        raise UnboundLocalError("ins_seq_2")            # SF:1860-1861 leave it unbound
+    flank = default_flank_length if len(ins_seq) > default_flank_length else len(ins_seq)
+    chrom = "_".join(ins_pos.split("_")[:-1])
+    pos_s = ins_pos.split("_")[-1]
+    pos = int(pos_s)
+    scores: List[float] = []
+    reads = seqio.simple_chop_pacbio_read_simple_short(bam_in, [chrom, pos_s] + [pos + len(ins_seq)], flank)
+    if len(reads) > num_reads_cff:
+        if len(ins_seq) < 5000:
+            ref_seq = seqio.ref_seq_readin(ref, chrom, pos - flank, pos + flank + len(ins_seq))
+            k = yield from _window(ref_seq + ins_seq)
+        else:
+            ref_seq = seqio.ref_seq_readin(ref, chrom, pos - flank, pos + flank)
+            k = yield from _window(ref_seq)
+        if not k == "Error":
+            alt_seq = (seqio.ref_seq_readin(ref, chrom, pos - flank, pos) + ins_seq_2
+                       + seqio.ref_seq_readin(ref, chrom, pos, pos + flank))
+
+            def few_n(x):                                   # SF:1878
+                return float(x[0].count("N") + x[0].count("n")) / float(len(x[0])) < 0.1
+
+            used = [x for x in reads if few_n(x)]
+            res = (yield Score("s1", ref_seq, alt_seq, used, k)) if used else []
+            best = _collect(res, reads, scores, keep=few_n)
+            if ins_seq_2.count("X") == len(ins_seq_2):
+                yield Figure(scores, best, k, ref_seq, ref_seq[2:flank], out_figure_name)
+            else:
+                yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_simple_disdup(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_simple_disdup_Vapor, SF:1786-1854.  sv_info = [chrom, s, e, ins_chrom, ins_pos]."""
+    sv_info[1:3] = [int(i) for i in sv_info[1:3]]
+    dup_block = sv_info[:3]
+    ins_point = [sv_info[3], int(sv_info[4])]
+    flank = seqio.flank_length_calculate(dup_block)
+    scores: List[float] = []
+    bp = sorted([int(i) for i in sv_info[1:3] + [sv_info[4]]])
+    ran = False
+    if sv_info[0] == sv_info[3] and max(bp) - min(bp) < default_max_sv_test:
+        ref_seq = seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, max(bp) + flank)
+        k = yield from _window(ref_seq)
+        if not k == "Error":
+            reads = seqio.simple_chop_pacbio_read_simple_short(
+                bam_in, [sv_info[0]] + bp + [int(bp[-1]) + sv_info[2] - sv_info[1]], flank)
+            if len(reads) > num_reads_cff:
+                ran = True
+                if sv_info[4] > sv_info[2]:
+                    structure = ["a", "b", "a"]
+                elif sv_info[4] < sv_info[1]:
+                    structure = ["b", "a", "b"]
+                else:
+                    raise UnboundLocalError("alt_structure")  # SF:1803-1804: insert point inside the block
+                alt_seq = seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, min(bp))
+                a_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[0], bp[1])
+                b_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[1], bp[2])
+                for x in structure:
+                    alt_seq += a_seq if x == "a" else b_seq
+                alt_seq += seqio.ref_seq_readin(ref, sv_info[0], max(bp), max(bp) + flank)
+                k = yield from _window(alt_seq)
+                if not k == "Error":
+                    res = yield Score("s3", ref_seq, alt_seq, reads, k)
+                    best = _collect(res, reads, scores)
+                    yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    if not ran:
+        short = max(bp) - min(bp) < default_max_sv_test
+        reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, ins_point, flank)
+        if len(reads) > num_reads_cff:
+            ref_seq = seqio.ref_seq_readin(ref, ins_point[0], ins_point[1] - flank, ins_point[1] + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                if short:
+                    alt_seq = (ref_seq[:flank] + seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[2])
+                               + ref_seq[-flank:])
+                else:
+                    alt_seq = ref_seq[:flank] + seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[1] + flank)
+                k = yield from _window(alt_seq)
+                if not k == "Error":
+                    res = yield Score("s1" if short else "s2", ref_seq, alt_seq, reads, k)
+                    best = _collect(res, reads, scores)
+                    yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_dup_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_dup_inv_VapoR, SF:1595-1665."""
+    sv_info[1:3] = [int(i) for i in sv_info[1:3]]
+    dup_block = sv_info[:3]
+    ins_point = [sv_info[3], int(sv_info[4])]
+    flank = seqio.flank_length_calculate(dup_block)
+    scores: List[float] = []
+    if sv_info[0] == sv_info[3]:
+        bp = sorted(sv_info[1:3] + [sv_info[4]])
+        ran = False
+        if max(bp) - min(bp) < default_max_sv_test:
+            ref_seq = seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, max(bp) + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                ran = True
+                if sv_info[4] > sv_info[2]:
+                    structure = ["a", "b", "a^"]
+                elif sv_info[4] < sv_info[1]:
+                    structure = ["b^", "a", "b"]
+                else:
+                    structure = ["a", "a^"]
+                reads = seqio.simple_chop_pacbio_read_simple_short(
+                    bam_in, [sv_info[0]] + bp + [bp[-1] + sv_info[2] - sv_info[1]], flank)
+                if len(reads) > num_reads_cff:
+                    alt_seq = seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, min(bp))
+                    a_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[0], bp[1])
+                    b_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[1], bp[2])
+                    for x in structure:
+                        alt_seq += {"a": a_seq, "a^": _rc(a_seq), "b": b_seq, "b^": _rc(b_seq)}[x]
+                    alt_seq += seqio.ref_seq_readin(ref, sv_info[0], max(bp), max(bp) + flank)
+                    k = yield from _window(alt_seq)
+                    if not k == "Error":
+                        res = yield Score("s3", ref_seq, alt_seq, reads, k)
+                        best = _collect(res, reads, scores, nan_guard=True)
+                        yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+        if not ran:
+            short = max(bp) - min(bp) < default_max_sv_test
+            ref_seq = seqio.ref_seq_readin(ref, ins_point[0], ins_point[1] - flank, ins_point[1] + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, ins_point, flank)
+                if len(reads) > num_reads_cff:
+                    if short:
+                        alt_seq = (ref_seq[:flank] + _rc(seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[2]))
+                                   + ref_seq[-flank:])
+                    else:
+                        alt_seq = ref_seq[:flank] + _rc(seqio.ref_seq_readin(ref, dup_block[0], dup_block[2] - flank, dup_block[2]))
+                    k = yield from _window(alt_seq)
+                    if not k == "Error":
+                        res = yield Score("s1" if short else "s2", ref_seq, alt_seq, reads, k)
+                        best = _collect(res, reads, scores, nan_guard=True)
+                        yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_long_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_long_del_inv, SF:1667-1688.  sv_info = [[chrom, s, e, 'del'], [chrom, s, e, 'inv']]."""
+    scores: List[float] = []
+    flank = 500
+    ref_seq = seqio.ref_seq_readin(ref, sv_info[0][0], sv_info[0][1] - flank, sv_info[1][1] + flank)
+    k = yield from _window(ref_seq)
+    if not k == "Error":
+        alt_seq = ref_seq[:flank] + _rc(seqio.ref_seq_readin(ref, sv_info[1][0], sv_info[1][2] - flank, sv_info[1][2]))
+        k = yield from _window(alt_seq)
+        if not k == "Error":
+            reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info[0], flank)
+            if len(reads) > num_reads_cff:
+                res = yield Score("s2", ref_seq, alt_seq, reads, k)
+                best = _collect(res, reads, scores)
+                yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+    return scores
+
+
+def vapor_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_del_inv_Vapor, SF:1557-1593.  sv_info = ordered [[chrom, s, e, 'del'|'inv'], ...]."""
+    sv_block = [sv_info[0][0], sv_info[0][1], sv_info[-1][2]]
+    flank = seqio.flank_length_calculate(sv_block)
+    scores: List[float] = []
+    if sv_info[1][1] - sv_info[0][2] < 100:
+        if sv_block[2] - sv_block[1] < default_max_sv_test:
+            ref_seq = seqio.ref_seq_readin(ref, sv_block[0], sv_block[1] - flank, sv_block[2] + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                alt_seq = ref_seq[:flank]
+                for x in sv_info:
+                    if x[-1] == "del":
+                        continue
+                    elif x[-1] == "inv":
+                        alt_seq += _rc(seqio.ref_seq_readin(ref, x[0], x[1], x[2]))
+                alt_seq += ref_seq[-flank:]
+                k = yield from _window(alt_seq)
+                if not k == "Error":
+                    reads = seqio.simple_chop_pacbio_read_simple_short(
+                        bam_in, sv_block[:2] + [sv_block[1] + len(alt_seq) - 2 * flank], flank)
+                    if len(reads) > num_reads_cff:
+                        res = yield Score("s1", ref_seq, alt_seq, reads, k)
+                        best = _collect(res, reads, scores)
+                        yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
+                    else:
+                        if len(sv_info) == 2 and [i[-1] for i in sv_info] == ["del", "inv"]:
+                            # SF:1585 calls vapor_long_del_inv with four arguments
+                            raise TypeError("vapor_long_del_inv() missing 2 required positional arguments: "
+                                            "'sv_info' and 'out_figure_name'")
+        else:
+            if len(sv_info) == 2 and [i[-1] for i in sv_info] == ["del", "inv"]:
+                scores = yield from vapor_long_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name)
+    else:
+        for sub in sv_info:
+            if "del" in sub or "inv" in sub:
+                # SF:1591-1592 call the simple drivers with four arguments
+                raise TypeError("vapor_simple_%s_Vapor() missing 2 required positional arguments: "
+                                "'sv_info' and 'out_figure_name'" % ("del" if "del" in sub else "inv"))
+    return scores

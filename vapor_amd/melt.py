@@ -1,0 +1,39 @@
+"""`vapor ins`: MELT insertion calls with their assembled sequences (melt_info_readin,
+vapor_vali/vapor:52-81).  <prefix>.vcf holds the sites, <prefix>.fa the inserted sequences keyed
+'chrom_pos'; results go to <prefix>.vapor.  (The reference reads args.sv_input_prefix, which
+its argparse never defines; here the prefix is --sv-input.)"""
+from __future__ import annotations
+
+from . import drivers, seqio
+from . import simple_function as SF
+from .finish import result_organize_ins
+
+
+def run(prefix, out_path, sample_name, bam_in, ref, num_reads_cff, chunk, figure_fn) -> None:
+    from .cli import Job, score_jobs
+    from . import dist as vdist
+    jobs = []
+    plt_li = 0
+    with open(prefix + '.vcf') as fin:
+        for line in fin:
+            pin = line.strip().split()
+            if pin[0][0] == '#':
+                continue
+            key = '_'.join(pin[:2])
+            lines = list(seqio.get_backend().faidx_lines(prefix + '.fa', key))
+            ins_seq = ''.join(l.strip() for l in lines[1:])
+            if ins_seq == '':
+                ins_seq = ''.join(['X' for _ in range(SF.INS_length_detect(pin))])
+            if not ins_seq == '' and 'INS' in pin[3]:
+                pol = SF.polarity_detect(pin)
+                ins_seq = ins_seq.replace('N', 'X')
+                plt_li += 1
+                fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, a=key, s=ins_seq, g=fig, q=pol:
+                                      drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, q))))
+    scores = score_jobs(jobs, chunk, figure_fn)
+    if vdist.rank() == 0:
+        SF.write_output_initiate(prefix + '.vapor')
+        with open(prefix + '.vapor', 'a') as fo:
+            for j, sc in zip(jobs, scores):
+                print(SF.format_output_row(result_organize_ins([j.key, sc])), file=fo)

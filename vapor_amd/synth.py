@@ -276,3 +276,13 @@ def make_pairs(seed: int, n_alleles: int, reads_per_allele: int, read_len: int, 
             reads.append(r[:read_len])
             pairs.append((len(reads) - 1, ai))
     return alleles, reads, pairs
+
+
+def world_from_json(d: dict) -> SynthWorld:
+    """Inverse of the fixture layout written by oracle/gen_golden.py (world_to_json)."""
+    w = SynthWorld()
+    w.contigs = dict(d["contigs"])
+    w.reads = {c: [SamRecord(q, c, pos, cig, seq, span) for q, pos, cig, seq, span in rs]
+               for c, rs in d["reads"].items()}
+    w.loci = [Locus(*l) for l in d["loci"]]
+    return w
