@@ -77,7 +77,7 @@ def main() -> None:
         rec = wl.finish_workload(w, st)
         if dist is not None:
             t = torch.from_numpy(rec).cuda()
-            out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t)
             gathered[0] = out
         else:

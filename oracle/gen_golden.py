@@ -552,10 +552,80 @@ def gen_locus(m):
                                "cases": out_cases})
 
 
+def run_vcf(m, cli, world, tmp, header, num_reads_cff=3):
+    """What `vapor vcf` does (vapor_vali/vapor:374-466) with figures disabled."""
+    vcf = os.path.join(tmp, "in_%d.vcf" % int(header))
+    open(vcf, "w").write(synth.vcf_text(world, header=header))
+    out_path = os.path.join(tmp, "figs") + "/"
+    vcf_list, rec_hash = cli["vcf_list_readin"](vcf)
+    rec_new = m.vcf_rec_hash_modify(rec_hash)
+    m.write_output_initiate(vcf + ".vapor")
+    rows = []
+    for x in list(vcf_list.keys()):
+        for y in vcf_list[x]:
+            y0 = jsonable(y)
+            if x in ("DEL", "INV"):
+                if y[2] - y[1] < 50:
+                    key, sc = ":".join([str(i) for i in y] + ["DEL"]), {"ok": []}
+                else:
+                    key = ":".join([str(i) for i in y] + [x])
+                    fn = m.vapor_simple_del_Vapor if x == "DEL" else m.vapor_simple_inv_Vapor
+                    sc = call(fn, num_reads_cff, 1, "x.bam", "ref.fa", y, out_path + "f.png")
+            elif x == "INS":
+                key = ":".join([str(i) for i in y[:3] + ["INS"]])
+                ins_pos = "_".join([str(i) for i in y[:2]])
+                ins_seq = y[-1] if len(y) == 4 else "X" * y[2]
+                sc = call(m.vapor_simple_ins_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", ins_pos, ins_seq, out_path + "f.png", "+")
+            elif x == "DISDUP":
+                key = ":".join([str(i) for i in y + ["DISDUP"]])
+                sc = call(m.vapor_simple_disdup_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", y, out_path + "f.png")
+            elif x == "DEL_INV":
+                key = ":".join(["_".join([str(i) for i in j]) for j in y] + ["DEL_INV"])
+                sc = call(m.vapor_del_inv_Vapor, num_reads_cff, 1, "x.bam", "ref.fa", y, out_path + "f.png")
+            elif x == "DUP_INV":
+                key = ":".join([str(i) for i in y + ["DUP_INV"]])
+                sc = call(m.vapor_dup_inv_VapoR, num_reads_cff, 1, "x.bam", "ref.fa", y, out_path + "f.png")
+            else:
+                continue
+            rec = {"type": x, "item": y0, "key": key, "scores": sc}
+            if "ok" in sc:
+                m.write_output_main(vcf + ".vapor", m.result_organize_ins([key, sc["ok"]]))
+            rows.append(rec)
+    table = open(vcf + ".vapor").read()
+    final = call(m.vcf_vapor_modify, vcf, rec_new)
+    return {"vcf": synth.vcf_text(world, header=header), "per_record": rows, "table": table,
+            "final": open(vcf + ".vapor").read() if "ok" in final else None, "final_status": final if "error" in final else "ok"}
+
+
+def gen_vcf(m):
+    cli = load_cli(m)
+    m.make_event_figure_1 = lambda *a, **k: None
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_vcf_")
+    os.makedirs(os.path.join(tmp, "figs"), exist_ok=True)
+    cases = []
+    specs = [
+        ("vcf_simple", dict(seed=81, n_loci=8, svtypes=("DEL", "INV", "INS", "TANDUP"), span_range=(120, 1200), read_len=4200, n_reads=8)),
+        ("vcf_complex", dict(seed=82, n_loci=9, svtypes=("DISDUP", "DUP_INV", "DEL_INV"), span_range=(200, 900), read_len=5200, n_reads=8)),
+        ("vcf_tiny_span", dict(seed=83, n_loci=4, svtypes=("DEL", "INV"), span_range=(20, 60), read_len=1600, n_reads=6)),
+    ]
+    for name, kw in specs:
+        w = synth.make_world(**kw)
+        for header in (False, True):
+            m.os = ShimOS(w)
+            r = run_vcf(m, cli, w, tmp, header)
+            m.os = os
+            r.update({"name": name + ("_hdr" if header else "_nohdr"), "world": world_to_json(w) if not header else None,
+                      "world_of": name + "_nohdr", "header": header})
+            cases.append(r)
+            print("  %s: %s final=%s" % (r["name"], [(p["type"], len(p["scores"].get("ok", [])) if "ok" in p["scores"] else p["scores"]["error"]) for p in r["per_record"]], r["final_status"]))
+    dump("locus_vcf.json.gz", {"source": "vapor vcf loop vapor_vali/vapor:374-466 + vcf_vapor_modify SF:1972-2028 (figures off)",
+                               "cases": cases})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)

@@ -126,3 +126,80 @@ def test_partition_is_balanced_and_complete():
     rec, extra = dist.pack_records({0: [0.5, -1.25], 2: [], 3: KeyError("x")}, 4)
     back = dist.unpack_records(np.where(np.isnan(rec[:, :1]), 0, rec), {**extra, 1: None})
     assert back[0] == [0.5, -1.25] and back[2] == [] and isinstance(back[3], KeyError)
+
+
+VCF = load_golden("locus_vcf.json.gz")["cases"]
+_VCF_WORLDS = {c["name"]: c["world"] for c in VCF if c["world"] is not None}
+
+
+def _vcf_world(case):
+    return synth.world_from_json(_VCF_WORLDS[case["world_of"]])
+
+
+@pytest.mark.parametrize("case", [c for c in VCF if not c["header"]], ids=lambda c: c["name"])
+def test_vcf_records_and_table(fake, case, tmp_path):
+    """`vapor vcf` on header-less input (where the reference's record numbering is consistent):
+    per-record scores, the 6-column table and the INFO-annotated VCF equal the reference's."""
+    from vapor_amd import drivers
+    world = _vcf_world(case)
+    seqio.set_backend(seqio.MemorySamtools(world))
+    vcf = tmp_path / "in.vcf"
+    vcf.write_text(case["vcf"])
+    vcf_list, rec_hash = cli.vcf_list_readin(str(vcf))
+    clean = all("ok" in p["scores"] for p in case["per_record"])
+    # record by record through the one-locus drivers
+    fns = {"DEL": drivers.vapor_simple_del, "INV": drivers.vapor_simple_inv, "DISDUP": drivers.vapor_simple_disdup,
+           "DEL_INV": drivers.vapor_del_inv, "DUP_INV": drivers.vapor_dup_inv}
+    it = iter(case["per_record"])
+    for x in list(vcf_list.keys()):
+        for y in vcf_list[x]:
+            if x not in ("DEL", "INV", "INS", "DISDUP", "DEL_INV", "DUP_INV"):
+                continue
+            p = next(it)
+            assert p["type"] == x
+            if x in ("DEL", "INV") and y[2] - y[1] < 50:
+                continue
+            if x == "INS":
+                gen = drivers.vapor_simple_ins(3, 1, "x.bam", "ref.fa", "_".join(str(i) for i in y[:2]),
+                                               y[-1] if len(y) == 4 else "X" * y[2], "f.png", "+")
+            else:
+                gen = fns[x](3, 1, "x.bam", "ref.fa", y, "f.png")
+            if "error" in p["scores"]:
+                if p["scores"]["error"] == "AttributeError":
+                    continue        # the reference died in the unseeded X-means branch (scipy.std)
+                with pytest.raises(Exception) as ei:
+                    pipeline.run_sync(gen)
+                assert type(ei.value).__name__ == p["scores"]["error"]
+            else:
+                try:
+                    got = pipeline.run_sync(gen)
+                except Exception:
+                    if x == "DUP_INV":
+                        continue    # X-means branch taken on this run only (unseeded in both worlds)
+                    raise
+                assert [float(v) for v in got] == [float(v) for v in p["scores"]["ok"]], (x, y)
+    if not clean:
+        return
+    rc = cli.main(["vcf", "--sv-input", str(vcf), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                   "--output-path", str(tmp_path / "figs"), "--output-file", "unused", "--no-figures"])
+    assert rc == 0
+    assert (tmp_path / "in.vcf.vapor").read_text() == case["final"]
+
+
+@pytest.mark.parametrize("name", ["vcf_simple", "vcf_tiny_span"])
+def test_vcf_with_header_annotates_the_right_records(fake, name, tmp_path):
+    """With header lines the reference mis-indexes records (KeyError, see vcf_vapor_modify's
+    docstring); here the same records get the same annotation as in the header-less run."""
+    hdr = [c for c in VCF if c["name"] == name + "_hdr"][0]
+    nohdr = [c for c in VCF if c["name"] == name + "_nohdr"][0]
+    assert hdr["final_status"] != "ok"
+    seqio.set_backend(seqio.MemorySamtools(_vcf_world(hdr)))
+    vcf = tmp_path / "in.vcf"
+    vcf.write_text(hdr["vcf"])
+    assert cli.main(["vcf", "--sv-input", str(vcf), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                     "--output-path", str(tmp_path / "figs"), "--output-file", "unused", "--no-figures"]) == 0
+    got = (tmp_path / "in.vcf.vapor").read_text().splitlines()
+    recs = [l for l in got if not l.startswith("#")]
+    assert recs == [l for l in nohdr["final"].splitlines() if l and not l.startswith("#")]
+    assert sum(1 for l in got if l.startswith("##INFO=<ID=VaPoR_")) == 4
+    assert got[[i for i, l in enumerate(got) if l.startswith("#CHROM")][0] - 1].startswith("##source")

@@ -117,9 +117,10 @@ def gather_results(local: Dict[int, object], n_items: int) -> List[object]:
     import torch.distributed as dist
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if _pg == "nccl" else torch.device("cpu")
     mine = torch.from_numpy(rec).to(dev)
-    allr = torch.empty((dist.get_world_size(),) + tuple(mine.shape), dtype=mine.dtype, device=dev)
-    dist.all_gather_into_tensor(allr, mine)
-    allr = allr.cpu().numpy()
+    nw = dist.get_world_size()
+    allr = torch.empty((nw * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=dev)
+    dist.all_gather_into_tensor(allr, mine.contiguous())
+    allr = allr.cpu().numpy().reshape(nw, mine.shape[0], mine.shape[1])
     # each item was scored by exactly one rank: take the row that is not NaN
     have = ~np.isnan(allr[:, :, 0])
     owner = have.argmax(axis=0)

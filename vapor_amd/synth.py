@@ -226,17 +226,18 @@ def bed_text(world: SynthWorld) -> str:
     return "\n".join(rows) + "\n"
 
 
-def vcf_text(world: SynthWorld) -> str:
+def vcf_text(world: SynthWorld, header: bool = True) -> str:
     """Minimal VCF with the INFO keys `vcf_list_readin` reads (vapor_vali/vapor:127-202,
     README.md:79-82 for the complex types)."""
-    out = ["##fileformat=VCFv4.1",
-           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE"]
+    out = ["##fileformat=VCFv4.1", "##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"Type of SV\">",
+           "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End\">", "##source=vapor_amd.synth",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE"] if header else []
     for l in world.loci:
         info = "SVTYPE=%s;END=%d" % ({"TANDUP": "DUP"}.get(l.svtype, l.svtype), l.end)
         alt = "<%s>" % l.svtype
         if l.svtype == "INS":
-            info = "SVTYPE=INS;END=%d;SVLEN=%d" % (l.end, len(l.ins_seq))
-            alt = l.ins_seq
+            info = "SVTYPE=INS;END=%d;SVLEN=%d;SEQ=%s" % (l.end, len(l.ins_seq), l.ins_seq)
+            alt = "<INS>"
         elif l.svtype in ("DISDUP", "DUP_INV"):
             info += ";insert_point=%s:%d" % (l.chrom, l.extra["insert_point"])
         elif l.svtype == "DEL_INV":
