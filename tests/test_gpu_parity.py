@@ -204,17 +204,21 @@ def test_overflow_retry_and_hit_fetch(eng, oracle):
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * 4, rows, "overflow")
 
 
-@pytest.mark.parametrize("rpt", [1, 3, 64])
-def test_reads_per_task_invariance(eng, oracle, rpt):
+@pytest.mark.parametrize("rpt,jt", [(1, 512), (3, 512), (64, 1), (64, 2), (64, 5), (7, 3)])
+def test_task_partition_invariance(eng, oracle, rpt, jt):
+    """Results do not depend on how the sorted pair list is cut into join tasks (one task may
+    span several alleles and rebuild its table; one allele may be split over several tasks)."""
     from vapor_amd import synth
-    alleles, reads, pr = synth.make_pairs(31, 3, 9, 1500, 2500)
+    alleles, reads, pr = synth.make_pairs(31, 5, 9, 1500, 2500)
     seqs = alleles + reads
-    rows = [(len(alleles) + r, a, 0, 10, 3) for r, a in pr]
+    rows = [(len(alleles) + r, a, 0, 10, 7) for r, a in pr]
     eng.set_param("reads_per_task", rpt)
+    eng.set_param("join_tasks", jt)
     try:
-        _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "rpt%d" % rpt)
+        _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "rpt%d_jt%d" % (rpt, jt))
     finally:
-        eng.set_param("reads_per_task", 8)
+        eng.set_param("reads_per_task", 64)
+        eng.set_param("join_tasks", 256)
 
 
 def test_bad_arguments(eng):

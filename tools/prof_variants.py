@@ -9,8 +9,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 w = wl.make_workload(name, seed=1000, **wl.WORKLOADS[name])
 eng = Engine(0)
 ss = eng.seqset(w.seqs)
-for rpt in (4, 8, 10, 20):
-    eng.set_param("reads_per_task", rpt)
+for rpt in (512, 256, 1024, 200):
+    eng.set_param("join_tasks", rpt)
     for fl in (None, 0, 1, 2, 3, 5, 7):
         pairs = w.pairs.copy()
         if fl is not None:
@@ -26,7 +26,7 @@ for rpt in (4, 8, 10, 20):
             tm = plan.timings()
             tj += tm["join_ms"]; tc += tm["clean_ms"]; tt += tm["total_ms"]
         wall = (time.perf_counter() - t0) / n * 1e3
-        print("rpt=%2d flags=%s join=%.3f clean=%.3f dev=%.3f wall=%.3f ms" % (rpt, fl, tj / n, tc / n, tt / n, wall), flush=True)
+        print("jt=%4d flags=%s join=%.3f clean=%.3f dev=%.3f wall=%.3f ms" % (rpt, fl, tj / n, tc / n, tt / n, wall), flush=True)
         plan.close()
-        if rpt != 8 and fl is None:
+        if rpt != 512 and fl is None:
             break

@@ -36,7 +36,8 @@ static int fail(int code, const std::string& msg)
 struct vapor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    int reads_per_task = 8;
+    int reads_per_task = MAX_READS_PER_TASK;   // upper bound on pairs per join task
+    int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
     bool attrs_set = false;
 };
@@ -103,6 +104,11 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
     vapor_ctx* c = new (std::nothrow) vapor_ctx();
     if (!c) return fail(VAPOR_E_NOMEM, "vapor_init: out of memory");
     c->device = device_ordinal;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+            c->join_tasks = prop.multiProcessorCount;   // a join workgroup fills a CU's LDS: one task per CU per launch
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VAPOR_E_HIP, hipGetErrorString(e)); }
     hipError_t a[8] = {set_join_attr<2, 10>(), set_join_attr<2, 20>(), set_join_attr<2, 30>(), set_join_attr<2, 40>(),
@@ -130,6 +136,11 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     if (!strcmp(name, "reads_per_task")) {
         if (v < 1 || v > MAX_READS_PER_TASK) return fail(VAPOR_E_ARG, "reads_per_task out of range");
         c->reads_per_task = (int)v;
+        return VAPOR_OK;
+    }
+    if (!strcmp(name, "join_tasks")) {
+        if (v < 1) return fail(VAPOR_E_ARG, "join_tasks out of range");
+        c->join_tasks = (int)v;
         return VAPOR_OK;
     }
     if (!strcmp(name, "max_pair_cap")) {
@@ -325,7 +336,9 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     }
     p->range_words_cap = rw;
     p->hcap_want = (int)std::min<int64_t>(hwant, 16384);
-    // group pairs that share (mode, k, allele) into tasks of at most reads_per_task reads
+    // Sort by (mode, k, allele): one launch per (mode, k); inside a launch the sorted pair list is
+    // cut into contiguous, cost-balanced ranges (tasks).  A workgroup rebuilds its allele hash table
+    // only where the allele changes inside its range.
     std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
         const DPair &a = p->hp[x], &b = p->hp[y];
         if (mode[x] != mode[y]) return mode[x] < mode[y];
@@ -333,37 +346,44 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         if (a.seq2 != b.seq2) return a.seq2 < b.seq2;
         return x < y;
     });
-    struct TmpTask { DTask t; int bps; int64_t cost; };
-    std::vector<TmpTask> tmp;
+    p->task_pairs = order;
+    auto tiles_of = [&](int32_t seq2, int k, int bps) {
+        const int ta = bps == 2 ? tile_pos<2>() : tile_pos<4>();
+        return std::max(1, (set->h[seq2].len - k + 1 + ta - 1) / ta);
+    };
     for (size_t q = 0; q < order.size();) {
         size_t e = q;
-        const DPair& a = p->hp[order[q]];
-        int m = mode[order[q]];
-        int64_t cost = set->h[a.seq2].len;
-        while (e < order.size() && (int)(e - q) < ctx->reads_per_task && mode[order[e]] == m &&
-               p->hp[order[e]].k == a.k && p->hp[order[e]].seq2 == a.seq2) {
-            cost += 2 * (int64_t)set->h[p->hp[order[e]].seq1].len;
-            ++e;
+        const int m = mode[order[q]], k = p->hp[order[q]].k;
+        while (e < order.size() && mode[order[e]] == m && p->hp[order[e]].k == k) ++e;
+        // cost of a pair: its probe passes, plus the table build when it opens a new allele
+        std::vector<int64_t> cost(e - q);
+        int64_t total = 0;
+        for (size_t t = q; t < e; ++t) {
+            const DPair& d = p->hp[order[t]];
+            int64_t c = (int64_t)set->h[d.seq1].len * tiles_of(d.seq2, k, m) + 256;
+            if (t == q || p->hp[order[t - 1]].seq2 != d.seq2) c += 2 * (int64_t)set->h[d.seq2].len;
+            cost[t - q] = c;
+            total += c;
         }
-        TmpTask t;
-        t.t.seq2 = a.seq2; t.t.k = a.k; t.t.n_reads = (int32_t)(e - q); t.t.first = (int32_t)q;
-        t.bps = m; t.cost = cost;
-        tmp.push_back(t);
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>((int64_t)(e - q), ctx->join_tasks));
+        const int64_t target = (total + want - 1) / want;
+        p->launches.push_back(Launch{m, k, (int)p->tasks.size(), 0});
+        size_t t0 = q;
+        int64_t acc = 0;
+        for (size_t t = q; t < e; ++t) {
+            acc += cost[t - q];
+            const bool full = (int)(t + 1 - t0) >= ctx->reads_per_task;
+            if (acc >= target || full || t + 1 == e) {
+                DTask tk;
+                tk.seq2 = p->hp[order[t0]].seq2; tk.k = k; tk.n_reads = (int32_t)(t + 1 - t0); tk.first = (int32_t)t0;
+                p->tasks.push_back(tk);
+                p->launches.back().n_tasks++;
+                // a range that stopped short of its share only shifts the remainder to the next one
+                acc = 0;
+                t0 = t + 1;
+            }
+        }
         q = e;
-    }
-    // one launch per (mode, k); inside a launch the longest tasks go first
-    std::stable_sort(tmp.begin(), tmp.end(), [](const TmpTask& a, const TmpTask& b) {
-        if (a.bps != b.bps) return a.bps < b.bps;
-        if (a.t.k != b.t.k) return a.t.k < b.t.k;
-        return a.cost > b.cost;
-    });
-    p->task_pairs = order;
-    p->tasks.reserve(tmp.size());
-    for (size_t q = 0; q < tmp.size(); ++q) {
-        if (q == 0 || tmp[q].bps != tmp[q - 1].bps || tmp[q].t.k != tmp[q - 1].t.k)
-            p->launches.push_back(Launch{tmp[q].bps, tmp[q].t.k, (int)q, 0});
-        p->launches.back().n_tasks++;
-        p->tasks.push_back(tmp[q].t);
     }
     int rc = VAPOR_OK;
     auto chk = [&](hipError_t e, const char* what) {

@@ -46,10 +46,6 @@ struct DTask {         // 16 B
 #define VP_X4_WORDS_PER_CHUNK 4
 #define VP_PAD_CHUNKS 3  // zeroed chunks after each sequence: window reads may run this far
 
-constexpr int TA_LOG2 = 15;            // allele k-mer positions per hash-table tile
-constexpr int TA = 1 << TA_LOG2;
-constexpr int NB_LOG2 = 14;            // hash buckets
-constexpr int NB = 1 << NB_LOG2;
 constexpr int JOIN_THREADS = 1024;
 constexpr int MAX_READS_PER_TASK = 64;
 constexpr int CLEAN_THREADS = 512;
@@ -196,19 +192,6 @@ __device__ __forceinline__ KeyT<BPS, K> revcomp_key(const KeyT<BPS, K>& k)
     return r;
 }
 
-template <int BPS, int K>
-__device__ __forceinline__ uint32_t hash_key(const KeyT<BPS, K>& k)
-{
-    using KT = KeyT<BPS, K>;
-    uint32_t x = k.w[0] * 0x9E3779B1u;
-    if (KT::NW > 1) x ^= k.w[1] * 0x85EBCA77u;
-    if (KT::NW > 2) x ^= k.w[2] * 0xC2B2AE3Du;
-    if (KT::NW > 3) x ^= k.w[3] * 0x27D4EB2Fu;
-    if (KT::NW > 4) x ^= k.w[4] * 0x165667B1u;
-    if (KT::NW > 1) { x ^= x >> 15; x *= 0x2C1B3C6Du; }
-    return x >> (32 - NB_LOG2);
-}
-
 // any nibble == 15 (a symbol that matches nothing; such allele k-mers are left out of the table)
 template <int BPS, int K>
 __device__ __forceinline__ bool key_has_invalid(const KeyT<BPS, K>& k)
@@ -237,15 +220,147 @@ __device__ __forceinline__ bool any_exc(P plane, uint32_t pos)
 // ------------------------------------------------------------------------------------------
 // join kernel
 // ------------------------------------------------------------------------------------------
-template <int BPS>
-__host__ __device__ constexpr int tile_words() { return ((TA + 64) * BPS) / 32 + 8; }
-constexpr int etile_words() { return (TA + 64) / 32 + 8; }
+// kmerhits (SF:951-983) as an LDS hash join on CANONICAL k-mers.
+//
+// A hit (j, i) exists when allele k-mer a_j equals read k-mer r_i, and once more when it equals
+// revcomp(r_i).  canon(x) = min(x, revcomp(x)) satisfies canon(a) == canon(r)  <=>  a == r or
+// a == revcomp(r), so ONE lookup per read position finds the candidates of both orientations and
+// the verification emits one tuple per orientation that really matches (two for a read k-mer that
+// is its own reverse complement, as the reference does).
+//
+// Table (per allele tile of up to TA k-mer positions), all in LDS:
+//   start[h]   u16, NB+1 entries: first slot of bucket h (bucket = hash of the canonical key)
+//   entries[]  u16: tile positions sorted by bucket (counting sort: packed 16-bit counters updated
+//              with 32-bit LDS atomics, block scan, fill from the back of each bucket)
+// Probe: a wave takes 1024 consecutive read positions, copies their packed words into its own LDS
+// strip (so the loop below touches no global memory except the hit stores, which nothing waits
+// for), each lane owns 16 of the positions and slides the key / reverse-complement registers over
+// them; the (position, slot) candidates of the whole wave are compacted into a per-wave LDS queue
+// and verified 128 at a time, so the data-dependent bucket sizes do not idle lanes.
+//
+// A task is a contiguous range of the batch's pairs sorted by allele (cost-balanced on the host);
+// the table is rebuilt only when the allele changes inside the range.
+constexpr int JNB_LOG2 = 15;
+constexpr int JNB = 1 << JNB_LOG2;
+constexpr int JOIN_WAVES = JOIN_THREADS / 64;
+constexpr int JCHUNK = 1024;                      // read positions per wave pass (16 per lane)
+
+template <int BPS> __host__ __device__ constexpr int tile_pos() { return BPS == 2 ? 31744 : 16384; }
+template <int BPS> __host__ __device__ constexpr int jqcap() { return 256; }   // per-wave candidate queue (items)
+template <int BPS> __host__ __device__ constexpr int tile_words() { return ((tile_pos<BPS>() + 64) * BPS) / 32 + 8; }
+template <int BPS> __host__ __device__ constexpr int etile_words() { return BPS == 2 ? (tile_pos<BPS>() + 64) / 32 + 8 : 0; }
+template <int BPS> __host__ __device__ constexpr int rbuf_words() { return ((JCHUNK + 64) * BPS) / 32 + 4; }
 
 template <int BPS>
 constexpr size_t join_lds_bytes()
 {
-    return sizeof(uint32_t) * NB + sizeof(uint16_t) * TA + sizeof(uint32_t) * tile_words<BPS>() +
-           (BPS == 2 ? sizeof(uint32_t) * etile_words() : 0) + sizeof(unsigned long long) * MAX_READS_PER_TASK;
+    return sizeof(uint32_t) * (JNB / 2 + 2) + sizeof(uint32_t) * tile_words<BPS>() + sizeof(uint32_t) * etile_words<BPS>() +
+           sizeof(unsigned long long) * MAX_READS_PER_TASK + sizeof(uint32_t) * JOIN_WAVES * jqcap<BPS>() +
+           sizeof(uint32_t) * JOIN_WAVES * rbuf_words<BPS>() + sizeof(uint32_t) * (2 * JOIN_WAVES + 4) +
+           sizeof(uint16_t) * tile_pos<BPS>();
+}
+
+template <int BPS, int K>
+__device__ __forceinline__ bool key_less(const KeyT<BPS, K>& a, const KeyT<BPS, K>& b)
+{
+    using KT = KeyT<BPS, K>;
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int t = KT::NW - 1; t >= 0; --t) {
+        if (!decided && a.w[t] != b.w[t]) { lt = a.w[t] < b.w[t]; decided = true; }
+    }
+    return lt;
+}
+
+template <int BPS, int K>
+__device__ __forceinline__ uint32_t canon_bucket(const KeyT<BPS, K>& k, const KeyT<BPS, K>& rc)
+{
+    using KT = KeyT<BPS, K>;
+    const bool use_rc = key_less<BPS, K>(rc, k);
+    uint32_t x = (use_rc ? rc.w[0] : k.w[0]) * 0x9E3779B1u;
+    if (KT::NW > 1) x ^= (use_rc ? rc.w[1] : k.w[1]) * 0x85EBCA77u;
+    if (KT::NW > 2) x ^= (use_rc ? rc.w[2] : k.w[2]) * 0xC2B2AE3Du;
+    if (KT::NW > 3) x ^= (use_rc ? rc.w[3] : k.w[3]) * 0x27D4EB2Fu;
+    if (KT::NW > 4) x ^= (use_rc ? rc.w[4] : k.w[4]) * 0x165667B1u;
+    if (KT::NW > 1) { x ^= x >> 15; x *= 0x2C1B3C6Du; }
+    return x >> (32 - JNB_LOG2);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// verify queued candidates [from, from+n), n <= 128, two per lane so that their LDS reads overlap.
+// item = local read position << 16 | entry slot.  The entry's k-mer is compared with the read
+// k-mer in both orientations; hits are compacted with ballots, staged in the (already consumed)
+// queue slots and written out as one contiguous run with ONE counter update per call.
+template <int BPS, int K>
+__device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
+                                            const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2,
+                                            unsigned long long* cnt_r, uint32_t cap, uint32_t* out)
+{
+    using KT = KeyT<BPS, K>;
+    const int lane = threadIdx.x & 63;
+    bool hf[2] = {false, false}, hr[2] = {false, false};
+    uint32_t val[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = q * 64 + lane;
+        if (idx < n) {
+            const uint32_t item = myq[from + idx];
+            const uint32_t il = item >> 16;
+            const uint32_t e = entries[item & 0xFFFFu];
+            KT kf = extract_key<BPS, K>(rbuf, il);
+            KT a = extract_key<BPS, K>(tile, e);
+            KT kr = revcomp_key<BPS, K>(kf);
+            const int jf = ts + (int)e;
+            const bool in = jf >= off2;
+            hf[q] = in && (a == kf);
+            hr[q] = in && (a == kr);
+            val[q] = ((uint32_t)(jf - off2) << 16) | (uint32_t)(cb + (int)il);
+        }
+    }
+    const unsigned long long m0 = __ballot(hf[0]), m1 = __ballot(hr[0]), m2 = __ballot(hf[1]), m3 = __ballot(hr[1]);
+    const uint32_t n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+    const uint32_t tot = n0 + n1 + n2 + n3;
+    if (tot == 0) return;
+    // stage the hits contiguously (tot <= 256 <= 2 * 128 queue slots; the items are in registers now)
+    uint32_t* stage = myq + from;
+    const bool fits = tot <= (uint32_t)n;
+    auto rank = [&](unsigned long long m) {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    const uint32_t r0 = rank(m0), r1 = n0 + rank(m1), r2 = n0 + n1 + rank(m2), r3 = n0 + n1 + n2 + rank(m3);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cnt_r, (unsigned long long)tot);
+    base = __shfl(base, 0, 64);
+    if (fits) {
+        if (hf[0]) stage[r0] = val[0];
+        if (hr[0]) stage[r1] = val[0];
+        if (hf[1]) stage[r2] = val[1];
+        if (hr[1]) stage[r3] = val[1];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t x = q * 64 + lane;
+            if (x < tot) {
+                const uint32_t v = stage[x];
+                const unsigned long long sl = base + x;
+                if (sl < cap) out[sl] = v;
+            }
+        }
+    } else {
+        if (hf[0] && base + r0 < cap) out[base + r0] = val[0];
+        if (hr[0] && base + r1 < cap) out[base + r1] = val[0];
+        if (hf[1] && base + r2 < cap) out[base + r2] = val[1];
+        if (hr[1] && base + r3 < cap) out[base + r3] = val[1];
+    }
 }
 
 template <int BPS, int K>
@@ -255,83 +370,240 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_kernel(
     const int32_t* __restrict__ task_pairs, uint32_t* __restrict__ hits, unsigned long long* __restrict__ n_hits)
 {
     using KT = KeyT<BPS, K>;
+    constexpr int TA = tile_pos<BPS>();
+    constexpr int JQCAP = jqcap<BPS>();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* head = lds;                                                   // NB
-    uint32_t* tile = head + NB;                                             // tile_words
-    uint32_t* etile = tile + tile_words<BPS>();                             // etile_words (BPS 2)
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + (BPS == 2 ? etile_words() : 0));
-    uint16_t* next = reinterpret_cast<uint16_t*>(cnt + MAX_READS_PER_TASK); // TA
+    uint32_t* start32 = lds;                                                  // JNB/2 + 2 words: u16 pairs
+    uint32_t* tile = start32 + (JNB / 2 + 2);
+    uint32_t* etile = tile + tile_words<BPS>();
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + etile_words<BPS>());
+    uint32_t* queue = reinterpret_cast<uint32_t*>(cnt + MAX_READS_PER_TASK);   // JOIN_WAVES * JQCAP
+    uint32_t* rbufs = queue + JOIN_WAVES * JQCAP;                              // JOIN_WAVES * rbuf_words
+    uint32_t* wtot = rbufs + JOIN_WAVES * rbuf_words<BPS>();                   // 2 * JOIN_WAVES + 4
+    uint16_t* entries = reinterpret_cast<uint16_t*>(wtot + 2 * JOIN_WAVES + 4);  // TA
+    const uint16_t* start16 = reinterpret_cast<const uint16_t*>(start32);
 
-    const int tid = threadIdx.x;
-    const DTask task = tasks[blockIdx.x];
-    const SeqDesc s2 = seqs[task.seq2];
-    const int nk2 = s2.len - K + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const DTask task = tasks[blockIdx.x];          // first = index into task_pairs, n_reads = pairs in the range
     const uint32_t* plane = (BPS == 2) ? p2 : x4;
     constexpr int WPC = (BPS == 2) ? VP_P2_WORDS_PER_CHUNK : VP_X4_WORDS_PER_CHUNK;
-    const bool exc2 = (BPS == 2) && s2.n_exc > 0;
+    uint32_t* myq = queue + wave * JQCAP;
+    uint32_t* rbuf = rbufs + wave * rbuf_words<BPS>();
 
     if (tid < MAX_READS_PER_TASK) cnt[tid] = 0ULL;
 
-    for (int ts = 0; ts < nk2; ts += TA) {
-        const int tn = min(TA, nk2 - ts);
-        __syncthreads();                       // previous tile fully probed
-        for (int x = tid; x < NB; x += JOIN_THREADS) head[x] = EMPTY32;
-        {
-            const uint32_t* src = plane + (size_t)s2.chunk0 * WPC + (((size_t)ts * BPS) >> 5);
-            const int nw = ((tn + K - 1) * BPS + 31) / 32 + 2;
-            for (int x = tid; x < nw; x += JOIN_THREADS) tile[x] = src[x];
-            if (exc2) {
-                const uint32_t* es = e1 + (size_t)s2.chunk0 + (ts >> 5);
-                const int ne = (tn + K - 1 + 31) / 32 + 3;
-                for (int x = tid; x < ne; x += JOIN_THREADS) etile[x] = es[x];
+    int g0 = 0;
+    while (g0 < task.n_reads) {
+        // group of consecutive pairs that share the allele
+        const int seq2 = pairs[task_pairs[task.first + g0]].seq2;
+        int g1 = g0 + 1;
+        while (g1 < task.n_reads && pairs[task_pairs[task.first + g1]].seq2 == seq2) ++g1;
+        const SeqDesc s2 = seqs[seq2];
+        const int nk2 = s2.len - K + 1;
+        const bool exc2 = (BPS == 2) && s2.n_exc > 0;
+
+        for (int ts = 0; ts < nk2; ts += TA) {
+            const int tn = min(TA, nk2 - ts);
+            __syncthreads();                       // previous table fully probed
+            for (int x = tid; x < JNB / 2 + 2; x += JOIN_THREADS) start32[x] = 0u;
+            {
+                const uint32_t* src = plane + (size_t)s2.chunk0 * WPC + (((size_t)ts * BPS) >> 5);
+                const int nw = ((tn + K - 1) * BPS + 31) / 32 + 2;
+                for (int x = tid; x < nw; x += JOIN_THREADS) tile[x] = src[x];
+                if (exc2) {
+                    const uint32_t* es = e1 + (size_t)s2.chunk0 + (ts >> 5);
+                    const int ne = (tn + K - 1 + 31) / 32 + 3;
+                    for (int x = tid; x < ne; x += JOIN_THREADS) etile[x] = es[x];
+                }
             }
-        }
-        __syncthreads();
-        // ---- build: chained hash table of the tile's k-mers ------------------------------
-        for (int p = tid; p < tn; p += JOIN_THREADS) {
-            KT key = extract_key<BPS, K>(tile, (uint32_t)p);
-            bool ok;
-            if (BPS == 2) ok = !(exc2 && any_exc<K>(etile, (uint32_t)p));
-            else ok = !key_has_invalid<BPS, K>(key);
-            if (ok) {
-                uint32_t old = atomicExch(&head[hash_key<BPS, K>(key)], (uint32_t)p);
-                next[p] = (uint16_t)old;       // EMPTY32 -> 0xFFFF
+            __syncthreads();
+            // ---- build 1/3: bucket sizes (two 16-bit counters per LDS word) --------------------
+            for (int p = tid; p < tn; p += JOIN_THREADS) {
+                KT key = extract_key<BPS, K>(tile, (uint32_t)p);
+                bool ok;
+                if (BPS == 2) ok = !(exc2 && any_exc<K>(etile, (uint32_t)p));
+                else ok = !key_has_invalid<BPS, K>(key);
+                if (ok) {
+                    KT rc = revcomp_key<BPS, K>(key);
+                    const uint32_t h = canon_bucket<BPS, K>(key, rc);
+                    atomicAdd(&start32[h >> 1], 1u << ((h & 1u) * 16));
+                }
             }
-        }
-        __syncthreads();
-        // ---- probe: every read of the task, forward and reverse-complement k-mers -----------
-        for (int r = 0; r < task.n_reads; ++r) {
-            const DPair pr = pairs[task_pairs[task.first + r]];
-            const SeqDesc s1 = seqs[pr.seq1];
-            const int nk1 = s1.len - K + 1;
-            const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
-            const uint32_t* re = e1 + (size_t)s1.chunk0;
-            const bool exc1 = (BPS == 2) && s1.n_exc > 0;
-            uint32_t* out = hits + pr.hit_off;
-            for (int i = tid; i < nk1; i += JOIN_THREADS) {
-                if (exc1 && any_exc<K>(re, (uint32_t)i)) continue;
-                KT kf = extract_key<BPS, K>(rplane, (uint32_t)i);
-                KT kr = revcomp_key<BPS, K>(kf);
+            __syncthreads();
+            // ---- build 2/3: inclusive prefix -> end of every bucket ---------------------------
+            {
+                constexpr int WPT = (JNB / 2) / JOIN_THREADS;   // words per thread (16)
+                uint32_t local = 0;
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const KT& key = o ? kr : kf;
-                    uint32_t e = head[hash_key<BPS, K>(key)];
-                    while (e != EMPTY32) {
-                        KT a = extract_key<BPS, K>(tile, e);
-                        if (a == key) {
-                            int jf = ts + (int)e;
-                            if (jf >= pr.off2) {
-                                unsigned long long slot = atomicAdd(&cnt[r], 1ULL);
-                                if (slot < (unsigned long long)pr.cap)
-                                    out[slot] = ((uint32_t)(jf - pr.off2) << 16) | (uint32_t)i;
+                for (int x = 0; x < WPT; ++x) {
+                    uint32_t w = start32[tid * WPT + x];
+                    local += (w & 0xFFFFu) + (w >> 16);
+                }
+                uint32_t incl = wave_incl_scan_u32(local);
+                if (lane == 63) wtot[wave] = incl;
+                __syncthreads();
+                uint32_t run = incl - local;
+                for (int q = 0; q < wave; ++q) run += wtot[q];
+#pragma unroll
+                for (int x = 0; x < WPT; ++x) {
+                    uint32_t w = start32[tid * WPT + x];
+                    uint32_t lo = run + (w & 0xFFFFu);
+                    uint32_t hi = lo + (w >> 16);
+                    start32[tid * WPT + x] = lo | (hi << 16);
+                    run = hi;
+                }
+                if (tid == JOIN_THREADS - 1) start32[JNB / 2] = run;     // start[JNB] = number of entries
+            }
+            __syncthreads();
+            // ---- build 3/3: fill every bucket from its end; the counter ends as the bucket start
+            for (int p = tid; p < tn; p += JOIN_THREADS) {
+                KT key = extract_key<BPS, K>(tile, (uint32_t)p);
+                bool ok;
+                if (BPS == 2) ok = !(exc2 && any_exc<K>(etile, (uint32_t)p));
+                else ok = !key_has_invalid<BPS, K>(key);
+                if (ok) {
+                    KT rc = revcomp_key<BPS, K>(key);
+                    const uint32_t h = canon_bucket<BPS, K>(key, rc);
+                    const uint32_t sh = (h & 1u) * 16;
+                    uint32_t old = atomicSub(&start32[h >> 1], 1u << sh);
+                    entries[((old >> sh) & 0xFFFFu) - 1u] = (uint16_t)p;
+                }
+            }
+            __syncthreads();
+            // ---- probe: every read of the group ----------------------------------------------
+            for (int r = g0; r < g1; ++r) {
+                const DPair pr = pairs[task_pairs[task.first + r]];
+                const SeqDesc s1 = seqs[pr.seq1];
+                const int nk1 = s1.len - K + 1;
+                const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
+                const uint32_t* re = e1 + (size_t)s1.chunk0;
+                const bool exc1 = (BPS == 2) && s1.n_exc > 0;
+                uint32_t* out = hits + pr.hit_off;
+                constexpr int NWIN = ((15 + K) * BPS + 31) / 32;
+                constexpr int WPL = BPS / 2;                      // plane words per 16 positions
+                constexpr uint32_t SYM = (1u << BPS) - 1u;
+                for (int cb = wave * JCHUNK; cb < nk1; cb += JOIN_WAVES * JCHUNK) {
+                    // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
+                    {
+                        const int nw = min(rbuf_words<BPS>(), (int)((((size_t)(nk1 + K - 1 - cb)) * BPS + 31) >> 5) + 2);
+                        const uint32_t* src = rplane + (((size_t)cb * BPS) >> 5);
+                        for (int x = lane; x < rbuf_words<BPS>(); x += 64) rbuf[x] = x < nw ? src[x] : 0u;
+                    }
+                    unsigned long long EE = 0;                     // exception bits of positions i0 .. i0+63
+                    const int i0 = cb + 16 * lane;
+                    if (exc1 && i0 < nk1) {
+                        const uint32_t wi = (uint32_t)i0 >> 5, sh = (uint32_t)i0 & 31u;
+                        const uint32_t e0 = re[wi], e1w = re[wi + 1], e2w = re[wi + 2];
+                        EE = ((unsigned long long)__builtin_amdgcn_alignbit(e2w, e1w, sh) << 32) |
+                             __builtin_amdgcn_alignbit(e1w, e0, sh);
+                    }
+                    int qlen = 0;                                  // queued candidates (wave-uniform)
+                    // lane owns the 16 consecutive positions i0 .. i0+15: its window of the strip
+                    uint32_t W[NWIN + 1];
+#pragma unroll
+                    for (int x = 0; x < NWIN; ++x) W[x] = rbuf[lane * WPL + x];
+                    W[NWIN] = 0u;
+                    KT kr;
+                    for (int g = 0; g < 4; ++g) {
+                        if (BPS == 4 && g == 2) {                  // positions 8..15 start one word further on
+#pragma unroll
+                            for (int x = 0; x < NWIN; ++x) W[x] = W[x + 1];
+                        }
+                        // ---- keys and bucket bounds of four positions (their LDS reads are in flight together)
+                        uint32_t sc[4];                            // first slot | bucket size << 16
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4) {
+                            const int t = g * 4 + t4;
+                            const uint32_t sh = (uint32_t)(t * BPS) & 31u;
+                            KT kf;
+#pragma unroll
+                            for (int x = 0; x < KT::NW; ++x) kf.w[x] = __builtin_amdgcn_alignbit(W[x + 1], W[x], sh);
+                            kf.w[KT::NW - 1] &= KT::TOPMASK;
+                            if (t == 0) {
+                                kr = revcomp_key<BPS, K>(kf);
+                            } else {
+                                // slide the reverse complement: drop its last symbol, prepend comp(new symbol)
+                                uint32_t sym = (kf.w[KT::NW - 1] >> (KT::TOPBITS - BPS)) & SYM;
+                                uint32_t cs = (BPS == 2) ? (sym ^ 3u) : (sym ^ ((sym & 8u) ? 0u : 3u));
+#pragma unroll
+                                for (int x = KT::NW - 1; x > 0; --x)
+                                    kr.w[x] = (kr.w[x] << BPS) | (kr.w[x - 1] >> (32 - BPS));
+                                kr.w[0] = (kr.w[0] << BPS) | cs;
+                                kr.w[KT::NW - 1] &= KT::TOPMASK;
+                            }
+                            bool valid = (i0 + t) < nk1;
+                            if (exc1) {
+                                constexpr unsigned long long KM = (1ULL << K) - 1ULL;
+                                valid = valid && (((EE >> t) & KM) == 0ULL);
+                            }
+                            const uint32_t h = canon_bucket<BPS, K>(kf, kr);
+                            const uint32_t s0 = start16[h], s1v = start16[h + 1];
+                            sc[t4] = valid ? (s0 | ((s1v - s0) << 16)) : 0u;
+                        }
+                        // ---- four wave prefix sums of the bucket sizes, interleaved -------------------------
+                        uint32_t incl[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) incl[x] = sc[x] >> 16;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            uint32_t up[4];
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) up[x] = __shfl_up(incl[x], o, 64);
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) incl[x] += (lane >= o) ? up[x] : 0u;
+                        }
+                        // ---- fill the queue position by position; verify 128 candidates whenever they are there
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const uint32_t c = sc[x] >> 16, s0 = sc[x] & 0xFFFFu;
+                            const uint32_t tot = __builtin_amdgcn_readlane(incl[x], 63);
+                            if (tot == 0) continue;
+                            const uint32_t il = (uint32_t)(16 * lane + g * 4 + x);
+                            if (tot > (uint32_t)(JQCAP - 127)) {
+                                // more candidates than the queue can always take (long repeats): level by level
+                                for (uint32_t u = 0;; ++u) {
+                                    const bool act = c > u;
+                                    const unsigned long long m = __ballot(act);
+                                    if (!m) break;
+                                    if (act) {
+                                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                                        myq[qlen + (int)rank] = (il << 16) | (s0 + u);
+                                    }
+                                    qlen += __popcll(m);
+                                    if (qlen >= 128) {
+                                        join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2,
+                                                            &cnt[r], pr.cap, out);
+                                        qlen -= 128;
+                                    }
+                                }
+                                continue;
+                            }
+                            // qlen <= 127 here, so qlen + tot <= JQCAP
+                            {
+                                // buckets hold one or two entries almost always: two predicated stores, a loop
+                                // only for the rest
+                                const uint32_t pos = (uint32_t)qlen + incl[x] - c;
+                                const uint32_t item = (il << 16) | s0;
+                                if (c > 0u) myq[pos] = item;
+                                if (c > 1u) myq[pos + 1] = item + 1u;
+                                for (uint32_t u = 2; u < c; ++u) myq[pos + u] = item + u;
+                            }
+                            qlen += (int)tot;
+                            if (qlen >= 128) {
+                                join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, &cnt[r],
+                                                    pr.cap, out);
+                                qlen -= 128;
                             }
                         }
-                        uint32_t nx = next[e];
-                        e = (nx == 0xFFFFu) ? EMPTY32 : nx;
                     }
+                    // the strip changes: drain
+                    if (qlen > 0)
+                        join_verify<BPS, K>(myq, 0, qlen, entries, rbuf, tile, cb, ts, pr.off2, &cnt[r], pr.cap, out);
                 }
             }
         }
+        g0 = g1;
     }
     __syncthreads();
     if (tid < task.n_reads) n_hits[task_pairs[task.first + tid]] = cnt[tid];
