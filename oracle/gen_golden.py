@@ -622,10 +622,72 @@ def gen_vcf(m):
                                "cases": cases})
 
 
+def gen_other(m):
+    """vapor_CANNOT_CLASSIFY_VapoR (SF:1490-1555) on letter-structure calls, incl. the junction fallback."""
+    rng = np.random.default_rng(909)
+    m.make_event_figure_1 = lambda *a, **k: None
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_other_")
+    cases = []
+    specs = [("del_b", "ab_ab", "a_ab", 700, 500, 8, 0.6), ("inv_b", "ab_ab", "ab^_ab", 600, 900, 8, 0.6),
+             ("dup_b", "ab_ab", "abb_ab", 500, 400, 8, 0.6), ("swap", "ab_ab", "ba_ab", 450, 650, 8, 1.0),
+             ("both_alt", "ab_ab", "a_b^a", 500, 500, 9, 1.0), ("few_reads", "ab_ab", "a_ab", 500, 500, 3, 0.6),
+             ("long_span", "ab_ab", "a_ab", 6000, 5000, 8, 0.6), ("same_as_ref", "ab_ab", "ab_ab", 500, 500, 6, 0.5)]
+    w = synth.SynthWorld()
+    for t, (name, ref_s, alt_s, la, lb, n_reads, alt_frac) in enumerate(specs):
+        chrom = "o%d" % (t + 1)
+        f = 500
+        left = f + 400
+        contig = synth.random_dna(rng, left + la + lb + 9000)
+        b1, b2, b3 = left, left + la, left + la + lb
+        w.contigs[chrom] = contig
+        blocks = {"a": contig[b1:b2], "b": contig[b2:b3]}
+        alts = [x for x in alt_s.split("_") if x not in ref_s.split("_")] or ["ab"]
+        recs = []
+        for ri in range(n_reads):
+            from_alt = rng.random() < alt_frac
+            if from_alt:
+                al = alts[ri % len(alts)]
+                mid = ""
+                for ch in al:
+                    if ch == "^":
+                        continue
+                mid = "".join(synth.revcomp(blocks[x[0]]) if "^" in x else blocks[x] for x in _letters(al))
+                hap = contig[:b1] + mid + contig[b3:]
+            else:
+                hap = contig
+            a0 = b1 - f - 1 - int(rng.integers(1, 250))
+            seg = hap[a0:a0 + la + lb + 2 * f + 2600]
+            rd, cg = synth.mutate(rng, seg)
+            recs.append(synth.SamRecord("%s_%d" % (name, ri), chrom, a0 + 1, cg, rd, len(seg)))
+        w.reads[chrom] = recs
+        cases.append({"name": name, "sv_info": [ref_s, alt_s, chrom, str(b1), str(b2), str(b3)]})
+    ref_path = os.path.join(tmp, "ref.fa")
+    with open(ref_path + ".fai", "w") as fo:
+        for k, v in w.contigs.items():
+            fo.write("%s\t%d\t0\t60\t61\n" % (k, len(v)))
+    m.os = ShimOS(w)
+    for c in cases:
+        c["scores"] = call(m.vapor_CANNOT_CLASSIFY_VapoR, 3, 1, "x.bam", ref_path, list(c["sv_info"]), os.path.join(tmp, "f.png"))
+        print("  %s: %s" % (c["name"], c["scores"] if "error" in c["scores"] else [round(v, 3) for v in c["scores"]["ok"]]))
+    m.os = os
+    dump("locus_other.json.gz", {"source": "vapor_CANNOT_CLASSIFY_VapoR SF:1490-1555 (figures off)",
+                                 "world": world_to_json(w), "cases": cases})
+
+
+def _letters(al):
+    out = []
+    for ch in al:
+        if ch == "^":
+            out[-1] += ch
+        else:
+            out.append(ch)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)

@@ -52,3 +52,38 @@ def test_figures_render(tmp_path):
     out = tmp_path / "x.DEL.c1__1__2__DEL.png"
     figures.make_event_figure_1(drivers.Figure([0.5], [read[:990], 0, "r"], 10, ref, alt, str(out)))
     assert out.exists() and out.stat().st_size > 1000
+
+
+OTHER = load_golden("locus_other.json.gz")
+
+
+@pytest.mark.parametrize("case", OTHER["cases"], ids=lambda c: c["name"])
+def test_cannot_classify_driver_gpu(case):
+    from vapor_amd import pipeline, seqio, synth
+    from vapor_amd import simple_function as SF
+    pipeline.set_engine(None)
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(OTHER["world"])))
+    try:
+        got = SF.vapor_CANNOT_CLASSIFY_VapoR(3, 1, "x.bam", "ref.fa", list(case["sv_info"]), "f.png")
+        assert [float(v) for v in got] == [float(v) for v in case["scores"]["ok"]]
+    finally:
+        seqio.set_backend(None)
+
+
+VCF = load_golden("locus_vcf.json.gz")["cases"]
+
+
+@pytest.mark.parametrize("name", ["vcf_simple_nohdr", "vcf_tiny_span_nohdr"])
+def test_vcf_cli_gpu(name, tmp_path):
+    from vapor_amd import cli, pipeline, seqio, synth
+    case = [c for c in VCF if c["name"] == name][0]
+    pipeline.set_engine(None)
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
+    try:
+        vcf = tmp_path / "in.vcf"
+        vcf.write_text(case["vcf"])
+        assert cli.main(["vcf", "--sv-input", str(vcf), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                         "--output-path", str(tmp_path / "figs"), "--output-file", "unused", "--no-figures"]) == 0
+        assert (tmp_path / "in.vcf.vapor").read_text() == case["final"]
+    finally:
+        seqio.set_backend(None)

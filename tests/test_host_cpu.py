@@ -203,3 +203,35 @@ def test_vcf_with_header_annotates_the_right_records(fake, name, tmp_path):
     assert recs == [l for l in nohdr["final"].splitlines() if l and not l.startswith("#")]
     assert sum(1 for l in got if l.startswith("##INFO=<ID=VaPoR_")) == 4
     assert got[[i for i, l in enumerate(got) if l.startswith("#CHROM")][0] - 1].startswith("##source")
+
+
+OTHER = load_golden("locus_other.json.gz")
+
+
+@pytest.mark.parametrize("case", OTHER["cases"], ids=lambda c: c["name"])
+def test_cannot_classify_driver(fake, case):
+    """vapor_CANNOT_CLASSIFY_VapoR on letter structures (whole-region scoring and the junction fallback)."""
+    from vapor_amd import simple_function as SF
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(OTHER["world"])))
+    got = SF.vapor_CANNOT_CLASSIFY_VapoR(3, 1, "x.bam", "ref.fa", list(case["sv_info"]), "f.png")
+    assert [float(v) for v in got] == [float(v) for v in case["scores"]["ok"]]
+
+
+def test_svelter_mode_rows(fake, tmp_path):
+    world = synth.world_from_json(OTHER["world"])
+    seqio.set_backend(seqio.MemorySamtools(world))
+    sv = tmp_path / "calls.svelter"
+    rows = ["chr\tstart\tend\tbp_info\tref\talt\tscore"]
+    for c in OTHER["cases"][:4]:
+        i = c["sv_info"]
+        rows.append("\t".join([i[2], i[3], i[5], ":".join(i[2:]), i[0].replace("_", "/"), i[1].replace("_", "/"), "0"]))
+    sv.write_text("\n".join(rows) + "\n")
+    out = tmp_path / "out.txt"
+    assert cli.main(["svelter", "--sv-input", str(sv), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                     "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+    lines = out.read_text().splitlines()
+    assert len(lines) == 4
+    from vapor_amd import finish, simple_function as SF
+    for line, c in zip(lines, OTHER["cases"][:4]):
+        exp = SF.format_output_row(finish.result_organize_ins(["." + "_".join(c["sv_info"][2:]), c["scores"]["ok"]]))
+        assert line == exp

@@ -1,4 +1,4 @@
-"""`vapor bed | vcf | ins` - the reference's command line (vapor_vali/vapor:287-496) on the HIP path.
+"""`vapor bed | vcf | svelter | ins` - the reference's command line (vapor_vali/vapor:287-496) on the HIP path.
 
 Same sub-commands, same flags, same output files and rows.  What differs is the schedule: the
 reference scores one locus at a time; here every locus becomes a driver generator
@@ -258,8 +258,42 @@ def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
                 jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
                                       drivers.vapor_dup_inv(num_reads_cff, p, bam_in, ref, info, g))))
             elif x == 'Other':
-                raise NotImplementedError("records with an Other= structure (vapor_CANNOT_CLASSIFY_VapoR, SF:1490) "
-                                          "are not scored by this build yet: %s" % (y,))
+                key = ':'.join([str(i) for i in y + ['CANNOT_CLASSIFY']])
+                fig = out_path + sample_name + '.CANNOT_CLASSIFY.' + key.replace(':', '__') + '.png'
+                jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
+                                      drivers.vapor_cannot_classify(num_reads_cff, p, bam_in, ref, info, g))))
+    return jobs
+
+
+def svelter_readin(file_in):
+    """vapor_vali/vapor:255-268: {ref structure: {alt structure: [[chrom, bp, bp, ...], ...]}}."""
+    out = {}
+    with open(file_in) as fin:
+        fin.readline()
+        for line in fin:
+            pin = line.strip().split()
+            r = '_'.join(pin[4].split('/'))
+            a = '_'.join(pin[5].split('/'))
+            lst = out.setdefault(r, {}).setdefault(a, [])
+            if pin[3].split(':') not in lst:
+                lst.append(pin[3].split(':'))
+    return out
+
+
+def svelter_jobs(sv_hash, num_reads_cff, bam_in, ref, out_path, sample_name) -> List[Job]:
+    """The loop of vapor_vali/vapor:481-492."""
+    jobs = []
+    plt_li = 0
+    for k1 in list(sv_hash.keys()):
+        for k2 in list(sv_hash[k1].keys()):
+            for k3 in sv_hash[k1][k2]:
+                plt_li += 1
+                key = '.' + '_'.join(k3)
+                fig = out_path + sample_name + key.replace(':', '__') + '.png'
+                info = [k1, k2] + k3
+                print(info)
+                jobs.append(Job(key, (lambda p=plt_li, i=info, g=fig:
+                                      drivers.vapor_cannot_classify(num_reads_cff, p, bam_in, ref, i, g))))
     return jobs
 
 
@@ -342,11 +376,18 @@ def main(argv: Optional[List[str]] = None) -> int:
                 for j, sc in zip(jobs, scores):
                     print(SF.format_output_row(result_organize_ins([j.key, sc])), file=fo)
             SF.vcf_vapor_modify(args.sv_input, rec_new)
+    elif mode == 'svelter':
+        jobs = svelter_jobs(svelter_readin(args.sv_input), num_reads_cff, bam_in, ref, out_path, sample_name)
+        scores = score_jobs(jobs, args.chunk, figure_fn)
+        if vdist.rank() == 0:
+            with open(args.output_file, 'a') as fo:      # appended, never initialised (vapor_vali/vapor:492)
+                for j, sc in zip(jobs, scores):
+                    print(SF.format_output_row(result_organize_ins([j.key, sc])), file=fo)
     elif mode == 'ins':
         from . import melt
         melt.run(args.sv_input, out_path, sample_name.split('.')[0], bam_in, ref, num_reads_cff, args.chunk, figure_fn)
     else:
-        raise SystemExit("vapor: unknown mode %r (bed | vcf | ins)" % mode)
+        raise SystemExit("vapor: unknown mode %r (bed | vcf | svelter | ins)" % mode)
     vdist.finalize()
     return 0
 

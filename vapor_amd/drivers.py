@@ -394,3 +394,132 @@ def vapor_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
                 raise TypeError("vapor_simple_%s_Vapor() missing 2 required positional arguments: "
                                 "'sv_info' and 'out_figure_name'" % ("del" if "del" in sub else "inv"))
     return scores
+
+
+# ------------------------------------------------------------------------------------------
+# complex structures written as letter strings (SVelter style): 'ab_ab' -> 'b_b^' etc.
+# ------------------------------------------------------------------------------------------
+
+def letter_split(let):
+    """SF:1013-1019: 'c^ba' -> ['c^', 'b', 'a']."""
+    out = []
+    for x in let:
+        if not x == '^':
+            out.append(x)
+        else:
+            out[-1] += x
+    return out
+
+
+def list_unify(items):
+    """SF:1021-1025."""
+    out = []
+    for i in items:
+        if i not in out:
+            out.append(i)
+    return out
+
+
+def block_subsplot(bp_list, chromos):
+    """SF:147-153: ['chr1', '10', '20', 'chr2', '5', '9'] -> [['chr1', 10, 20], ['chr2', 5, 9]]."""
+    out = []
+    for x in bp_list:
+        if x not in chromos:
+            out[-1].append(int(x))
+        else:
+            out.append([x])
+    return out
+
+
+def bp_to_chr_hash(bps, chromos, flank_length=500):
+    """SF:98-114: letters a, b, ... for consecutive blocks, '-' / '+' for the flanks (with the
+    reference's mix of int and str coordinates)."""
+    groups = []
+    for i in bps:
+        if i in chromos:
+            groups.append([i])
+        else:
+            groups[-1].append(i)
+    out = {}
+    rec = -1
+    for k1 in groups:
+        for k2 in range(len(k1[2:])):
+            rec += 1
+            out[chr(97 + rec)] = [k1[0], k1[k2 + 1], k1[k2 + 2]]
+    last = out[sorted(out.keys())[-1]]
+    out['+'] = [last[0], last[2], str(int(last[2]) + flank_length)]
+    out['-'] = [out['a'][0], str(int(out['a'][1]) - flank_length), int(out['a'][1])]
+    return out
+
+
+def block_around_check(alt_allele, ref_allele):
+    """SF:91-96: junctions of the alt allele that the ref allele does not have."""
+    al = ['-'] + letter_split(alt_allele) + ['+']
+    rl = ['-'] + letter_split(ref_allele) + ['+']
+    n = len(letter_split(alt_allele)) + 1
+    alt_j = [al[j:j + 2] for j in range(n)]
+    ref_j = [rl[j:j + 2] for j in range(n)]
+    return [i for i in alt_j if i not in ref_j]
+
+
+def vapor_cannot_classify(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    """vapor_CANNOT_CLASSIFY_VapoR, SF:1490-1555.
+    sv_info = ['ab_ab', 'b_b^', 'chr7', '70955990', '70961199', '70973901']."""
+    ref_sv = sv_info[0].split('_')
+    alt_sv = list_unify([i for i in sv_info[1].split('_') if i not in ref_sv])
+    chromos = seqio.chromos_readin(ref)
+    bp_info = block_subsplot(sv_info[2:], chromos)
+    flank = max([seqio.flank_length_calculate(i) for i in bp_info])
+    scores: List[float] = []
+    ran = False
+    if len(bp_info) == 1:
+        b0 = bp_info[0]
+        if b0[-1] - b0[1] < default_max_sv_test:
+            ref_seq = seqio.ref_seq_readin(ref, b0[0], b0[1] - flank, b0[-1] + flank)
+            k = yield from _window(ref_seq)
+            if not k == "Error":
+                reads = seqio.simple_chop_pacbio_read_simple_short(bam_in, b0, flank)
+                let_hash = bp_to_chr_hash(b0, chromos, flank)
+                if len(reads) > num_reads_cff:
+                    ran = True
+                    let_seq = {}
+                    for i in list(let_hash.keys()):
+                        let_seq[i] = seqio.ref_seq_readin(ref, let_hash[i][0], int(let_hash[i][1]), int(let_hash[i][-1]))
+                    for alt_allele in alt_sv:
+                        alt_seq = ref_seq[:flank]
+                        for i in letter_split(alt_allele):
+                            alt_seq += let_seq[i] if '^' not in i else _rc(let_seq[i[0]])
+                        alt_seq += ref_seq[-flank:]
+                        k = yield from _window(alt_seq)
+                        if not k == "Error":
+                            repeated = max([alt_allele.count(i) for i in alt_allele] + [0]) > 1
+                            res = yield Score("s3" if repeated else "s1", ref_seq, alt_seq, reads, k)
+                            best = _collect(res, reads, scores)
+                            parts = out_figure_name.split('.')
+                            yield Figure(scores, best, k, ref_seq, alt_seq,
+                                         '.'.join(parts[:-1] + [ref_sv[0] + '.vs.' + alt_allele, parts[-1]]))
+        if not ran:
+            for alt_allele in alt_sv:
+                juncs = block_around_check(alt_allele, ref_sv[0])
+                let_hash = bp_to_chr_hash(b0, chromos, flank)
+                for jun in juncs:
+                    ha, hb = let_hash[jun[0][0]], let_hash[jun[1][0]]
+                    if '^' not in jun[0]:
+                        ref_a = seqio.ref_seq_readin(ref, ha[0], ha[2] - flank, ha[2] + flank)
+                    else:
+                        ref_a = _rc(seqio.ref_seq_readin(ref, ha[0], ha[1] - flank, ha[1] + flank))
+                    if '^' not in jun[1]:
+                        ref_b = seqio.ref_seq_readin(ref, hb[0], hb[1] - flank, hb[1] + flank)
+                    else:
+                        ref_b = _rc(seqio.ref_seq_readin(ref, hb[0], hb[2] - flank, hb[2] + flank))
+                    k = yield from _window(ref_a + ref_b)
+                    if not k == "Error":
+                        alt_seq = ref_a[-flank:] + ref_b[:flank]
+                        k = yield from _window(alt_seq)
+                        if not k == "Error":
+                            where = [ha[0], ha[2]] if '^' not in jun[0] else [ha[0], ha[1]]
+                            reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, where, flank)
+                            if len(reads) > 0:
+                                res = yield Score("s2", ref_a, alt_seq, reads, k)
+                                _collect(res, reads, scores)
+    return scores

@@ -145,6 +145,13 @@ def vapor_long_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_n
     return _sync(drivers.vapor_long_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name))
 
 
+def vapor_CANNOT_CLASSIFY_VapoR(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
+    return _sync(drivers.vapor_cannot_classify(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name))
+
+
+from .drivers import block_around_check, block_subsplot, bp_to_chr_hash, letter_split, list_unify  # noqa: E402,F401
+
+
 # ---------------------------------------------------------------------------
 # output writers and small helpers (SURVEY.md components #5, #6)
 # ---------------------------------------------------------------------------
