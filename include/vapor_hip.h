@@ -116,7 +116,7 @@ int vapor_plan_destroy(vapor_plan* plan);
 int vapor_plan_run(vapor_plan* plan, int64_t* stats);
 /* device time of the kernels of the last vapor_plan_run, measured with HIP events on the
  * library's stream: ms[0] = join kernels, ms[1] = clean kernel, ms[2] = whole run incl. copies,
- * ms[3] = number of join launches, ms[4] = number of retried pairs */
+ * ms[3] = number of join launches, ms[4] = number of retried pairs, ms[5] = finish kernel */
 int vapor_plan_timings(vapor_plan* plan, double* ms, int32_t n);
 /* algorithmic bytes of one run: sum over pairs of packed read + packed allele
  * + 8 B per hit + 128 B statistics record, using the hit counts of the last run */
@@ -129,6 +129,31 @@ int vapor_plan_algorithmic_bytes(vapor_plan* plan, int64_t* bytes, int64_t* cell
  */
 int vapor_plan_fetch_hits(vapor_plan* plan, int64_t n_sel, const int64_t* pair_idx,
                           int32_t* hits_ji, uint8_t* hit_flags, int64_t capacity, int64_t* hit_off);
+
+/* ---- per-read scores and per-locus results on the device ------------------------------------ */
+/*
+ * One read of one locus and the dot plots that score it.  kind 1: abs_dis_m1b (SF:182-203) on pairs
+ * (ref_a, alt_a); 2: within_10Perc_m1b (SF:277-294); 3: directed_dis_m1b_redefine_diagnal
+ * (SF:241-257); 0: a deletion read - abs_dis_m1b on (ref_a, alt_a) and within_10Perc_m1b on
+ * (ref_b, alt_b), the smaller score wins (SF:1718-1726).  len_ref / len_alt are the full allele
+ * lengths the gates divide by.  Reads must be sorted by locus.
+ */
+typedef struct vapor_read {
+    int32_t ref_a, alt_a, ref_b, alt_b;
+    int32_t kind, locus, len_ref, len_alt;
+} vapor_read;
+
+#define VAPOR_GT_TABLE_N 65
+#define VAPOR_LOCUS_STRIDE 8 /* doubles per locus: QS, GS, GT (0 = 0/0, 1 = 0/1, 2 = 1/1), GQ, reads scored,
+                                positive scores, scores that round to <= 0, reserved; all NaN but [4] = 0 for an 'NA' locus */
+/* gt_table[(k * 65 + l) * 2 + {0,1}] = genotype index and quality for k scored reads of which l round to
+ * <= 0 (gt_estimate_log_likelihood SF:2054-2069, evaluated by the host with the reference's float64 steps). */
+int vapor_plan_set_reads(vapor_plan* plan, int64_t n_reads, const vapor_read* reads, int64_t n_loci,
+                         const double* gt_table);
+/* join -> clean -> per-read scores (SF:1718-1726 etc.) -> result_organize_ins (SF:1219-1231) ->
+ * genotype, all on the device.  d_loci_out: device buffer (may be NULL) filled on the library's stream
+ * before it is synchronised; loci_out / read_scores: host copies (may be NULL; a skipped read is NaN). */
+int vapor_plan_run_loci(vapor_plan* plan, void* d_loci_out, double* loci_out, double* read_scores);
 
 /* ---- one-shot conveniences over the above -------------------------------------------------- */
 /* dotdata for a batch (create + run + fetch all + destroy). */

@@ -227,3 +227,35 @@ def test_bad_arguments(eng):
     assert st[0, 15] == -4 and st[1, 15] == -4
     assert st[2, 15] == 0 and st[2, 0] == 0 and st[2, 1] == -1
     assert st[3, 15] == 0 and st[3, 0] == 0
+
+
+@pytest.mark.parametrize("name", ["tiny", "mid"])
+def test_device_finish_matches_host_finish(eng, name):
+    """finish_kernel (per-read scores, QS/GS/GT/GQ on the device) == vapor_amd.finish on the host."""
+    from vapor_amd import workload as wl
+    spec = dict(wl.WORKLOADS["tiny"]) if name == "tiny" else dict(n_loci=24, svtypes=("DEL", "TANDUP", "INV", "INS"),
+                                                                read_len=3000, allele_len=3400, reads_per_locus=17)
+    w = wl.make_workload(name, seed=5, **spec)
+    ss = eng.seqset(w.seqs)
+    plan = eng.plan(ss, w.pairs)
+    st = plan.run().copy()
+    host = wl.finish_workload(w, st)
+    plan.set_reads(wl.read_table(w), w.n_loci)
+    for _ in range(2):          # first call takes the full path, the second the statistics-stay-on-device path
+        dev = plan.run_loci(want_scores=True).copy()
+        assert np.array_equal(np.isnan(dev[:, 0]), np.isnan(host[:, 0]))
+        ok = ~np.isnan(host[:, 0])
+        assert ok.sum() >= 2
+        assert np.array_equal(dev[ok, 1], host[ok, 1])            # GS
+        assert np.array_equal(dev[ok, 2], host[ok, 2])            # GT
+        assert np.array_equal(dev[ok, 3], host[ok, 3])            # GQ (same table)
+        assert np.array_equal(dev[ok, 4], host[ok, 4])            # reads scored
+        assert np.allclose(dev[ok, 0], host[ok, 0], rtol=0, atol=1e-12)
+        # QS in numpy's own summation order: identical to np.mean over the positive scores
+        sc = plan.read_scores[:len(w.read_locus)]
+        for li in np.flatnonzero(ok):
+            v = sc[w.read_locus == li]
+            v = v[~np.isnan(v)]
+            pos = [float(x) for x in v if x > 0]
+            assert dev[li, 0] == (np.mean(pos) if pos else 0.0)
+    plan.close()

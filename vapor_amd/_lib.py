@@ -14,7 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libvapor_hip.so")
 
 PAIR_DTYPE = np.dtype([("seq1", "<i4"), ("seq2", "<i4"), ("off2", "<i4"), ("k", "<i4"), ("flags", "<u4")])
+READ_DTYPE = np.dtype([("ref_a", "<i4"), ("alt_a", "<i4"), ("ref_b", "<i4"), ("alt_b", "<i4"), ("kind", "<i4"),
+                       ("locus", "<i4"), ("len_ref", "<i4"), ("len_alt", "<i4")])
 STATS_STRIDE = 16
+LOCUS_STRIDE = 8
+GT_TABLE_N = 65
 ST_N_HITS, ST_FIRST_J, ST_LAST_J, ST_C1_KEPT, ST_C1_SUM_ABS = 0, 1, 2, 3, 4
 ST_C2_KEPT, ST_C2_COUNT10, ST_N_DIAG, ST_N_LOWER, ST_C2_KEPT_DIAG, ST_STATUS = 5, 6, 7, 8, 9, 15
 ST_DIR_C2X, ST_DIR_N, ST_DIR_SUM2, ST_DIR_LISTS = 10, 11, 12, 13
@@ -29,6 +33,7 @@ EXPORTS = [
     "vapor_seqset_create", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
+    "vapor_plan_set_reads", "vapor_plan_run_loci",
 ]
 
 _lib = None
@@ -72,6 +77,8 @@ def load() -> ctypes.CDLL:
     L.vapor_score_batch.argtypes = [vp, vp, ctypes.c_int64, vp, i64p]
     L.vapor_selfplot_qc.argtypes = [vp, vp, ctypes.c_int32, i32p, i32p, i64p]
     L.vapor_clean_hits.argtypes = [vp, ctypes.c_int64, i32p, i64p, u32p, i64p, u8p]
+    L.vapor_plan_set_reads.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, f64p]
+    L.vapor_plan_run_loci.argtypes = [vp, vp, f64p, f64p]
     for name in EXPORTS:
         if name not in ("vapor_last_error",):
             getattr(L, name).restype = ctypes.c_int

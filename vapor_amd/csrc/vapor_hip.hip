@@ -77,9 +77,20 @@ struct vapor_plan {
     long long* d_stats = nullptr;
     long long* h_stats = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_f[2] = {nullptr, nullptr};
     double t_join = 0, t_clean = 0, t_total = 0;
     int n_retried = 0;
     bool ran = false;
+    // optional per-read / per-locus finishing on the device
+    int64_t n_reads = 0, n_loci = 0;
+    DRead* d_reads = nullptr;
+    int32_t* d_locus_first = nullptr;
+    double* d_gt = nullptr;
+    double* d_read_scores = nullptr;
+    double* d_loci = nullptr;
+    unsigned int* d_overflow = nullptr;
+    unsigned int* h_overflow = nullptr;   // pinned
+    double t_finish = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -259,6 +270,11 @@ static void plan_free_device(vapor_plan* p)
     (void)hipFree(p->d_hflags); p->d_hflags = nullptr;
     (void)hipFree(p->d_nhits); p->d_nhits = nullptr;
     (void)hipFree(p->d_stats); p->d_stats = nullptr;
+    (void)hipFree(p->d_reads); p->d_reads = nullptr;
+    (void)hipFree(p->d_locus_first); p->d_locus_first = nullptr;
+    (void)hipFree(p->d_gt); p->d_gt = nullptr;
+    (void)hipFree(p->d_read_scores); p->d_read_scores = nullptr;
+    (void)hipFree(p->d_loci); p->d_loci = nullptr;
 }
 
 extern "C" int vapor_plan_destroy(vapor_plan* p)
@@ -267,7 +283,11 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
     (void)hipSetDevice(p->ctx->device);
     plan_free_device(p);
     if (p->h_stats) (void)hipHostFree(p->h_stats);
+    if (p->h_overflow) (void)hipHostFree(p->h_overflow);
+    (void)hipFree(p->d_overflow);
     for (auto& e : p->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : p->ev_f)
         if (e) (void)hipEventDestroy(e);
     delete p;
     return VAPOR_OK;
@@ -395,7 +415,10 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     chk(hipMalloc((void**)&p->d_nhits, sizeof(unsigned long long) * p->hp.size()), "hipMalloc nhits");
     chk(hipMalloc((void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
     chk(hipHostMalloc((void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
+    chk(hipMalloc((void**)&p->d_overflow, sizeof(unsigned int)), "hipMalloc overflow");
+    chk(hipHostMalloc((void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
+    for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
     if (rc == VAPOR_OK && !p->tasks.empty())
         chk(hipMemcpyAsync(p->d_tasks, p->tasks.data(), sizeof(DTask) * p->tasks.size(), hipMemcpyHostToDevice, ctx->stream), "copy tasks");
     if (rc == VAPOR_OK && !order.empty())
@@ -433,12 +456,13 @@ static size_t clean_lds_bytes(int range_words_cap, int hcap)
     return sizeof(uint32_t) * ((size_t)range_words_cap * 3 + (size_t)clean_groups_cap(range_words_cap)) + (size_t)hcap * 5;
 }
 
-static int plan_run_once(vapor_plan* p)
+static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = c->stream;
     HIPCHK(hipEventRecord(p->ev[0], st));
     HIPCHK(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), st));
+    HIPCHK(hipMemsetAsync(p->d_overflow, 0, sizeof(unsigned int), st));
     for (const Launch& L : p->launches) {
         if (L.bps == 2) {
             if (L.k == 10) launch_join<2, 10>(p, L);
@@ -459,12 +483,18 @@ static int plan_run_once(vapor_plan* p)
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st, p->set->d_seqs,
                            p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
-                           p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap);
+                           p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap, p->d_overflow);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(p->ev[2], st));
-    if (p->n_pairs > 0)
+    if (p->n_pairs > 0 && fetch_stats)
         HIPCHK(hipMemcpyAsync(p->h_stats, p->d_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyDeviceToHost, st));
+    if (!fetch_stats) {
+        // device-side finishing: the statistics stay in HBM, only the overflow count comes back
+        HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(p->ev[3], st));
+        return VAPOR_OK;
+    }
     HIPCHK(hipEventRecord(p->ev[3], st));
     HIPCHK(hipStreamSynchronize(st));
     float a = 0, b = 0, t = 0;
@@ -514,8 +544,8 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
 {
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
-    double v[5] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried};
-    for (int i = 0; i < n && i < 5; ++i) ms[i] = v[i];
+    double v[6] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish};
+    for (int i = 0; i < n && i < 6; ++i) ms[i] = v[i];
     return VAPOR_OK;
 }
 
@@ -690,7 +720,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     if (rc == VAPOR_OK) {
         int hcap = clean_hcap(rw, 4096);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_sd, d_dp,
-                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), hcap);
+                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), hcap, (unsigned int*)nullptr);
         chk(hipGetLastError(), "clean launch");
         chk(hipMemcpyAsync(stats, d_st, sizeof(long long) * 16 * (size_t)n_lists, hipMemcpyDeviceToHost, st), "copy");
         if (hit_flags && tot) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)tot, hipMemcpyDeviceToHost, st), "copy");
@@ -698,4 +728,95 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     }
     (void)hipFree(d_sd); (void)hipFree(d_dp); (void)hipFree(d_nh); (void)hipFree(d_hits); (void)hipFree(d_fl); (void)hipFree(d_st);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-read scores and per-locus summaries on the device
+extern "C" int vapor_plan_set_reads(vapor_plan* p, int64_t n_reads, const vapor_read* reads, int64_t n_loci,
+                                    const double* gt_table)
+{
+    if (!p || n_reads < 0 || n_loci < 0 || (n_reads && !reads) || !gt_table)
+        return fail(VAPOR_E_ARG, "vapor_plan_set_reads: null argument");
+    static_assert(sizeof(vapor_read) == sizeof(DRead), "vapor_read layout");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    std::vector<int32_t> first((size_t)n_loci + 1, 0);
+    int32_t prev = -1;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const vapor_read& x = reads[r];
+        if (x.locus < prev || x.locus >= n_loci) return fail(VAPOR_E_ARG, "reads must be sorted by locus");
+        const int32_t idx[4] = {x.ref_a, x.alt_a, x.kind == 0 ? x.ref_b : x.ref_a, x.kind == 0 ? x.alt_b : x.alt_a};
+        for (int32_t q : idx)
+            if (q < 0 || q >= p->n_pairs) return fail(VAPOR_E_ARG, "read refers to a pair outside the plan");
+        if (x.kind < 0 || x.kind > 3) return fail(VAPOR_E_ARG, "unknown scorer kind");
+        prev = x.locus;
+        first[(size_t)x.locus + 1]++;
+    }
+    for (int64_t l = 0; l < n_loci; ++l) first[l + 1] += first[l];
+    (void)hipFree(p->d_reads); (void)hipFree(p->d_locus_first); (void)hipFree(p->d_gt); (void)hipFree(p->d_read_scores); (void)hipFree(p->d_loci);
+    p->d_reads = nullptr; p->d_locus_first = nullptr; p->d_gt = nullptr; p->d_read_scores = nullptr; p->d_loci = nullptr;
+    HIPCHK(hipMalloc((void**)&p->d_reads, sizeof(DRead) * std::max<int64_t>(n_reads, 1)));
+    HIPCHK(hipMalloc((void**)&p->d_locus_first, sizeof(int32_t) * first.size()));
+    HIPCHK(hipMalloc((void**)&p->d_gt, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N));
+    HIPCHK(hipMalloc((void**)&p->d_read_scores, sizeof(double) * std::max<int64_t>(n_reads, 1)));
+    HIPCHK(hipMalloc((void**)&p->d_loci, sizeof(double) * 8 * std::max<int64_t>(n_loci, 1)));
+    if (n_reads) HIPCHK(hipMemcpy(p->d_reads, reads, sizeof(DRead) * n_reads, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_locus_first, first.data(), sizeof(int32_t) * first.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_gt, gt_table, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N, hipMemcpyHostToDevice));
+    p->n_reads = n_reads;
+    p->n_loci = n_loci;
+    return VAPOR_OK;
+}
+
+// join -> clean -> finish on the device; the per-pair statistics stay in HBM.  d_loci_out (device
+// pointer, n_loci * 8 doubles, may be NULL) receives a copy on the library's stream before it is
+// synchronised; loci_out / read_scores (host, may be NULL) receive host copies.
+extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci_out, double* read_scores)
+{
+    if (!p) return fail(VAPOR_E_ARG, "vapor_plan_run_loci: null plan");
+    if (!p->d_reads) return fail(VAPOR_E_ARG, "vapor_plan_run_loci: call vapor_plan_set_reads first");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    bool host_status = false;
+    for (int64_t i = 0; i < p->n_pairs; ++i)
+        if (p->status[i] != 0) { host_status = true; break; }
+    int rc;
+    if (host_status || !p->ran) {
+        // first run, or pairs the host marked as failed: full path once (statistics to the host, slots grown)
+        rc = vapor_plan_run(p, p->last_stats.data());
+        if (rc != VAPOR_OK) return rc;
+        if (host_status)
+            HIPCHK(hipMemcpyAsync(p->d_stats, p->h_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyHostToDevice, st));
+    } else {
+        rc = plan_run_once(p, false);
+        if (rc != VAPOR_OK) return rc;
+    }
+    hipEvent_t e0 = p->ev_f[0], e1 = p->ev_f[1];
+    HIPCHK(hipEventRecord(e0, st));
+    if (p->n_loci > 0) {
+        hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, st, p->d_reads, p->d_locus_first, p->d_stats,
+                           p->d_gt, p->d_read_scores, p->d_loci);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    if (d_loci_out && p->n_loci)
+        HIPCHK(hipMemcpyAsync(d_loci_out, p->d_loci, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToDevice, st));
+    if (loci_out && p->n_loci)
+        HIPCHK(hipMemcpyAsync(loci_out, p->d_loci, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
+    if (read_scores && p->n_reads)
+        HIPCHK(hipMemcpyAsync(read_scores, p->d_read_scores, sizeof(double) * (size_t)p->n_reads, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!(host_status) && p->ran && *p->h_overflow != 0) {
+        // some pair outgrew its hit slot on this run: redo through the full path, which resizes
+        rc = vapor_plan_run(p, p->last_stats.data());
+        if (rc != VAPOR_OK) return rc;
+        return vapor_plan_run_loci(p, d_loci_out, loci_out, read_scores);
+    }
+    float f = 0, a = 0, b = 0, t = 0;
+    HIPCHK(hipEventElapsedTime(&f, e0, e1));
+    p->t_finish = f;
+    if (hipEventElapsedTime(&a, p->ev[0], p->ev[1]) == hipSuccess && hipEventElapsedTime(&b, p->ev[1], p->ev[2]) == hipSuccess &&
+        hipEventElapsedTime(&t, p->ev[0], e1) == hipSuccess) {
+        p->t_join = a; p->t_clean = b; p->t_total = t;
+    }
+    return VAPOR_OK;
 }

@@ -973,7 +973,8 @@ __device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPai
 __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
     const SeqDesc* __restrict__ seqs, const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
-    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap)
+    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
+    unsigned int* __restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
@@ -990,6 +991,7 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
             if (tid == 15 && nh) v = -2;      // VAPOR_E_OVERFLOW: rerun with cap >= n_hits
             st[tid] = v;
         }
+        if (tid == 0 && nh && overflow) atomicAdd(overflow, 1u);
         return;
     }
     const int n = (int)nh;                     // cap < 2^31
@@ -1052,6 +1054,151 @@ __global__ __launch_bounds__(256) void gather_kernel(const DPair* __restrict__ p
         out_ji[2 * (o + h)] = (int32_t)(x >> 16);
         out_ji[2 * (o + h) + 1] = (int32_t)(x & 0xFFFFu);
         if (out_flags) out_flags[o + h] = hflags[pr.hit_off + h];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// finish kernel: statistics records -> per-read scores -> per-locus VaPoR_QS / GS / GT / GQ
+// ------------------------------------------------------------------------------------------
+// Float64 restatement of the scorers' gates (SF:182-203, 241-257, 277-294), the drivers' per-read
+// rule (skip a read when either scorer output is 0, score = 1 - b/a; DEL takes the min of the
+// abs_dis and within_10Perc scores, SF:1718-1726), result_organize_ins (SF:1219-1231; the mean of
+// the positive scores in numpy's pairwise order) and gt_estimate_log_likelihood (SF:2054-2069)
+// through a (k, l) -> (GT, GQ) table the host fills with the reference's own float64 operations.
+struct DRead {            // 32 B: one read of one locus
+    int32_t ref_a, alt_a; // pair indices for scorer A (kind 1 abs_dis_m1b, 2 within_10Perc, 3 directed_dis)
+    int32_t ref_b, alt_b; // kind 0 (DEL): scorer A = abs_dis_m1b, scorer B = within_10Perc on these pairs
+    int32_t kind, locus, len_ref, len_alt;
+};
+
+#define VAPOR_GT_TABLE_N 65   // k, l in 0..64
+
+__device__ __forceinline__ bool score_s1(const long long* r, const long long* a, double lr, double la, double* oa, double* ob)
+{
+    *oa = 0.0; *ob = 0.0;
+    if (r[0] > 2 && a[0] > 2 && (double)r[0] / fmin(lr, la) > 0.1) {
+        const bool r_ok = (double)(r[2] - r[1]) / lr > 0.6, a_ok = (double)(a[2] - a[1]) / la > 0.6;
+        if (r_ok && a_ok) {
+            if (r[3] > 0 && a[3] > 0) { *oa = (double)r[4] / (double)r[3]; *ob = (double)a[4] / (double)a[3]; }
+        } else if (r_ok) { *oa = 1.1; *ob = 2.1; }
+        else if (a_ok) { *oa = 2.1; *ob = 1.1; }
+    }
+    return *oa != 0.0 && *ob != 0.0;
+}
+
+__device__ __forceinline__ bool score_s2(const long long* r, const long long* a, double lr, double la, double* oa, double* ob)
+{
+    *oa = 0.0; *ob = 0.0;
+    if (fmax((double)r[0] / lr, (double)a[0] / la) > 0.1 && r[5] > 0 && a[5] > 0) { *oa = (double)a[6]; *ob = (double)r[6]; }
+    return *oa != 0.0 && *ob != 0.0;
+}
+
+__device__ __forceinline__ double dir_value(const long long* s)
+{
+    return s[11] == 0 ? 0.0001 : fabs(((double)s[12] * 0.5) / (double)s[11]);
+}
+
+__device__ __forceinline__ bool score_s3(const long long* r, const long long* a, double lr, double la, double* oa, double* ob)
+{
+    *oa = 0.0; *ob = 0.0;
+    if ((double)r[0] / lr > 0.1 && (double)a[0] / la > 0.1 && (double)(r[2] - r[1]) / lr > 0.7 &&
+        (double)(a[2] - a[1]) / la > 0.7 && r[3] > 0 && a[3] > 0) { *oa = dir_value(r); *ob = dir_value(a); }
+    return *oa != 0.0 && *ob != 0.0;
+}
+
+// one wave per locus; reads of a locus are contiguous (locus_first[l] .. locus_first[l+1])
+__global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ reads, const int32_t* __restrict__ locus_first,
+                                                   const long long* __restrict__ stats, const double* __restrict__ gt_table,
+                                                   double* __restrict__ read_scores, double* __restrict__ loci_out)
+{
+    __shared__ double sc[256];
+    const int l = blockIdx.x, lane = threadIdx.x;
+    const int r0 = locus_first[l], r1 = locus_first[l + 1];
+    int n = 0, npos = 0, nnonpos = 0;
+    double res = 0.0;
+    // numpy.add.reduce order for the mean of the positives (pairwise_sum, n <= 128): fewer than 8 values
+    // are added one by one; otherwise eight strided partial sums over the first n - n%8 values are combined
+    // as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the last n%8 values are added after that.  Exact for
+    // loci of up to 256 reads (the reference keeps at most 20, SF:1091); longer synthetic lists are summed
+    // chunk by chunk.
+    for (int base = r0; base < r1; base += 256) {
+        const int cnt = min(256, r1 - base);
+        for (int t = lane; t < cnt; t += 64) {
+            const DRead rd = reads[base + t];
+            const double lr = (double)rd.len_ref, la = (double)rd.len_alt;
+            double a, b, s = __builtin_nan("");
+            bool ok = false;
+            if (rd.kind == 0) {
+                double a2, b2;
+                const bool v1 = score_s1(stats + 16LL * rd.ref_a, stats + 16LL * rd.alt_a, lr, la, &a, &b);
+                const bool v2 = score_s2(stats + 16LL * rd.ref_b, stats + 16LL * rd.alt_b, lr, la, &a2, &b2);
+                const double s1 = 1.0 - b / a, s2 = 1.0 - b2 / a2;
+                if (v1 && v2) { s = (s2 < s1) ? s2 : s1; ok = true; }
+                else if (v1) { s = s1; ok = true; }
+                else if (v2) { s = s2; ok = true; }
+            } else {
+                const long long* r = stats + 16LL * rd.ref_a;
+                const long long* q = stats + 16LL * rd.alt_a;
+                ok = rd.kind == 1 ? score_s1(r, q, lr, la, &a, &b) : rd.kind == 2 ? score_s2(r, q, lr, la, &a, &b)
+                                                                               : score_s3(r, q, lr, la, &a, &b);
+                if (ok) s = 1.0 - b / a;
+            }
+            sc[t] = ok ? s : __builtin_nan("");
+            if (read_scores) read_scores[base + t] = sc[t];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int cpos = 0;
+            for (int t = 0; t < cnt; ++t) {
+                const double v = sc[t];
+                if (v != v) continue;                 // NaN marks a skipped read
+                ++n;
+                if (!(v >= 0.005)) ++nnonpos;         // round(v, 2) > 0  <=>  v >= 0.005
+                if (v > 0.0) ++cpos;
+            }
+            double part = 0.0;
+            if (cpos < 8) {
+                for (int t = 0; t < cnt; ++t) if (sc[t] > 0.0) part += sc[t];
+            } else {
+                double r8[8];
+                const int full = cpos - (cpos % 8);
+                int idx = 0;
+                for (int t = 0; t < cnt; ++t) {
+                    const double v = sc[t];
+                    if (!(v > 0.0)) continue;
+                    if (idx < 8) r8[idx] = v;
+                    else if (idx < full) r8[idx & 7] += v;
+                    else {
+                        if (idx == full) part = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+                        part += v;
+                    }
+                    ++idx;
+                }
+                if (cpos == full) part = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+            }
+            res += part;
+            npos += cpos;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        double* o = loci_out + 8LL * l;
+        if (n == 0) {
+            for (int t = 0; t < 8; ++t) o[t] = __builtin_nan("");
+            o[4] = 0.0;
+            return;
+        }
+        const double qs = npos > 0 ? res / (double)npos : 0.0;
+        const double gs = (double)npos / (double)n;
+        int gt = 1;
+        double gq = __builtin_nan("");
+        if (n < VAPOR_GT_TABLE_N) {
+            gt = (int)gt_table[2 * (n * VAPOR_GT_TABLE_N + nnonpos)];
+            gq = gt_table[2 * (n * VAPOR_GT_TABLE_N + nnonpos) + 1];
+        }
+        if (gt == 0 && gs > 0.15) gt = 1;
+        o[0] = qs; o[1] = gs; o[2] = (double)gt; o[3] = gq; o[4] = (double)n; o[5] = (double)npos; o[6] = (double)nnonpos; o[7] = 0.0;
     }
 }
 

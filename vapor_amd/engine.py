@@ -71,10 +71,30 @@ class Plan:
         return self.stats[:self.n]
 
     def timings(self) -> dict:
-        ms = np.zeros(5, dtype=np.float64)
-        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 5))
+        ms = np.zeros(6, dtype=np.float64)
+        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 6))
         return {"join_ms": ms[0], "clean_ms": ms[1], "total_ms": ms[2], "join_launches": int(ms[3]),
-                "retried_pairs": int(ms[4])}
+                "retried_pairs": int(ms[4]), "finish_ms": ms[5]}
+
+    def set_reads(self, reads: np.ndarray, n_loci: int) -> None:
+        """Describe which pairs score which read of which locus (READ_DTYPE rows sorted by locus) so that
+        run_loci() can finish on the device."""
+        from . import finish
+        self.reads = np.ascontiguousarray(reads, dtype=L.READ_DTYPE)
+        self.n_loci = int(n_loci)
+        L.check(L.load().vapor_plan_set_reads(self._h, len(self.reads), self.reads.ctypes.data_as(ctypes.c_void_p),
+                                              self.n_loci, L.ptr(finish.gt_table(), ctypes.c_double)))
+        self.loci = np.zeros((max(self.n_loci, 1), L.LOCUS_STRIDE), dtype=np.float64)
+        self.read_scores = np.zeros(max(len(self.reads), 1), dtype=np.float64)
+
+    def run_loci(self, device_out: int = 0, want_host: bool = True, want_scores: bool = False):
+        """join -> clean -> finish on the device.  Returns the (n_loci, 8) float64 records
+        [QS, GS, GT index, GQ, n scored, n positive, n rounding to <= 0, 0] (NaN row = 'NA'); with
+        `device_out` (a device pointer, e.g. tensor.data_ptr()) they are also written there."""
+        L.check(L.load().vapor_plan_run_loci(self._h, ctypes.c_void_p(device_out) if device_out else None,
+                                             L.ptr(self.loci, ctypes.c_double) if want_host else None,
+                                             L.ptr(self.read_scores, ctypes.c_double) if want_scores else None))
+        return self.loci[:self.n_loci]
 
     def algorithmic(self) -> Tuple[int, int]:
         b = ctypes.c_int64()

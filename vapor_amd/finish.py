@@ -201,3 +201,21 @@ def locus_summary(scores: Sequence[float]):
 
 def gt_name(idx: int) -> str:
     return _GT_NAMES[idx]
+
+
+_GT_TABLE = None
+
+
+def gt_table() -> np.ndarray:
+    """(65, 65, 2) float64: genotype index and quality for k scored reads of which l round to <= 0,
+    for the device-side finish (include/vapor_hip.h, vapor_plan_set_reads)."""
+    global _GT_TABLE
+    if _GT_TABLE is None:
+        t = np.zeros((L.GT_TABLE_N, L.GT_TABLE_N, 2), dtype=np.float64)
+        for k in range(1, L.GT_TABLE_N):
+            for l in range(0, k + 1):
+                idx, gq = _gt_from_counts(k, l)
+                t[k, l, 0] = idx
+                t[k, l, 1] = gq
+        _GT_TABLE = t
+    return _GT_TABLE

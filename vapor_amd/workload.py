@@ -87,6 +87,19 @@ WORKLOADS = {
 }
 
 
+def read_table(w: Workload) -> np.ndarray:
+    """READ_DTYPE rows for Plan.set_reads: read r is scored by pairs 2r (ref) and 2r+1 (alt)."""
+    n = len(w.read_locus)
+    t = np.zeros(n, dtype=L.READ_DTYPE)
+    t["ref_a"] = t["ref_b"] = 2 * np.arange(n)
+    t["alt_a"] = t["alt_b"] = 2 * np.arange(n) + 1
+    t["kind"] = w.read_kind
+    t["locus"] = w.read_locus
+    t["len_ref"] = w.len_ref
+    t["len_alt"] = w.len_alt
+    return t
+
+
 def finish_workload(w: Workload, stats: np.ndarray) -> np.ndarray:
     """Per-locus records [QS, GS, GT index, GQ, n_scored] (float64; NaN row = 'NA') from the
     statistics of one pass (L1 -> L2 -> L3)."""
