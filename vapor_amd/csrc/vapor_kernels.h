@@ -704,18 +704,27 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
     if (tid == 0) sh->max_group = 0;
     __syncthreads();
-    // 1. occupancy bitmap (one atomic per run of equal values)
-    for (int base = 0; base < n; base += CLEAN_THREADS) {
-        const int h = base + tid;
-        bool act = h < n;
-        if (act && need_clear) act = !(hflags[h] & need_clear);
-        uint32_t v = INACTIVE_KEY;
-        if (act) {
-            uint32_t x = hits[h];
-            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            v = (uint32_t)(AXIS_A ? (i + j) : (i - j + vbias));
+    // 1. occupancy bitmap (one atomic per run of equal values); CU hits per thread and trip so that
+    // their LDS reads, shuffles and atomics overlap (the passes are latency-bound, not issue-bound)
+    constexpr int CU = 4;
+    for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+        uint32_t v[CU];
+#pragma unroll
+        for (int q = 0; q < CU; ++q) {
+            const int h = base + q * CLEAN_THREADS + tid;
+            bool act = h < n;
+            uint32_t x = 0, f = 0;
+            if (act) { x = hits[h]; if (need_clear) f = hflags[h]; }
+            if (need_clear && (f & need_clear)) act = false;
+            const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            v[q] = act ? (uint32_t)(AXIS_A ? (i + j) : (i - j + vbias)) : INACTIVE_KEY;
         }
-        if (run_head_len(v)) atomicOr(&bm[v >> 5], 1u << (v & 31));
+        int head[CU];
+#pragma unroll
+        for (int q = 0; q < CU; ++q) head[q] = run_head_len(v[q]);
+#pragma unroll
+        for (int q = 0; q < CU; ++q)
+            if (head[q]) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
     }
     __syncthreads();
     // 2. group starts and their ranks
@@ -740,19 +749,26 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) gcnt[g] = 0;
     __syncthreads();
     // 3. group sizes (one atomic per run of equal group ids)
-    for (int base = 0; base < n; base += CLEAN_THREADS) {
-        const int h = base + tid;
-        bool act = h < n;
-        if (act && need_clear) act = !(hflags[h] & need_clear);
-        uint32_t g = INACTIVE_KEY;
-        if (act) {
-            uint32_t x = hits[h];
-            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            int v = AXIS_A ? (i + j) : (i - j + vbias);
-            g = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+    for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+        uint32_t g[CU];
+#pragma unroll
+        for (int q = 0; q < CU; ++q) {
+            const int h = base + q * CLEAN_THREADS + tid;
+            bool act = h < n;
+            uint32_t x = 0, f = 0;
+            if (act) { x = hits[h]; if (need_clear) f = hflags[h]; }
+            if (need_clear && (f & need_clear)) act = false;
+            const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+            const int v = act ? (AXIS_A ? (i + j) : (i - j + vbias)) : 0;
+            const uint32_t gid = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+            g[q] = act ? gid : INACTIVE_KEY;
         }
-        int len = run_head_len(g);
-        if (len) atomicAdd(&gcnt[g], (uint32_t)len);
+        int len[CU];
+#pragma unroll
+        for (int q = 0; q < CU; ++q) len[q] = run_head_len(g[q]);
+#pragma unroll
+        for (int q = 0; q < CU; ++q)
+            if (len[q]) atomicAdd(&gcnt[g[q]], (uint32_t)len[q]);
     }
     __syncthreads();
     if (set_rule) {
@@ -764,17 +780,24 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     }
     const uint32_t mx = sh->max_group;
     // 4. flags
-    for (int h = tid; h < n; h += CLEAN_THREADS) {
-        uint32_t f = hflags[h];
-        if (need_clear && (f & need_clear)) continue;
-        uint32_t x = hits[h];
-        int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-        int v = AXIS_A ? (i + j) : (i - j + vbias);
-        uint32_t g = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
-        uint32_t c = gcnt[g];
-        if (set_gt10 && c > 10u) f |= set_gt10;
-        if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
-        hflags[h] = (uint8_t)f;
+    for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+#pragma unroll
+        for (int q = 0; q < CU; ++q) {
+            const int h = base + q * CLEAN_THREADS + tid;
+            if (h < n) {
+                uint32_t f = hflags[h];
+                if (!(need_clear && (f & need_clear))) {
+                    const uint32_t x = hits[h];
+                    const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+                    const int v = AXIS_A ? (i + j) : (i - j + vbias);
+                    const uint32_t gid = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+                    const uint32_t c = gcnt[gid];
+                    if (set_gt10 && c > 10u) f |= set_gt10;
+                    if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
+                    hflags[h] = (uint8_t)f;
+                }
+            }
+        }
     }
     __syncthreads();
 }

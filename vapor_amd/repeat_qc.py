@@ -35,7 +35,7 @@ def _bic(km, X) -> float:
     N, d = X.shape
     var = []
     for c in range(m):
-        ssq = sum(distance.cdist(X[np.where(labels == c)], [centers[c]], "euclidean") ** 2)
+        ssq = (distance.cdist(X[np.where(labels == c)], [centers[c]], "euclidean") ** 2).sum(axis=0)
         var.append((1.0 / (n[c] - m)) * ssq if n[c] - m != 0 else float(10 ** 20) * ssq)
     bad = []
     for c, v in enumerate(var):
@@ -60,8 +60,10 @@ def _split_once(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     rs = int(seed) if seed else None
     pts = np.array([[xs[t], ys[t]] for t in range(len(xs))])
     ks = list(range(1, min([5, len(xs) + 1])))
+    # the reference fits every k twice (SF:860-861: once for the BIC, once more only to test whether a
+    # cluster came out empty); one fit serves both here - the draws are unseeded either way
     fits = [cluster.KMeans(n_clusters=k, init="k-means++", random_state=rs).fit(pts) for k in ks]
-    preds = [cluster.KMeans(n_clusters=k, init="k-means++", random_state=rs).fit_predict(pts) for k in ks]
+    preds = [f.labels_ for f in fits]
     bic, bic_k = [], []
     for k in ks:
         if preds[k - 1].max() < k - 1:
