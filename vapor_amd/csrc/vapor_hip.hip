@@ -78,6 +78,7 @@ struct vapor_plan {
     long long* h_stats = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_f[2] = {nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr;
     double t_join = 0, t_clean = 0, t_total = 0;
     int n_retried = 0;
     bool ran = false;
@@ -100,8 +101,8 @@ extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 template <int BPS, int K>
 static hipError_t set_join_attr()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<BPS, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<BPS>());
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinBig, BPS, K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<JoinBig, BPS>());
 }
 
 extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
@@ -289,6 +290,7 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : p->ev_f)
         if (e) (void)hipEventDestroy(e);
+    if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     delete p;
     return VAPOR_OK;
 }
@@ -368,7 +370,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     });
     p->task_pairs = order;
     auto tiles_of = [&](int32_t seq2, int k, int bps) {
-        const int ta = bps == 2 ? tile_pos<2>() : tile_pos<4>();
+        const int ta = bps == 2 ? tile_pos<JoinBig, 2>() : tile_pos<JoinBig, 4>();
         return std::max(1, (set->h[seq2].len - k + 1 + ta - 1) / ta);
     };
     for (size_t q = 0; q < order.size();) {
@@ -419,6 +421,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     chk(hipHostMalloc((void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
+    chk(hipEventCreate(&p->ev_t0), "hipEventCreate");
     if (rc == VAPOR_OK && !p->tasks.empty())
         chk(hipMemcpyAsync(p->d_tasks, p->tasks.data(), sizeof(DTask) * p->tasks.size(), hipMemcpyHostToDevice, ctx->stream), "copy tasks");
     if (rc == VAPOR_OK && !order.empty())
@@ -435,7 +438,7 @@ template <int BPS, int K>
 static void launch_join(vapor_plan* p, const Launch& L)
 {
     const vapor_seqset* s = p->set;
-    hipLaunchKernelGGL((join_kernel<BPS, K>), dim3((unsigned)L.n_tasks), dim3(JOIN_THREADS), join_lds_bytes<BPS>(),
+    hipLaunchKernelGGL((join_kernel<JoinBig, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinBig::THREADS), (join_lds_bytes<JoinBig, BPS>()),
                        p->ctx->stream, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
                        p->d_task_pairs, p->d_hits, p->d_nhits);
 }
@@ -468,9 +471,10 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = c->stream;
-    HIPCHK(hipEventRecord(p->ev[0], st));
+    HIPCHK(hipEventRecord(p->ev_t0, st));
     HIPCHK(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), st));
     HIPCHK(hipMemsetAsync(p->d_overflow, 0, sizeof(unsigned int), st));
+    HIPCHK(hipEventRecord(p->ev[0], st));       // join time = first join launch .. last join end (no memsets)
     for (const Launch& L : p->launches) {
         if (L.bps == 2) {
             if (L.k == 10) launch_join<2, 10>(p, L);
@@ -508,7 +512,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
     float a = 0, b = 0, t = 0;
     HIPCHK(hipEventElapsedTime(&a, p->ev[0], p->ev[1]));
     HIPCHK(hipEventElapsedTime(&b, p->ev[1], p->ev[2]));
-    HIPCHK(hipEventElapsedTime(&t, p->ev[0], p->ev[3]));
+    HIPCHK(hipEventElapsedTime(&t, p->ev_t0, p->ev[3]));
     p->t_join = a; p->t_clean = b; p->t_total = t;
     return VAPOR_OK;
 }
@@ -823,7 +827,7 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     HIPCHK(hipEventElapsedTime(&f, e0, e1));
     p->t_finish = f;
     if (hipEventElapsedTime(&a, p->ev[0], p->ev[1]) == hipSuccess && hipEventElapsedTime(&b, p->ev[1], p->ev[2]) == hipSuccess &&
-        hipEventElapsedTime(&t, p->ev[0], e1) == hipSuccess) {
+        hipEventElapsedTime(&t, p->ev_t0, e1) == hipSuccess) {
         p->t_join = a; p->t_clean = b; p->t_total = t;
     }
     return VAPOR_OK;

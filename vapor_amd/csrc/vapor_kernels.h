@@ -46,7 +46,6 @@ struct DTask {         // 16 B
 #define VP_X4_WORDS_PER_CHUNK 4
 #define VP_PAD_CHUNKS 3  // zeroed chunks after each sequence: window reads may run this far
 
-constexpr int JOIN_THREADS = 1024;
 constexpr int MAX_READS_PER_TASK = 64;
 constexpr int CLEAN_THREADS = 512;
 constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
@@ -240,24 +239,25 @@ __device__ __forceinline__ bool any_exc(P plane, uint32_t pos)
 //
 // A task is a contiguous range of the batch's pairs sorted by allele (cost-balanced on the host);
 // the table is rebuilt only when the allele changes inside the range.
-constexpr int JNB_LOG2 = 15;
-constexpr int JNB = 1 << JNB_LOG2;
-constexpr int JOIN_WAVES = JOIN_THREADS / 64;
 constexpr int JCHUNK = 1024;                      // read positions per wave pass (16 per lane)
 
-template <int BPS> __host__ __device__ constexpr int tile_pos() { return BPS == 2 ? 31744 : 16384; }
-template <int BPS> __host__ __device__ constexpr int jqcap() { return 256; }   // per-wave candidate queue (items)
-template <int BPS> __host__ __device__ constexpr int tile_words() { return ((tile_pos<BPS>() + 64) * BPS) / 32 + 8; }
-template <int BPS> __host__ __device__ constexpr int etile_words() { return BPS == 2 ? (tile_pos<BPS>() + 64) / 32 + 8 : 0; }
+// Geometry of the join workgroup: it owns a whole CU's LDS (16 waves, one table of up to 31744 positions
+// in 32768 buckets).  Smaller tables would not raise residency: at ~117 VGPRs four waves per SIMD is the
+// register limit as well.
+struct JoinBig { static constexpr int THREADS = 1024, TA2 = 31744, TA4 = 16384, NB_LOG2 = 15, QCAP = 256; };
+
+template <typename C, int BPS> __host__ __device__ constexpr int tile_pos() { return BPS == 2 ? C::TA2 : C::TA4; }
+template <typename C, int BPS> __host__ __device__ constexpr int tile_words() { return ((tile_pos<C, BPS>() + 64) * BPS) / 32 + 8; }
+template <typename C, int BPS> __host__ __device__ constexpr int etile_words() { return BPS == 2 ? (tile_pos<C, BPS>() + 64) / 32 + 8 : 0; }
 template <int BPS> __host__ __device__ constexpr int rbuf_words() { return ((JCHUNK + 64) * BPS) / 32 + 4; }
 
-template <int BPS>
+template <typename C, int BPS>
 constexpr size_t join_lds_bytes()
 {
-    return sizeof(uint32_t) * (JNB / 2 + 2) + sizeof(uint32_t) * tile_words<BPS>() + sizeof(uint32_t) * etile_words<BPS>() +
-           sizeof(unsigned long long) * MAX_READS_PER_TASK + sizeof(uint32_t) * JOIN_WAVES * jqcap<BPS>() +
-           sizeof(uint32_t) * JOIN_WAVES * rbuf_words<BPS>() + sizeof(uint32_t) * (2 * JOIN_WAVES + 4) +
-           sizeof(uint16_t) * tile_pos<BPS>();
+    return sizeof(uint32_t) * ((1 << C::NB_LOG2) / 2 + 2) + sizeof(uint32_t) * tile_words<C, BPS>() +
+           sizeof(uint32_t) * etile_words<C, BPS>() + sizeof(unsigned long long) * MAX_READS_PER_TASK +
+           sizeof(uint32_t) * (C::THREADS / 64) * C::QCAP + sizeof(uint32_t) * (C::THREADS / 64) * rbuf_words<BPS>() +
+           sizeof(uint32_t) * (2 * (C::THREADS / 64) + 4 + MAX_READS_PER_TASK + 2) + sizeof(uint16_t) * tile_pos<C, BPS>();
 }
 
 template <int BPS, int K>
@@ -272,7 +272,7 @@ __device__ __forceinline__ bool key_less(const KeyT<BPS, K>& a, const KeyT<BPS, 
     return lt;
 }
 
-template <int BPS, int K>
+template <int NBL, int BPS, int K>
 __device__ __forceinline__ uint32_t canon_bucket(const KeyT<BPS, K>& k, const KeyT<BPS, K>& rc)
 {
     using KT = KeyT<BPS, K>;
@@ -283,7 +283,7 @@ __device__ __forceinline__ uint32_t canon_bucket(const KeyT<BPS, K>& k, const Ke
     if (KT::NW > 3) x ^= (use_rc ? rc.w[3] : k.w[3]) * 0x27D4EB2Fu;
     if (KT::NW > 4) x ^= (use_rc ? rc.w[4] : k.w[4]) * 0x165667B1u;
     if (KT::NW > 1) { x ^= x >> 15; x *= 0x2C1B3C6Du; }
-    return x >> (32 - JNB_LOG2);
+    return x >> (32 - NBL);
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
@@ -363,24 +363,27 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
     }
 }
 
-template <int BPS, int K>
-__global__ __launch_bounds__(JOIN_THREADS) void join_kernel(
+template <typename C, int BPS, int K>
+__global__ __launch_bounds__(C::THREADS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
     const int32_t* __restrict__ task_pairs, uint32_t* __restrict__ hits, unsigned long long* __restrict__ n_hits)
 {
     using KT = KeyT<BPS, K>;
-    constexpr int TA = tile_pos<BPS>();
-    constexpr int JQCAP = jqcap<BPS>();
+    constexpr int TA = tile_pos<C, BPS>();
+    constexpr int JQCAP = C::QCAP;
+    constexpr int JOIN_THREADS = C::THREADS, JOIN_WAVES = C::THREADS / 64;
+    constexpr int JNB_LOG2 = C::NB_LOG2, JNB = 1 << C::NB_LOG2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* start32 = lds;                                                  // JNB/2 + 2 words: u16 pairs
     uint32_t* tile = start32 + (JNB / 2 + 2);
-    uint32_t* etile = tile + tile_words<BPS>();
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + etile_words<BPS>());
+    uint32_t* etile = tile + tile_words<C, BPS>();
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + etile_words<C, BPS>());
     uint32_t* queue = reinterpret_cast<uint32_t*>(cnt + MAX_READS_PER_TASK);   // JOIN_WAVES * JQCAP
     uint32_t* rbufs = queue + JOIN_WAVES * JQCAP;                              // JOIN_WAVES * rbuf_words
     uint32_t* wtot = rbufs + JOIN_WAVES * rbuf_words<BPS>();                   // 2 * JOIN_WAVES + 4
-    uint16_t* entries = reinterpret_cast<uint16_t*>(wtot + 2 * JOIN_WAVES + 4);  // TA
+    int* cstart = reinterpret_cast<int*>(wtot + 2 * JOIN_WAVES + 4);              // MAX_READS_PER_TASK + 2: strip prefix of the group's reads
+    uint16_t* entries = reinterpret_cast<uint16_t*>(cstart + MAX_READS_PER_TASK + 2);  // TA
     const uint16_t* start16 = reinterpret_cast<const uint16_t*>(start32);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_kernel(
                 else ok = !key_has_invalid<BPS, K>(key);
                 if (ok) {
                     KT rc = revcomp_key<BPS, K>(key);
-                    const uint32_t h = canon_bucket<BPS, K>(key, rc);
+                    const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(key, rc);
                     atomicAdd(&start32[h >> 1], 1u << ((h & 1u) * 16));
                 }
             }
@@ -463,26 +466,41 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_kernel(
                 else ok = !key_has_invalid<BPS, K>(key);
                 if (ok) {
                     KT rc = revcomp_key<BPS, K>(key);
-                    const uint32_t h = canon_bucket<BPS, K>(key, rc);
+                    const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(key, rc);
                     const uint32_t sh = (h & 1u) * 16;
                     uint32_t old = atomicSub(&start32[h >> 1], 1u << sh);
                     entries[((old >> sh) & 0xFFFFu) - 1u] = (uint16_t)p;
                 }
             }
             __syncthreads();
-            // ---- probe: every read of the group ----------------------------------------------
-            for (int r = g0; r < g1; ++r) {
-                const DPair pr = pairs[task_pairs[task.first + r]];
-                const SeqDesc s1 = seqs[pr.seq1];
-                const int nk1 = s1.len - K + 1;
-                const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
-                const uint32_t* re = e1 + (size_t)s1.chunk0;
-                const bool exc1 = (BPS == 2) && s1.n_exc > 0;
-                uint32_t* out = hits + pr.hit_off;
+            // ---- probe: every read of the group.  The 1024-position strips of ALL reads of the group are
+            // dealt round-robin to the waves (a 10 kb read alone has only 10 strips for 16 waves).
+            if (tid == 0) {
+                int acc = 0;
+                for (int r = g0; r < g1; ++r) {
+                    cstart[r - g0] = acc;
+                    const int nk = seqs[pairs[task_pairs[task.first + r]].seq1].len - K + 1;
+                    acc += nk > 0 ? (nk + JCHUNK - 1) / JCHUNK : 0;
+                }
+                cstart[g1 - g0] = acc;
+            }
+            __syncthreads();
+            const int total_strips = cstart[g1 - g0];
+            {
                 constexpr int NWIN = ((15 + K) * BPS + 31) / 32;
                 constexpr int WPL = BPS / 2;                      // plane words per 16 positions
                 constexpr uint32_t SYM = (1u << BPS) - 1u;
-                for (int cb = wave * JCHUNK; cb < nk1; cb += JOIN_WAVES * JCHUNK) {
+                int r = g0;                                        // strips are visited in increasing order
+                for (int si = wave; si < total_strips; si += JOIN_WAVES) {
+                    while (si >= cstart[r - g0 + 1]) ++r;
+                    const int cb = (si - cstart[r - g0]) * JCHUNK;
+                    const DPair pr = pairs[task_pairs[task.first + r]];
+                    const SeqDesc s1 = seqs[pr.seq1];
+                    const int nk1 = s1.len - K + 1;
+                    const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
+                    const uint32_t* re = e1 + (size_t)s1.chunk0;
+                    const bool exc1 = (BPS == 2) && s1.n_exc > 0;
+                    uint32_t* out = hits + pr.hit_off;
                     // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
                     {
                         const int nw = min(rbuf_words<BPS>(), (int)((((size_t)(nk1 + K - 1 - cb)) * BPS + 31) >> 5) + 2);
@@ -536,7 +554,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void join_kernel(
                                 constexpr unsigned long long KM = (1ULL << K) - 1ULL;
                                 valid = valid && (((EE >> t) & KM) == 0ULL);
                             }
-                            const uint32_t h = canon_bucket<BPS, K>(kf, kr);
+                            const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(kf, kr);
                             const uint32_t s0 = start16[h], s1v = start16[h + 1];
                             sc[t4] = valid ? (s0 | ((s1v - s0) << 16)) : 0u;
                         }
