@@ -445,26 +445,32 @@ static void launch_join(vapor_plan* p, const Launch& L)
 
 static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 / 10 + 8; }
 
-// hits of a pair are cleaned out of LDS when they fit next to the clustering arrays.  The kernel is
-// latency-bound, so residency matters: take the largest number of workgroups per CU (4, 3, 2, 1) whose
-// share of the 160 KB still stages at least ~90 % of the expected hit count.
+// clean_kernel's LDS: bitmap + 16-bit ranks + group sizes (+ staged hits).  Pairs cleaned out of LDS use
+// 16-bit group counters; pairs that stream their hits need 32-bit ones, which must fit as well.
+static size_t clean_fixed_bytes(int rw, bool wide)
+{
+    const size_t g = (size_t)clean_groups_cap(rw);
+    return sizeof(uint32_t) * ((size_t)rw + ((size_t)rw + 1) / 2 + (wide ? g : (g + 1) / 2)) + 64;
+}
+
+// The kernel is latency-bound, so residency matters: take the largest number of workgroups per CU
+// (4, 3, 2, 1) whose share of the 160 KB still stages at least ~90 % of the expected hit count.
 static int clean_hcap(int range_words_cap, int want)
 {
-    const size_t fixed = sizeof(uint32_t) * ((size_t)range_words_cap * 3 + (size_t)clean_groups_cap(range_words_cap)) + 1024;
+    const size_t fixed = clean_fixed_bytes(range_words_cap, false) + 512;
     int best = 0;
     for (int per_cu = 4; per_cu >= 1; --per_cu) {
         const size_t share = (size_t)(160 * 1024) / per_cu - 512;
         if (share <= fixed) continue;
-        const int cap = (int)std::min<size_t>((share - fixed) / 5, (size_t)want) & ~3;
+        const int cap = (int)std::min<size_t>(std::min<size_t>((share - fixed) / 5, (size_t)want), 65532) & ~3;
         if (cap >= want * 9 / 10 || per_cu == 1) { best = cap; break; }
-        if (cap > best && per_cu == 1) best = cap;
     }
     return std::max(best, 0);
 }
 
 static size_t clean_lds_bytes(int range_words_cap, int hcap)
 {
-    return sizeof(uint32_t) * ((size_t)range_words_cap * 3 + (size_t)clean_groups_cap(range_words_cap)) + (size_t)hcap * 5;
+    return std::max(clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 5, clean_fixed_bytes(range_words_cap, true));
 }
 
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true)

@@ -713,12 +713,17 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanSh
 // of the group's start.  Afterwards, for every selected hit, set_gt10 is OR-ed into its flag byte
 // when its group has more than 10 members, and set_rule when the group passes dis_cluster's rule
 // (more than 50 members, or maximal size when no group has more than 50).
-template <bool AXIS_A, typename HP, typename FP>
+// NARROW (hits staged in LDS, so n < 65536): group sizes are 16-bit counters, two per LDS word.
+template <bool AXIS_A, bool NARROW, typename HP, typename FP>
 __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
-                                             uint32_t* sb, uint32_t* wrank, uint32_t* gcnt, CleanShared* sh,
+                                             uint16_t* wrank, uint32_t* gcnt, CleanShared* sh,
                                              uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule)
 {
     const int tid = threadIdx.x;
+    uint32_t* sb = bm;                               // the start bits replace the occupancy bits in place
+    auto gsize = [&](uint32_t g) -> uint32_t {
+        return NARROW ? ((gcnt[g >> 1] >> ((g & 1u) * 16)) & 0xFFFFu) : gcnt[g];
+    };
     for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
     if (tid == 0) sh->max_group = 0;
     __syncthreads();
@@ -749,22 +754,34 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
     const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
     uint32_t local = 0;
-    for (int w = w0; w < w1; ++w) {
-        uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
-        unsigned long long y = ((unsigned long long)cur << 32) | prev;
-        unsigned long long sm = (y << 1) | (y << 2) | (y << 3) | (y << 4) | (y << 5) | (y << 6) | (y << 7) |
-                                (y << 8) | (y << 9);
-        uint32_t st = cur & ~(uint32_t)(sm >> 32);
-        sb[w] = st;
+    constexpr int PER_MAX = 8;                       // range_words_cap <= 4096, CLEAN_THREADS = 512
+    uint32_t stv[PER_MAX];
+#pragma unroll
+    for (int q = 0; q < PER_MAX; ++q) {
+        const int w = w0 + q;
+        uint32_t st = 0;
+        if (w < w1) {
+            uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
+            unsigned long long y = ((unsigned long long)cur << 32) | prev;
+            unsigned long long sm = (y << 1) | (y << 2) | (y << 3) | (y << 4) | (y << 5) | (y << 6) | (y << 7) |
+                                    (y << 8) | (y << 9);
+            st = cur & ~(uint32_t)(sm >> 32);
+        }
+        stv[q] = st;
         local += __popc(st);
     }
     uint32_t ng;
-    uint32_t run = block_exclusive_scan(local, sh, &ng);
-    for (int w = w0; w < w1; ++w) {
-        wrank[w] = run;
-        run += __popc(sb[w]);
+    uint32_t run = block_exclusive_scan(local, sh, &ng);      // (its barrier also ends all reads of bm)
+#pragma unroll
+    for (int q = 0; q < PER_MAX; ++q) {
+        const int w = w0 + q;
+        if (w < w1) {
+            sb[w] = stv[q];
+            wrank[w] = (uint16_t)run;
+            run += __popc(stv[q]);
+        }
     }
-    for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) gcnt[g] = 0;
+    for (uint32_t g = tid; g < (NARROW ? (ng + 1) / 2 : ng); g += CLEAN_THREADS) gcnt[g] = 0;
     __syncthreads();
     // 3. group sizes (one atomic per run of equal group ids)
     for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
@@ -778,7 +795,7 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
             if (need_clear && (f & need_clear)) act = false;
             const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
             const int v = act ? (AXIS_A ? (i + j) : (i - j + vbias)) : 0;
-            const uint32_t gid = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+            const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
             g[q] = act ? gid : INACTIVE_KEY;
         }
         int len[CU];
@@ -786,12 +803,15 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
         for (int q = 0; q < CU; ++q) len[q] = run_head_len(g[q]);
 #pragma unroll
         for (int q = 0; q < CU; ++q)
-            if (len[q]) atomicAdd(&gcnt[g[q]], (uint32_t)len[q]);
+            if (len[q]) {
+                if (NARROW) atomicAdd(&gcnt[g[q] >> 1], (uint32_t)len[q] << ((g[q] & 1u) * 16));
+                else atomicAdd(&gcnt[g[q]], (uint32_t)len[q]);
+            }
     }
     __syncthreads();
     if (set_rule) {
         uint32_t m = 0;
-        for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) m = max(m, gcnt[g]);
+        for (uint32_t g = tid; g < ng; g += CLEAN_THREADS) m = max(m, gsize(g));
         m = (uint32_t)wave_max_i32((int)m);
         if ((tid & 63) == 0) atomicMax(&sh->max_group, m);
         __syncthreads();
@@ -808,8 +828,8 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
                     const uint32_t x = hits[h];
                     const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
                     const int v = AXIS_A ? (i + j) : (i - j + vbias);
-                    const uint32_t gid = wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
-                    const uint32_t c = gcnt[gid];
+                    const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+                    const uint32_t c = gsize(gid);
                     if (set_gt10 && c > 10u) f |= set_gt10;
                     if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
                     hflags[h] = (uint8_t)f;
@@ -961,20 +981,19 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
 }
 
 // everything after the hits are in place (LDS copy or global), for one pair
-template <typename HP, typename FP>
+template <bool NARROW, typename HP, typename FP>
 __device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPair& pr, int len2, int range_words,
-                                           uint32_t* bm, uint32_t* sb, uint32_t* wrank, uint32_t* gcnt,
-                                           CleanShared* sh, long long* st)
+                                           uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, CleanShared* sh, long long* st)
 {
     const int tid = threadIdx.x;
     const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u, s3 = (pr.flags & 4u) && c1;
     if (c1 || c2)   // i - j over all dots: C1's diagonal groups (>10) and C2's diagonal step
-        cluster_axis<false>(hits, hflags, n, len2, range_words, bm, sb, wrank, gcnt, sh, 0u, c1 ? WF_D1 : 0u,
+        cluster_axis<false, NARROW>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, c1 ? WF_D1 : 0u,
                             c2 ? HF_C2D : 0u);
     if (c1)         // i + j over all dots: C1's anti-diagonal groups
-        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, sh, 0u, WF_A1, 0u);
+        cluster_axis<true, NARROW>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u);
     if (c2)         // i + j over the dots the diagonal step left: C2's anti-diagonal step
-        cluster_axis<true>(hits, hflags, n, 0, range_words, bm, sb, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
+        cluster_axis<true, NARROW>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
     // final pass: reductions and public flags
     {
         int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
@@ -1008,10 +1027,11 @@ __device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPai
     }
 }
 
-// One workgroup per pair.  Dynamic LDS: bm | sb | wrank (range_words_cap words each) | gcnt
-// (groups_cap words) | hit copy (hcap words) | flag bytes (hcap).  Pairs with at most hcap hits
-// are cleaned entirely out of LDS; larger ones stream their hits from L2/HBM on every pass.
-__global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
+// One workgroup per pair.  Dynamic LDS: bitmap (range_words_cap words) | wrank (u16 each) | group sizes
+// | hit copy (hcap words) | flag bytes (hcap).  Pairs with at most hcap hits are cleaned entirely out of
+// LDS with 16-bit group counters (groups_cap / 2 words); larger ones stream their hits from L2/HBM on
+// every pass and use 32-bit counters (the region then extends over the unused hit copy).
+__global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const SeqDesc* __restrict__ seqs, const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
     uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
@@ -1041,10 +1061,9 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
     const int len1 = seqs[pr.seq1].len, len2 = seqs[pr.seq2].len;
     const int range_words = min((len1 + len2 + 2 + 31) >> 5, range_words_cap);
     uint32_t* bm = lds;
-    uint32_t* sb = bm + range_words_cap;
-    uint32_t* wrank = sb + range_words_cap;
-    uint32_t* gcnt = wrank + range_words_cap;
-    uint32_t* lhits = gcnt + groups_cap;
+    uint16_t* wrank = reinterpret_cast<uint16_t*>(bm + range_words_cap);
+    uint32_t* gcnt = bm + range_words_cap + (range_words_cap + 1) / 2;
+    uint32_t* lhits = gcnt + (groups_cap + 1) / 2;
     uint8_t* lflags = reinterpret_cast<uint8_t*>(lhits + hcap);
     const bool in_lds = n <= hcap;
 
@@ -1073,11 +1092,11 @@ __global__ __launch_bounds__(CLEAN_THREADS) void clean_kernel(
     }
     __syncthreads();
     if (in_lds) {
-        clean_body((const uint32_t*)lhits, lflags, n, pr, len2, range_words, bm, sb, wrank, gcnt, &sh, st);
+        clean_body<true>((const uint32_t*)lhits, lflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st);
         __syncthreads();
         for (int h = tid; h < n; h += CLEAN_THREADS) gflags[h] = lflags[h];
     } else {
-        clean_body(ghits, gflags, n, pr, len2, range_words, bm, sb, wrank, gcnt, &sh, st);
+        clean_body<false>(ghits, gflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st);
     }
 }
 
