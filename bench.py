@@ -123,6 +123,16 @@ def main() -> None:
     dom_ms = max(join_avg, clean_avg)
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
 
+    # HBM-side bytes of the dominant kernel per launch, from the committed PMC passes of this same workload
+    # (the byte counts depend on the batch only, not on the run)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = int(json.load(open(tpath))[dom]["bytes"])
+        except Exception:
+            traffic = None
+
     cpu = None
     if rank == 0 and not args.no_cpu:
         from oracle import oracle as orc
@@ -174,7 +184,7 @@ def main() -> None:
                           "device_total": round(dev_ms / steps, 4), "join_launches": launches},
             "upload_pack_s": round(upload_s, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
             "cpu_baseline": cpu,
         }
