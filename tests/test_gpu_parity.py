@@ -259,3 +259,24 @@ def test_device_finish_matches_host_finish(eng, name):
             pos = [float(x) for x in v if x > 0]
             assert dev[li, 0] == (np.mean(pos) if pos else 0.0)
     plan.close()
+
+
+def test_exception_paths_at_bench_shapes(eng, oracle):
+    """Reads with N runs against a clean 20 kb allele (2-bit path, read k-mers masked through the
+    exception plane) and against a soft-masked / N-holding allele (4-bit path, two 16 k tiles)."""
+    from vapor_amd import synth
+    rng = np.random.default_rng(21)
+    a = synth.random_dna(rng, 20000)
+    am = a[:3000] + a[3000:9000].lower() + a[9000:12000] + "N" * 60 + a[12060:17000] + a[17000:].lower()
+    r, _ = synth.mutate(rng, a[2000:13000], 0.004, 0.02, 0.01)
+    r = r[:10000]
+    rn = r[:2000] + "N" * 25 + r[2025:6000] + "n" * 9 + r[6009:]
+    rl = r[:4000] + r[4000:7000].lower() + r[7000:]
+    seqs = [a, am, r, rn, rl]
+    rows = []
+    for rd in (2, 3, 4):
+        for al in (0, 1):
+            for k in (10, 20):
+                rows.append((rd, al, 3 * rd, k, 7))
+    rows += [(1, 1, 0, 10, 7), (1, 1, 0, 30, 7)]
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "exc_bench")
