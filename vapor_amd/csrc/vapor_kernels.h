@@ -714,7 +714,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanSh
 // when its group has more than 10 members, and set_rule when the group passes dis_cluster's rule
 // (more than 50 members, or maximal size when no group has more than 50).
 // NARROW (hits staged in LDS, so n < 65536): group sizes are 16-bit counters, two per LDS word.
-template <bool AXIS_A, bool NARROW, typename HP, typename FP>
+// HAVE_BM: the caller has already filled the occupancy bitmap (fused with the staging pass).
+// FINAL: this is the last clustering step of the pair; its flag pass also does the reductions over the
+// finished flags (kept counts, sum |j-i|, count10, range of i-j over the C1-kept dots) and leaves the
+// public VAPOR_HF_* bits in the flag bytes.
+template <bool AXIS_A, bool NARROW, bool HAVE_BM, bool FINAL, typename HP, typename FP>
 __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
                                              uint16_t* wrank, uint32_t* gcnt, CleanShared* sh,
                                              uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule)
@@ -724,12 +728,13 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     auto gsize = [&](uint32_t g) -> uint32_t {
         return NARROW ? ((gcnt[g >> 1] >> ((g & 1u) * 16)) & 0xFFFFu) : gcnt[g];
     };
-    for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
+    constexpr int CU = 4;
     if (tid == 0) sh->max_group = 0;
+    if (!HAVE_BM) {
+    for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
     __syncthreads();
     // 1. occupancy bitmap (one atomic per run of equal values); CU hits per thread and trip so that
     // their LDS reads, shuffles and atomics overlap (the passes are latency-bound, not issue-bound)
-    constexpr int CU = 4;
     for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
         uint32_t v[CU];
 #pragma unroll
@@ -748,6 +753,7 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
 #pragma unroll
         for (int q = 0; q < CU; ++q)
             if (head[q]) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
+    }
     }
     __syncthreads();
     // 2. group starts and their ranks
@@ -817,24 +823,46 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
         __syncthreads();
     }
     const uint32_t mx = sh->max_group;
-    // 4. flags
+    // 4. flags (and, for the last step of a pair, the reductions over the finished flags)
+    int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
+    long long sabs = 0;
     for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
 #pragma unroll
         for (int q = 0; q < CU; ++q) {
             const int h = base + q * CLEAN_THREADS + tid;
             if (h < n) {
                 uint32_t f = hflags[h];
-                if (!(need_clear && (f & need_clear))) {
+                const bool sel = !(need_clear && (f & need_clear));
+                if (sel || FINAL) {
                     const uint32_t x = hits[h];
                     const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-                    const int v = AXIS_A ? (i + j) : (i - j + vbias);
-                    const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
-                    const uint32_t c = gsize(gid);
-                    if (set_gt10 && c > 10u) f |= set_gt10;
-                    if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
+                    if (sel) {
+                        const int v = AXIS_A ? (i + j) : (i - j + vbias);
+                        const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+                        const uint32_t c = gsize(gid);
+                        if (set_gt10 && c > 10u) f |= set_gt10;
+                        if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
+                    }
+                    if (FINAL) {
+                        const int ad = j > i ? j - i : i - j;
+                        uint32_t pub = f & (HF_C2D | HF_C2A);
+                        if (f & (WF_D1 | WF_A1)) { pub |= HF_C1; ++k1; sabs += ad; dlo = min(dlo, i - j); dhi = max(dhi, i - j); }
+                        if (f & (HF_C2D | HF_C2A)) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
+                        kd += (f & HF_C2D) ? 1 : 0;
+                        f = pub;
+                    }
                     hflags[h] = (uint8_t)f;
                 }
             }
+        }
+    }
+    if (FINAL) {
+        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
+        sabs = wave_sum_i64(sabs); dlo = wave_min_i32(dlo); dhi = wave_max_i32(dhi);
+        if ((tid & 63) == 0) {
+            atomicAdd(&sh->c1_kept, k1); atomicAdd(&sh->c2_kept, k2); atomicAdd(&sh->c2_count10, c10);
+            atomicAdd(&sh->c2_kept_diag, kd); atomicAdd(&sh->c1_sum_abs, (unsigned long long)sabs);
+            atomicMin(&sh->kd_lo, dlo); atomicMax(&sh->kd_hi, dhi);
         }
     }
     __syncthreads();
@@ -987,37 +1015,19 @@ __device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPai
 {
     const int tid = threadIdx.x;
     const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u, s3 = (pr.flags & 4u) && c1;
-    if (c1 || c2)   // i - j over all dots: C1's diagonal groups (>10) and C2's diagonal step
-        cluster_axis<false, NARROW>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, c1 ? WF_D1 : 0u,
-                            c2 ? HF_C2D : 0u);
-    if (c1)         // i + j over all dots: C1's anti-diagonal groups
-        cluster_axis<true, NARROW>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u);
-    if (c2)         // i + j over the dots the diagonal step left: C2's anti-diagonal step
-        cluster_axis<true, NARROW>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
-    // final pass: reductions and public flags
-    {
-        int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
-        long long sabs = 0;
-        for (int h = tid; h < n; h += CLEAN_THREADS) {
-            uint32_t f = hflags[h];
-            uint32_t x = hits[h];
-            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            int ad = j > i ? j - i : i - j;
-            uint32_t pub = f & (HF_C2D | HF_C2A);
-            if (f & (WF_D1 | WF_A1)) { pub |= HF_C1; ++k1; sabs += ad; dlo = min(dlo, i - j); dhi = max(dhi, i - j); }
-            if (f & (HF_C2D | HF_C2A)) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
-            kd += (f & HF_C2D) ? 1 : 0;
-            hflags[h] = (uint8_t)pub;
-        }
-        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
-        sabs = wave_sum_i64(sabs); dlo = wave_min_i32(dlo); dhi = wave_max_i32(dhi);
-        if ((tid & 63) == 0) {
-            atomicAdd(&sh->c1_kept, k1); atomicAdd(&sh->c2_kept, k2); atomicAdd(&sh->c2_count10, c10);
-            atomicAdd(&sh->c2_kept_diag, kd); atomicAdd(&sh->c1_sum_abs, (unsigned long long)sabs);
-            atomicMin(&sh->kd_lo, dlo); atomicMax(&sh->kd_hi, dhi);
-        }
+    // i - j over all dots (its bitmap was filled while the hits were staged): C1's diagonal groups (>10)
+    // and C2's diagonal step; then i + j over all dots (C1) and / or over the dots the diagonal step left (C2)
+    if (c1 && c2) {
+        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D);
+        cluster_axis<true, NARROW, false, false>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u);
+        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
+    } else if (c1) {
+        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u);
+        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u);
+    } else if (c2) {
+        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D);
+        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
     }
-    __syncthreads();
     if (s3) directed_stats(hits, hflags, n, gcnt, sh);
     if (tid == 0) {
         st[0] = n; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
@@ -1073,16 +1083,26 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
         sh.kd_lo = 0x7FFFFFFF; sh.kd_hi = -0x7FFFFFFF;
     }
     __syncthreads();
-    // pass 0: first/last j, diagonal and lower-triangle counts; stage the hits, clear the flags
+    // pass 0: first/last j, diagonal and lower-triangle counts; stage the hits, clear the flags, and fill
+    // the occupancy bitmap of i - j for the first clustering step
+    const bool any_axis = (pr.flags & 3u) != 0u;
+    for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
+    __syncthreads();
     {
         int mn = 0x7FFFFFFF, mx = -1, nd = 0, nl = 0;
-        for (int h = tid; h < n; h += CLEAN_THREADS) {
-            uint32_t x = ghits[h];
-            int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            mn = min(mn, j); mx = max(mx, j);
-            nd += (j == i); nl += (j > i);
-            if (in_lds) { lhits[h] = x; lflags[h] = 0; }
-            else gflags[h] = 0;
+        for (int base = 0; base < n; base += CLEAN_THREADS) {
+            const int h = base + tid;
+            uint32_t v = INACTIVE_KEY;
+            if (h < n) {
+                uint32_t x = ghits[h];
+                int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
+                mn = min(mn, j); mx = max(mx, j);
+                nd += (j == i); nl += (j > i);
+                if (in_lds) { lhits[h] = x; lflags[h] = 0; }
+                else gflags[h] = 0;
+                if (any_axis) v = (uint32_t)(i - j + len2);
+            }
+            if (run_head_len(v)) atomicOr(&bm[v >> 5], 1u << (v & 31));
         }
         mn = wave_min_i32(mn); mx = wave_max_i32(mx); nd = wave_sum_i32(nd); nl = wave_sum_i32(nl);
         if ((tid & 63) == 0) {
