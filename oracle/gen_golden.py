@@ -684,10 +684,27 @@ def _letters(al):
     return out
 
 
+def gen_config1(m):
+    """BASELINE.json configs[0]: the loci of the reference's own vapor_test/vapor_test.bed (coordinates and
+    types are fixture data) on a stand-in genome, through the reference's `vapor bed` loop."""
+    cli = load_cli(m)
+    m.make_event_figure_1 = lambda *a, **k: None
+    rows = [l.split() for l in open("/root/reference/vapor_test/vapor_test.bed") if l.strip()]
+    w = synth.make_world_from_bed(rows, seed=10)
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_cfg1_")
+    m.os = ShimOS(w)
+    per_locus, text = run_bed(m, cli, w, tmp)
+    m.os = os
+    print("  config1: %s" % [len(p["scores"].get("ok", [])) if "ok" in p["scores"] else p["scores"] for p in per_locus])
+    dump("config1_bed.json.gz", {"source": "vapor_test/vapor_test.bed rows (chr start end TYPE) + vapor bed loop vapor_vali/vapor:322-367",
+                                 "bed_rows": rows, "seed": 10, "bed": synth.bed_text(w),
+                                 "cases": [{"name": "vapor_test_bed", "per_locus": per_locus, "vapor_text": text}]})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)

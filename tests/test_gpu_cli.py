@@ -87,3 +87,19 @@ def test_vcf_cli_gpu(name, tmp_path):
         assert (tmp_path / "in.vcf.vapor").read_text() == case["final"]
     finally:
         seqio.set_backend(None)
+
+
+def test_config1_vapor_test_bed_gpu(tmp_path):
+    from vapor_amd import cli, pipeline, seqio, synth
+    cfg = load_golden("config1_bed.json.gz")
+    pipeline.set_engine(None)
+    seqio.set_backend(seqio.MemorySamtools(synth.make_world_from_bed(cfg["bed_rows"], seed=cfg["seed"])))
+    try:
+        bed = tmp_path / "vapor_test.bed"
+        bed.write_text(cfg["bed"])
+        out = tmp_path / "vapor_test.bed.vapor"
+        assert cli.main(["bed", "--sv-input", str(bed), "--reference", "hg19.fa", "--pacbio-input", "x.bam",
+                         "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+        assert out.read_text() == cfg["cases"][0]["vapor_text"]
+    finally:
+        seqio.set_backend(None)

@@ -235,3 +235,20 @@ def test_svelter_mode_rows(fake, tmp_path):
     for line, c in zip(lines, OTHER["cases"][:4]):
         exp = SF.format_output_row(finish.result_organize_ins(["." + "_".join(c["sv_info"][2:]), c["scores"]["ok"]]))
         assert line == exp
+
+
+CFG1 = load_golden("config1_bed.json.gz")
+
+
+def test_config1_vapor_test_bed_plumbing(fake, tmp_path):
+    """BASELINE.json configs[0]: the 19 loci of the reference's vapor_test.bed (re-expressed as the 5-column
+    BED today's parser wants) on a stand-in genome: `vapor bed` writes the table the reference writes."""
+    world = synth.make_world_from_bed(CFG1["bed_rows"], seed=CFG1["seed"])
+    assert synth.bed_text(world) == CFG1["bed"]
+    seqio.set_backend(seqio.MemorySamtools(world))
+    bed = tmp_path / "vapor_test.bed"
+    bed.write_text(CFG1["bed"])
+    out = tmp_path / "vapor_test.bed.vapor"
+    assert cli.main(["bed", "--sv-input", str(bed), "--reference", "hg19.fa", "--pacbio-input", "x.bam",
+                     "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+    assert out.read_text() == CFG1["cases"][0]["vapor_text"]

@@ -1,14 +1,18 @@
 // vapor_kernels.h - device code of libvapor_hip.so (gfx950 / CDNA4 only).
 //
-// Three kernels, all integer/bit work (no MFMA: there is no dense contraction on this path):
+// Four kernels; the first three are integer/bit work (no MFMA: there is no dense contraction on this
+// path), the last is a few float64 operations per read:
 //
-//   pack_kernel   ASCII -> bit planes in HBM (2-bit bases, 1-bit "not ACGT", 4-bit symbols)
-//   join_kernel   kmerhits (SF:951-983) as an LDS hash join.  One workgroup owns one allele
-//                 window: it builds a chained hash table of the window's k-mers in LDS once
-//                 and streams up to `reads_per_task` reads through it, each lane owning one
-//                 read position and probing with the k-mer and its reverse complement.
-//   clean_kernel  dis_cluster / dis_cluster_2 (SF:551-580) as occupancy bitmaps + ranked group
-//                 counters in LDS, then the integer reductions of SF:705-733 and SF:1154-1171.
+//   pack_kernel    ASCII -> bit planes in HBM (2-bit bases, 1-bit "not ACGT", 4-bit symbols)
+//   join_kernel    kmerhits (SF:951-983) as an LDS hash join on canonical k-mers.  One workgroup
+//                  owns a cost-balanced range of the (read, allele) pairs sorted by allele: it
+//                  builds a bucket-sorted table of the allele window's k-mers in LDS and streams
+//                  the reads of that allele through it (details above the kernel).
+//   clean_kernel   dis_cluster / dis_cluster_2 (SF:551-580) as occupancy bitmaps + ranked group
+//                  counters in LDS, the integer reductions of SF:705-733 and SF:1154-1171, and
+//                  dis_to_diagnal_most_abundant_defined (SF:582-591) in exact integer arithmetic.
+//   finish_kernel  scorer gates, per-read scores, VaPoR_QS / GS / GT / GQ per locus (SF:182-294,
+//                  1219-1231, 2054-2077) in float64.
 //
 // SF = /root/reference/vapor_vali/Simple_function.pyx.
 #pragma once
@@ -36,7 +40,7 @@ struct DPair {         // 32 B
     int64_t hit_off;
 };
 
-struct DTask {         // 16 B
+struct DTask {         // 16 B: pairs task_pairs[first .. first + n_reads) of one launch, sorted by allele
     int32_t seq2, k, n_reads, first;
 };
 
@@ -49,7 +53,6 @@ struct DTask {         // 16 B
 constexpr int MAX_READS_PER_TASK = 64;
 constexpr int CLEAN_THREADS = 512;
 constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
-constexpr uint32_t EMPTY32 = 0xFFFFFFFFu;
 
 // per-hit working flags inside clean_kernel (upper nibble) and the public ones (lower)
 #define HF_C1 1u

@@ -287,3 +287,68 @@ def world_from_json(d: dict) -> SynthWorld:
                for c, rs in d["reads"].items()}
     w.loci = [Locus(*l) for l in d["loci"]]
     return w
+
+
+class VirtualContig:
+    """A chromosome-sized i.i.d. ACGT sequence that is never materialised: 4 kb blocks are generated
+    on demand from (seed, block index).  Supports len() and slicing like a str."""
+    BLOCK = 4096
+
+    def __init__(self, seed: int, length: int):
+        self.seed, self.length = int(seed), int(length)
+        self._cache: Dict[int, str] = {}
+
+    def __len__(self) -> int:
+        return self.length
+
+    def _block(self, b: int) -> str:
+        s = self._cache.get(b)
+        if s is None:
+            s = random_dna(np.random.default_rng([self.seed, b]), self.BLOCK)
+            if len(self._cache) > 4096:
+                self._cache.clear()
+            self._cache[b] = s
+        return s
+
+    def __getitem__(self, sl) -> str:
+        if not isinstance(sl, slice):
+            raise TypeError("VirtualContig supports slices only")
+        a, b, _ = sl.indices(self.length)
+        if b <= a:
+            return ""
+        parts = [self._block(k) for k in range(a // self.BLOCK, (b - 1) // self.BLOCK + 1)]
+        s = "".join(parts)
+        off = a - (a // self.BLOCK) * self.BLOCK
+        return s[off:off + (b - a)]
+
+
+def make_world_from_bed(rows: Sequence[Sequence], seed: int, contig_len: int = 135534747, n_reads: int = 10,
+                        alt_fraction: float = 0.5, lead: int = 250,
+                        errors: Tuple[float, float, float] = (0.01, 0.08, 0.04)) -> SynthWorld:
+    """Loci at given genome coordinates (rows of chrom, start, end, TYPE) on virtual contigs, with reads
+    sampled around every locus - BASELINE.json configs[0]: the reference's vapor_test.bed needs a BAM
+    and hg19 that are not bundled, so the plumbing runs on a stand-in genome."""
+    rng = np.random.default_rng(seed)
+    w = SynthWorld()
+    for li, row in enumerate(rows):
+        chrom, s, e, svtype = row[0], int(row[1]), int(row[2]), {"DUP": "TANDUP"}.get(row[3], row[3])
+        if chrom not in w.contigs:
+            w.contigs[chrom] = VirtualContig(seed * 1000003 + len(w.contigs), contig_len)
+            w.reads[chrom] = []
+        span = e - s
+        flank = min(500, span)
+        r0 = s - flank - lead - 50                       # 0-based start of the local window
+        read_len = 2 * flank + 2 * span + lead + 400
+        local = w.contigs[chrom][r0:r0 + read_len + 3 * span + 2000]
+        ls, le = s - r0, e - r0
+        alt = apply_sv(local, svtype, ls, le)
+        for ri in range(n_reads):
+            from_alt = rng.random() < alt_fraction
+            hap = alt if from_alt else local
+            a = (s - flank) - r0 - 1 - int(rng.integers(1, lead + 1))
+            b = min(a + read_len, len(hap))
+            read, cigar = mutate(rng, hap[a:b], *errors)
+            w.reads[chrom].append(SamRecord("v%d_%d%s" % (li + 1, ri, "a" if from_alt else "r"), chrom,
+                                            r0 + a + 1, cigar, read, b - a))
+        w.loci.append(Locus(chrom, svtype, s, e, "sv%d" % (li + 1)))
+    return w
