@@ -701,10 +701,49 @@ def gen_config1(m):
                                  "cases": [{"name": "vapor_test_bed", "per_locus": per_locus, "vapor_text": text}]})
 
 
+def gen_melt(m):
+    """`vapor ins` (MELT calls): melt_info_readin, vapor_vali/vapor:52-81, driven directly because the
+    script's own `ins` branch reads an argparse attribute that does not exist (vapor_vali/vapor:310)."""
+    cli = load_cli(m)
+    m.make_event_figure_1 = lambda *a, **k: None
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_melt_")
+    w = synth.make_world(seed=91, n_loci=5, svtypes=("INS",), span_range=(100, 200), read_len=2600, n_reads=8,
+                         ins_len_range=(150, 700))
+    prefix = os.path.join(tmp, "S1.melt.sites")
+    lines = ["##fileformat=VCFv4.2"]
+    fa = {}
+    for t, l in enumerate(w.loci):
+        key = "%s_%d" % (l.chrom, l.start)
+        pol = "+" if t % 2 == 0 else "-"
+        seq = l.ins_seq if pol == "+" else synth.revcomp(l.ins_seq)
+        if t == 3:
+            seq = ""                      # no assembled sequence: the reader falls back to X * SVLEN
+        if t == 1:
+            seq = seq[:40] + "N" * 5 + seq[45:]
+        fa[key] = seq
+        lines.append("\t".join([l.chrom, str(l.start), ".", "<INS:ME:ALU>", "N", ".", "PASS",
+                                 "SVTYPE=ALU;SVLEN=%d;MEIINFO=AluYa5,3,281,%s" % (len(l.ins_seq), pol)]))
+    open(prefix + ".vcf", "w").write("\n".join(lines) + "\n")
+    w.contigs.update(fa)                  # the in-memory samtools serves `faidx <prefix>.fa key` from here
+    shim = ShimOS(w)
+    m.os = shim
+    cli["os"] = shim
+    cli["num_reads_cff"] = 3
+    r = call(cli["melt_info_readin"], prefix, os.path.join(tmp, "figs") + "/", "S1", "x.bam", "ref.fa")
+    m.os = os
+    text = open(prefix + ".vapor").read() if os.path.exists(prefix + ".vapor") else None
+    print("  melt:", r if "error" in r else "ok", (text or "").count("\n"), "lines")
+    for k in fa:
+        w.contigs.pop(k)
+    dump("melt_ins.json.gz", {"source": "melt_info_readin vapor_vali/vapor:52-81 (figures off)", "world": world_to_json(w),
+                              "fasta": fa, "vcf": "\n".join(lines) + "\n", "status": r if "error" in r else "ok",
+                              "cases": [{"name": "melt", "vapor_text": text}]})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)

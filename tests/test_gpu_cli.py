@@ -103,3 +103,19 @@ def test_config1_vapor_test_bed_gpu(tmp_path):
         assert out.read_text() == cfg["cases"][0]["vapor_text"]
     finally:
         seqio.set_backend(None)
+
+
+def test_melt_ins_mode_gpu(tmp_path):
+    from vapor_amd import cli, pipeline, seqio, synth
+    d = load_golden("melt_ins.json.gz")
+    pipeline.set_engine(None)
+    world = synth.world_from_json(d["world"])
+    world.contigs.update(d["fasta"])
+    seqio.set_backend(seqio.MemorySamtools(world))
+    try:
+        (tmp_path / "S1.melt.sites.vcf").write_text(d["vcf"])
+        assert cli.main(["ins", "--sv-input", str(tmp_path / "S1.melt.sites"), "--reference", "ref.fa", "--pacbio-input",
+                         "x.bam", "--output-path", str(tmp_path / "figs"), "--output-file", "unused", "--no-figures"]) == 0
+        assert (tmp_path / "S1.melt.sites.vapor").read_text() == d["cases"][0]["vapor_text"]
+    finally:
+        seqio.set_backend(None)

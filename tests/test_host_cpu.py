@@ -252,3 +252,21 @@ def test_config1_vapor_test_bed_plumbing(fake, tmp_path):
     assert cli.main(["bed", "--sv-input", str(bed), "--reference", "hg19.fa", "--pacbio-input", "x.bam",
                      "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
     assert out.read_text() == CFG1["cases"][0]["vapor_text"]
+
+
+def _run_melt(tmp_path):
+    d = load_golden("melt_ins.json.gz")
+    world = synth.world_from_json(d["world"])
+    world.contigs.update(d["fasta"])
+    seqio.set_backend(seqio.MemorySamtools(world))
+    prefix = tmp_path / "S1.melt.sites"
+    (tmp_path / "S1.melt.sites.vcf").write_text(d["vcf"])
+    rc = cli.main(["ins", "--sv-input", str(prefix), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                   "--output-path", str(tmp_path / "figs"), "--output-file", "unused", "--no-figures"])
+    return rc, (tmp_path / "S1.melt.sites.vapor").read_text(), d["cases"][0]["vapor_text"]
+
+
+def test_melt_ins_mode(fake, tmp_path):
+    """`vapor ins`: MELT sites + assembled sequences (polarity, N -> X, missing sequence -> X * SVLEN)."""
+    rc, got, exp = _run_melt(tmp_path)
+    assert rc == 0 and got == exp
