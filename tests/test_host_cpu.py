@@ -270,3 +270,36 @@ def test_melt_ins_mode(fake, tmp_path):
     """`vapor ins`: MELT sites + assembled sequences (polarity, N -> X, missing sequence -> X * SVLEN)."""
     rc, got, exp = _run_melt(tmp_path)
     assert rc == 0 and got == exp
+
+
+def test_fai_fasta_reader_matches_faidx_semantics(tmp_path):
+    """In-process .fai reader: 1-based inclusive windows, clipping, and the lines ref_seq_readin parses."""
+    rng = np.random.default_rng(3)
+    contigs = {"chrA": synth.random_dna(rng, 1234), "chrB_x": synth.random_dna(rng, 61), "chrC": synth.random_dna(rng, 60)}
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as f, open(str(fa) + ".fai", "w") as fi:
+        off = 0
+        for name, s in contigs.items():
+            hdr = ">%s some description\n" % name
+            f.write(hdr)
+            off += len(hdr)
+            fi.write("%s\t%d\t%d\t60\t61\n" % (name, len(s), off))
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+                off += len(s[i:i + 60]) + 1
+    r = seqio.FaiFasta(str(fa))
+    for name, s in contigs.items():
+        for a, b in ((1, 10), (55, 130), (1, len(s)), (len(s) - 5, len(s) + 50), (60, 61), (61, 61), (-5, 3)):
+            assert r.fetch(name, a, b) == s[max(a, 1) - 1:min(b, len(s))], (name, a, b)
+    lines = r.lines("chrA:100-400")
+    assert lines[0] == ">chrA:100-400" and "".join(lines[1:]) == contigs["chrA"][99:400] and all(len(l) <= 60 for l in lines[1:])
+
+    class Be(seqio.MemorySamtools):
+        def faidx_lines(self, ref, region):
+            return r.lines(region)
+    seqio.set_backend(Be(synth.SynthWorld()))
+    try:
+        assert seqio.ref_seq_readin(str(fa), "chrA", 100, 400) == contigs["chrA"][99:400]
+        assert seqio.ref_seq_readin(str(fa), "chrB_x", 1, 61, "TRUE") == seqio.reverse(seqio.complementary(contigs["chrB_x"]))
+    finally:
+        seqio.set_backend(None)

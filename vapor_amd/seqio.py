@@ -48,6 +48,63 @@ class SamtoolsCLI:
             return f.read().splitlines()
 
 
+class FaiFasta:
+    """In-process `samtools faidx ref chrom:start-end` through the .fai index (no process per locus)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.index = {}
+        with open(path + ".fai") as f:
+            for ln in f:
+                t = ln.rstrip("\n").split("\t")
+                if len(t) >= 5:
+                    self.index[t[0]] = (int(t[1]), int(t[2]), int(t[3]), int(t[4]))
+        self._fh = open(path, "rb")
+
+    def fetch(self, chrom: str, start: int, end: int) -> str:
+        """1-based inclusive, clipped to the contig like samtools."""
+        if chrom not in self.index:
+            return ""
+        length, offset, linebases, linewidth = self.index[chrom]
+        start = max(int(start), 1)
+        end = min(int(end), length)
+        if end < start:
+            return ""
+        a, b = start - 1, end
+        first = offset + (a // linebases) * linewidth + a % linebases
+        last = offset + ((b - 1) // linebases) * linewidth + (b - 1) % linebases + 1
+        self._fh.seek(first)
+        raw = self._fh.read(last - first)
+        return raw.replace(b"\n", b"").replace(b"\r", b"").decode("ascii")
+
+    def lines(self, region: str) -> List[str]:
+        chrom, _, span = region.rpartition(":")
+        if not chrom:
+            chrom, a, b = region, 1, self.index.get(region, (0,))[0]
+        else:
+            a, _, b = span.partition("-")
+            a, b = int(a.replace(",", "")), int(b.replace(",", ""))
+        seq = self.fetch(chrom, a, b)
+        return [">" + region] + [seq[i:i + 60] for i in range(0, len(seq), 60)]
+
+
+class SamtoolsHybrid(SamtoolsCLI):
+    """samtools for the BAM, the .fai index read in-process for the reference windows: one process per
+    locus instead of two or more."""
+
+    def __init__(self, exe: str = "samtools") -> None:
+        super().__init__(exe)
+        self._fa = {}
+
+    def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
+        fa = self._fa.get(ref)
+        if fa is None:
+            if not os.path.exists(ref + ".fai"):
+                return super().faidx_lines(ref, region)
+            fa = self._fa[ref] = FaiFasta(ref)
+        return fa.lines(region)
+
+
 class MemorySamtools:
     """Answers faidx/view from a `SynthWorld`; file names are ignored."""
 
@@ -91,7 +148,7 @@ def set_backend(b) -> None:
 def get_backend():
     global _backend
     if _backend is None:
-        _backend = SamtoolsCLI()
+        _backend = SamtoolsHybrid()
     return _backend
 
 
