@@ -303,3 +303,51 @@ def test_fai_fasta_reader_matches_faidx_semantics(tmp_path):
         assert seqio.ref_seq_readin(str(fa), "chrB_x", 1, 61, "TRUE") == seqio.reverse(seqio.complementary(contigs["chrB_x"]))
     finally:
         seqio.set_backend(None)
+
+
+def test_inprocess_bam_reader_equals_memory_backend(tmp_path):
+    """BAM + BAI written by vapor_amd.bamio from a synthetic world, read back in-process: region queries
+    return the records the in-memory backend returns, and the read trimming built on them is identical."""
+    from vapor_amd import bamio
+    w = synth.make_world(seed=5, n_loci=3, svtypes=("DEL", "INV", "TANDUP"), span_range=(200, 900), read_len=2600, n_reads=30)
+    # put all loci on ONE contig 40 kb apart so that bins and the linear index are exercised
+    contig = ""
+    recs = []
+    shift = {}
+    for k, (name, seq) in enumerate(w.contigs.items()):
+        shift[name] = len(contig)
+        contig += seq + synth.random_dna(np.random.default_rng(k), 40000)
+    for name, rs in w.reads.items():
+        for r in rs:
+            recs.append((r.qname, 0, shift[name] + r.pos - 1, r.cigar, r.seq))
+    bam = str(tmp_path / "x.bam")
+    bamio.write_bam(bam, [("chrU", len(contig))], recs, block_size=4096)
+    big = synth.SynthWorld()
+    big.contigs["chrU"] = contig
+    big.reads["chrU"] = sorted([synth.SamRecord(q, "chrU", p + 1, c, s, sum(int(n) for n, o in
+                                __import__("re").findall(r"(\d+)([MD=XN])", c))) for q, _t, p, c, s in recs], key=lambda r: r.pos)
+    mem = seqio.MemorySamtools(big)
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as f, open(str(fa) + ".fai", "w") as fi:
+        f.write(">chrU\n")
+        fi.write("chrU\t%d\t6\t60\t61\n" % len(contig))
+        for i in range(0, len(contig), 60):
+            f.write(contig[i:i + 60] + "\n")
+    inproc = seqio.InProcessBam()
+    for l in w.loci:
+        s0 = shift[l.chrom]
+        for a, b in ((s0 + l.start - 500, s0 + l.start + 500), (s0 + l.start - 500, s0 + l.end + 500), (s0 + 1, s0 + 50)):
+            exp = [ln.split("\t") for ln in mem.view_lines("x.bam", "chrU:%d-%d" % (a, b))]
+            got = [ln.split("\t") for ln in inproc.view_lines(bam, "chrU:%d-%d" % (a, b))]
+            key = lambda t: (int(t[3]), t[0])
+            assert sorted([(t[0], t[3], t[5], t[9]) for t in got], key=lambda t: (int(t[1]), t[0])) == \
+                sorted([(t[0], t[3], t[5], t[9]) for t in exp], key=lambda t: (int(t[1]), t[0]))
+        seqio.set_backend(mem)
+        e1 = seqio.simple_chop_pacbio_read_simple_short("x.bam", ["chrU", s0 + l.start, s0 + l.end], 500)
+        r1 = seqio.ref_seq_readin(str(fa), "chrU", s0 + l.start - 500, s0 + l.end + 500)
+        seqio.set_backend(inproc)
+        e2 = seqio.simple_chop_pacbio_read_simple_short(bam, ["chrU", s0 + l.start, s0 + l.end], 500)
+        r2 = seqio.ref_seq_readin(str(fa), "chrU", s0 + l.start - 500, s0 + l.end + 500)
+        seqio.set_backend(None)
+        assert sorted(e1) == sorted(e2) and len(e1) > 3
+        assert r1 == r2

@@ -1,0 +1,324 @@
+"""In-process BAM access for `samtools view bam chrom:start-end`.
+
+The reference starts one samtools process per locus and BAM (SF:340); once scoring runs on the GPU
+that popen is the wall-clock floor.  This module reads BGZF/BAM and the .bai index directly and returns
+the four fields the reference uses from every SAM line (QNAME, POS, CIGAR, SEQ; SF:342-352) as text
+lines in SAM column order, so `seqio.chop_pacbio_read_by_pos` is unchanged.
+
+Opt-in (`seqio.set_backend(seqio.InProcessBam())` or VAPOR_BAM_BACKEND=inprocess): it follows the
+SAM/BAM specification (v1 BAM, BAI bins and linear index) and is checked against this repository's own
+BAM writer (tests), but it has not been run on third-party BAM files in this environment.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Dict, Iterator, List, Tuple
+
+_SEQ = "=ACMGRSVTWYHKDBN"
+_CIG = "MIDNSHP=X"
+_SEQ_LUT = [a + b for a in _SEQ for b in _SEQ]
+
+
+# ---------------------------------------------------------------------------------------------
+# BGZF
+# ---------------------------------------------------------------------------------------------
+class BgzfReader:
+    """Random access by virtual offset (compressed block offset << 16 | offset inside the block)."""
+
+    def __init__(self, path: str):
+        self.f = open(path, "rb")
+        self._cache: Dict[int, Tuple[bytes, int]] = {}
+
+    def _block(self, coff: int) -> Tuple[bytes, int]:
+        got = self._cache.get(coff)
+        if got is not None:
+            return got
+        self.f.seek(coff)
+        hdr = self.f.read(18)
+        if len(hdr) < 18:
+            return b"", 0
+        if hdr[:4] != b"\x1f\x8b\x08\x04":
+            raise ValueError("not a BGZF block at offset %d" % coff)
+        xlen = struct.unpack("<H", hdr[10:12])[0]
+        extra = hdr[12:] + self.f.read(xlen - 6)
+        bsize = None
+        p = 0
+        while p + 4 <= len(extra):
+            si1, si2, slen = extra[p], extra[p + 1], struct.unpack("<H", extra[p + 2:p + 4])[0]
+            if si1 == 66 and si2 == 67 and slen == 2:
+                bsize = struct.unpack("<H", extra[p + 4:p + 6])[0] + 1
+            p += 4 + slen
+        if bsize is None:
+            raise ValueError("BGZF block without BC field")
+        cdata = self.f.read(bsize - 12 - xlen - 8)
+        self.f.read(8)
+        data = zlib.decompress(cdata, -15)
+        if len(self._cache) > 64:
+            self._cache.clear()
+        self._cache[coff] = (data, bsize)
+        return data, bsize
+
+    def read_from(self, voff: int):
+        """Generator of (bytes, virtual offset after them) is awkward for records; use Cursor."""
+        return BgzfCursor(self, voff)
+
+
+class BgzfCursor:
+    def __init__(self, rd: BgzfReader, voff: int):
+        self.rd = rd
+        self.coff, self.uoff = voff >> 16, voff & 0xFFFF
+        self.data, self.bsize = rd._block(self.coff)
+
+    def tell(self) -> int:
+        return (self.coff << 16) | self.uoff
+
+    def read(self, n: int) -> bytes:
+        out = []
+        while n > 0:
+            if self.uoff >= len(self.data):
+                if self.bsize == 0:
+                    break
+                self.coff += self.bsize
+                self.uoff = 0
+                self.data, self.bsize = self.rd._block(self.coff)
+                if not self.data and self.bsize == 0:
+                    break
+                continue
+            take = self.data[self.uoff:self.uoff + n]
+            out.append(take)
+            self.uoff += len(take)
+            n -= len(take)
+        return b"".join(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# BAI
+# ---------------------------------------------------------------------------------------------
+def reg2bins(beg: int, end: int) -> List[int]:
+    """Bins overlapping the 0-based half-open interval [beg, end) (SAM spec, section 5.3)."""
+    end -= 1
+    out = [0]
+    for shift, off in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        out.extend(range(off + (beg >> shift), off + (end >> shift) + 1))
+    return out
+
+
+def reg2bin(beg: int, end: int) -> int:
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+class BaiIndex:
+    def __init__(self, path: str):
+        raw = open(path, "rb").read()
+        if raw[:4] != b"BAI\x01":
+            raise ValueError("not a BAI index: " + path)
+        p = 4
+        n_ref = struct.unpack_from("<i", raw, p)[0]
+        p += 4
+        self.bins: List[Dict[int, List[Tuple[int, int]]]] = []
+        self.linear: List[List[int]] = []
+        for _ in range(n_ref):
+            n_bin = struct.unpack_from("<i", raw, p)[0]
+            p += 4
+            d = {}
+            for _b in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", raw, p)
+                p += 8
+                ch = list(struct.iter_unpack("<QQ", raw[p:p + 16 * n_chunk]))
+                p += 16 * n_chunk
+                d[b] = ch
+            n_intv = struct.unpack_from("<i", raw, p)[0]
+            p += 4
+            lin = list(struct.unpack_from("<%dQ" % n_intv, raw, p)) if n_intv else []
+            p += 8 * n_intv
+            self.bins.append(d)
+            self.linear.append(lin)
+
+    def chunks(self, tid: int, beg: int, end: int) -> List[Tuple[int, int]]:
+        d = self.bins[tid]
+        lin = self.linear[tid]
+        min_off = lin[min(beg >> 14, len(lin) - 1)] if lin else 0
+        out = []
+        for b in reg2bins(beg, end):
+            for s, e in d.get(b, ()):
+                if e > min_off:
+                    out.append((max(s, min_off), e))
+        out.sort()
+        merged: List[Tuple[int, int]] = []
+        for s, e in out:
+            if merged and s <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], e))
+            else:
+                merged.append((s, e))
+        return merged
+
+
+# ---------------------------------------------------------------------------------------------
+# BAM
+# ---------------------------------------------------------------------------------------------
+class BamFile:
+    def __init__(self, path: str):
+        self.path = path
+        self.bgzf = BgzfReader(path)
+        c = self.bgzf.read_from(0)
+        if c.read(4) != b"BAM\x01":
+            raise ValueError("not a BAM file: " + path)
+        l_text = struct.unpack("<i", c.read(4))[0]
+        c.read(l_text)
+        n_ref = struct.unpack("<i", c.read(4))[0]
+        self.refs: List[Tuple[str, int]] = []
+        self.tid: Dict[str, int] = {}
+        for t in range(n_ref):
+            l_name = struct.unpack("<i", c.read(4))[0]
+            name = c.read(l_name)[:-1].decode()
+            l_ref = struct.unpack("<i", c.read(4))[0]
+            self.refs.append((name, l_ref))
+            self.tid[name] = t
+        self.first_record = c.tell()
+        import os
+        bai = path + ".bai" if os.path.exists(path + ".bai") else path[:-4] + ".bai"
+        self.index = BaiIndex(bai)
+
+    @staticmethod
+    def _parse(rec: bytes):
+        ref_id, pos, l_name, _mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHi", rec, 0)
+        p = 32
+        name = rec[p:p + l_name - 1].decode()
+        p += l_name
+        cig = struct.unpack_from("<%dI" % n_cig, rec, p) if n_cig else ()
+        p += 4 * n_cig
+        nb = (l_seq + 1) // 2
+        sq = rec[p:p + nb]
+        return ref_id, pos, name, flag, cig, l_seq, sq
+
+    def fetch_lines(self, chrom: str, start: int, end: int) -> List[str]:
+        """SAM-ordered text lines (QNAME FLAG RNAME POS MAPQ CIGAR * 0 0 SEQ *) of the alignments that
+        overlap the 1-based inclusive region, in file order."""
+        tid = self.tid.get(chrom)
+        if tid is None:
+            return []
+        beg, stop = max(start - 1, 0), end               # 0-based half-open
+        out: List[str] = []
+        for cs, ce in self.index.chunks(tid, beg, stop):
+            cur = self.bgzf.read_from(cs)
+            while cur.tell() < ce:
+                hdr = cur.read(4)
+                if len(hdr) < 4:
+                    break
+                rec = cur.read(struct.unpack("<i", hdr)[0])
+                ref_id, pos, name, flag, cig, l_seq, sq = self._parse(rec)
+                if ref_id != tid or pos >= stop:
+                    if ref_id > tid or (ref_id == tid and pos >= stop):
+                        break
+                    continue
+                rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+                if pos + max(rlen, 1) <= beg:
+                    continue
+                cigar = "".join("%d%s" % (c >> 4, _CIG[c & 15]) for c in cig) or "*"
+                seq = "".join(_SEQ_LUT[b] for b in sq)[:l_seq] or "*"
+                out.append("\t".join([name, str(flag), chrom, str(pos + 1), "0", cigar, "*", "0", "0", seq, "*"]))
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# writer (tests and synthetic worlds): coordinate-sorted BAM + BAI
+# ---------------------------------------------------------------------------------------------
+def _bgzf_block(data: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(data) + comp.flush()
+    bsize = len(cdata) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+            + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, int, int, str, str]],
+              block_size: int = 16384) -> None:
+    """records: (qname, tid, pos0, cigar string, seq), will be sorted by (tid, pos).  Writes path and
+    path + '.bai'."""
+    import re
+    enc = {c: i for i, c in enumerate(_SEQ)}
+    recs = sorted(records, key=lambda r: (r[1], r[2]))
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    head = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
+    for name, ln in refs:
+        head += struct.pack("<i", len(name) + 1) + name.encode() + b"\x00" + struct.pack("<i", ln)
+    blobs = []
+    meta = []
+    for qname, tid, pos, cigar, seq in recs:
+        ops = [(int(n), _CIG.index(o)) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", cigar)]
+        rlen = sum(n for n, o in ops if o in (0, 2, 3, 7, 8))
+        end = pos + max(rlen, 1)
+        sq = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            sq[i >> 1] |= enc.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
+        body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname) + 1, 60, reg2bin(pos, end), len(ops), 0, len(seq), -1, -1, 0)
+        body += qname.encode() + b"\x00" + b"".join(struct.pack("<I", (n << 4) | o) for n, o in ops) + bytes(sq) + b"\xff" * len(seq)
+        blobs.append(struct.pack("<i", len(body)) + body)
+        meta.append((tid, pos, end))
+    # lay the stream out in BGZF blocks, remembering the virtual offset of every record
+    stream = head
+    starts = []
+    for b in blobs:
+        starts.append(len(stream))
+        stream += b
+    ends = starts[1:] + [len(stream)]
+    out = bytearray()
+    block_coff = []
+    for o in range(0, len(stream), block_size):
+        block_coff.append(len(out))
+        out += _bgzf_block(stream[o:o + block_size])
+    out += _BGZF_EOF
+
+    def voff(u: int) -> int:
+        b = u // block_size
+        if b >= len(block_coff):
+            return (len(out) - len(_BGZF_EOF)) << 16
+        return (block_coff[b] << 16) | (u % block_size)
+
+    open(path, "wb").write(bytes(out))
+    bins: List[Dict[int, List[List[int]]]] = [dict() for _ in refs]
+    linear: List[List[int]] = [[] for _ in refs]
+    for (tid, pos, end), s, e in zip(meta, starts, ends):
+        vs, ve = voff(s), voff(e)
+        ch = bins[tid].setdefault(reg2bin(pos, end), [])
+        if ch and ch[-1][1] == vs:
+            ch[-1][1] = ve
+        else:
+            ch.append([vs, ve])
+        lin = linear[tid]
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            while len(lin) <= w:
+                lin.append(0)
+            if lin[w] == 0:
+                lin[w] = vs
+        # windows without their own first record inherit the next known offset backwards (spec: the
+        # linear index gives the smallest offset of any record overlapping the window)
+    bai = b"BAI\x01" + struct.pack("<i", len(refs))
+    for t in range(len(refs)):
+        lin = linear[t]
+        last = 0
+        for w in range(len(lin)):
+            if lin[w] == 0:
+                lin[w] = last
+            last = lin[w]
+        bai += struct.pack("<i", len(bins[t]))
+        for b, ch in sorted(bins[t].items()):
+            bai += struct.pack("<Ii", b, len(ch)) + b"".join(struct.pack("<QQ", s, e) for s, e in ch)
+        bai += struct.pack("<i", len(lin)) + b"".join(struct.pack("<Q", v) for v in lin)
+    bai += struct.pack("<Q", 0)
+    open(path + ".bai", "wb").write(bai)

@@ -105,6 +105,31 @@ class SamtoolsHybrid(SamtoolsCLI):
         return fa.lines(region)
 
 
+class InProcessBam(SamtoolsHybrid):
+    """BAM and BAI read in-process as well (vapor_amd.bamio): no samtools process at all per locus.
+    samtools itself is then not needed."""
+
+    def __init__(self) -> None:        # noqa: D401 - does not require the samtools binary
+        self.exe = None
+        self._fa = {}
+        self._bam = {}
+
+    def view_lines(self, bam: str, region: str) -> Iterable[str]:
+        from . import bamio
+        b = self._bam.get(bam)
+        if b is None:
+            b = self._bam[bam] = bamio.BamFile(bam)
+        chrom, _, span = region.rpartition(":")
+        a, _, e = span.partition("-")
+        return b.fetch_lines(chrom, int(a), int(e))
+
+    def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
+        fa = self._fa.get(ref)
+        if fa is None:
+            fa = self._fa[ref] = FaiFasta(ref)
+        return fa.lines(region)
+
+
 class MemorySamtools:
     """Answers faidx/view from a `SynthWorld`; file names are ignored."""
 
@@ -148,7 +173,13 @@ def set_backend(b) -> None:
 def get_backend():
     global _backend
     if _backend is None:
-        _backend = SamtoolsHybrid()
+        # samtools for the BAM when it is installed (or asked for); otherwise the in-process reader, which
+        # raises on a missing .bai/.fai instead of returning nothing
+        want = os.environ.get("VAPOR_BAM_BACKEND", "")
+        if want == "inprocess" or (want != "samtools" and shutil.which("samtools") is None):
+            _backend = InProcessBam()
+        else:
+            _backend = SamtoolsHybrid()
     return _backend
 
 
