@@ -289,15 +289,34 @@ __device__ __forceinline__ uint32_t canon_bucket(const KeyT<BPS, K>& k, const Ke
     return x >> (32 - NBL);
 }
 
+// Cross-lane steps as DPP modifiers of VALU instructions (gfx9: row_shr, wave_shr, row_bcast15/31) instead of
+// ds_bpermute: they do not occupy the LDS pipe that the table and bitmap traffic needs and their latency is a
+// few cycles.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T dpp_from(T identity, T v)
+{
+    return (T)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+struct OpAdd { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct OpMin { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a < b ? a : b; } };
+struct OpMax { template <typename T> __device__ __forceinline__ T operator()(T a, T b) const { return a > b ? a : b; } };
+// inclusive scan over the 64 lanes (lane 63 ends with the reduction)
+template <typename OP, typename T>
+__device__ __forceinline__ T wave_scan(T v, T identity)
+{
+    OP op;
+    v = op(v, dpp_from<0x111, 0xF>(identity, v));   // row_shr:1
+    v = op(v, dpp_from<0x112, 0xF>(identity, v));   // row_shr:2
+    v = op(v, dpp_from<0x114, 0xF>(identity, v));   // row_shr:4
+    v = op(v, dpp_from<0x118, 0xF>(identity, v));   // row_shr:8
+    v = op(v, dpp_from<0x142, 0xA>(identity, v));   // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_from<0x143, 0xC>(identity, v));   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
-    }
-    return v;
+    return wave_scan<OpAdd>(v, 0u);
 }
 
 // verify queued candidates [from, from+n), n <= 128, two per lane so that their LDS reads overlap.
@@ -566,13 +585,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
 #pragma unroll
                         for (int x = 0; x < 4; ++x) incl[x] = sc[x] >> 16;
 #pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            uint32_t up[4];
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) up[x] = __shfl_up(incl[x], o, 64);
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) incl[x] += (lane >= o) ? up[x] : 0u;
-                        }
+                        for (int x = 0; x < 4; ++x) incl[x] = wave_scan<OpAdd>(incl[x], 0u);
                         // ---- fill the queue position by position; verify 128 candidates whenever they are there
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
@@ -633,11 +646,10 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
 // ------------------------------------------------------------------------------------------
 // clean kernel
 // ------------------------------------------------------------------------------------------
+// wave reductions: every lane gets the result
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    return __builtin_amdgcn_readlane(wave_scan<OpAdd>(v, 0), 63);
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
@@ -647,15 +659,11 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
 }
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, 64));
-    return v;
+    return __builtin_amdgcn_readlane(wave_scan<OpMin>(v, 0x7FFFFFFF), 63);
 }
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, 64));
-    return v;
+    return __builtin_amdgcn_readlane(wave_scan<OpMax>(v, (int)0x80000000), 63);
 }
 
 struct CleanShared {
@@ -679,7 +687,7 @@ struct CleanShared {
 __device__ __forceinline__ int run_head_len(uint32_t key)
 {
     const int lane = threadIdx.x & 63;
-    uint32_t prev = __shfl_up(key, 1, 64);
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, false);   // wave_shr:1
     bool head = (lane == 0) || (key != prev);
     unsigned long long m = __ballot(head);
     unsigned long long above = (lane == 63) ? 0ULL : (m >> (lane + 1));
@@ -690,12 +698,7 @@ __device__ __forceinline__ int run_head_len(uint32_t key)
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanShared* sh, uint32_t* total)
 {
     const int tid = threadIdx.x;
-    uint32_t incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += t;
-    }
+    uint32_t incl = wave_incl_scan_u32(local);
     if ((tid & 63) == 63) sh->wave_tot[tid >> 6] = incl;
     __syncthreads();
     uint32_t base = 0, tot = 0;
