@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvapor_hip.so")
+# VAPOR_HIP_LIB: developer builds of the same library (tools/phase_timing.py); never a different backend
+SO_PATH = os.environ.get("VAPOR_HIP_LIB") or os.path.join(_HERE, "libvapor_hip.so")
 
 PAIR_DTYPE = np.dtype([("seq1", "<i4"), ("seq2", "<i4"), ("off2", "<i4"), ("k", "<i4"), ("flags", "<u4")])
 READ_DTYPE = np.dtype([("ref_a", "<i4"), ("alt_a", "<i4"), ("ref_b", "<i4"), ("alt_b", "<i4"), ("kind", "<i4"),

@@ -89,7 +89,8 @@ struct vapor_plan {
     double* d_gt = nullptr;
     double* d_read_scores = nullptr;
     double* d_loci = nullptr;
-    unsigned int* d_overflow = nullptr;
+    unsigned int* d_overflow = nullptr;   // [0] pairs whose slot overflowed, [1] length of d_big_list
+    int32_t* d_big_list = nullptr;        // pairs with more dots than clean_kernel stages in LDS
     unsigned int* h_overflow = nullptr;   // pinned
     double t_finish = 0;
 };
@@ -128,6 +129,8 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
     for (hipError_t x : a)
         if (x != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(join): ") + hipGetErrorString(x)); }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(clean): ") + hipGetErrorString(e)); }
     *out = c;
     return VAPOR_OK;
@@ -286,6 +289,7 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
     if (p->h_stats) (void)hipHostFree(p->h_stats);
     if (p->h_overflow) (void)hipHostFree(p->h_overflow);
     (void)hipFree(p->d_overflow);
+    (void)hipFree(p->d_big_list);
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : p->ev_f)
@@ -346,6 +350,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         }
         const SeqDesc& s1 = set->h[a.seq1];
         const SeqDesc& s2 = set->h[a.seq2];
+        d.len1 = s1.len; d.len2 = s2.len;
         if (s1.len > VAPOR_MAX_SEQ_LEN || s2.len > VAPOR_MAX_SEQ_LEN) { p->status[i] = VAPOR_E_ARG; continue; }
         if (s1.len - a.k + 1 > 0 && s1.n_invalid > 0) { p->status[i] = VAPOR_E_KEYERROR; continue; }
         int64_t n1 = s1.len, n2 = std::max(0, s2.len - a.off2);
@@ -417,7 +422,8 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     chk(hipMalloc((void**)&p->d_nhits, sizeof(unsigned long long) * p->hp.size()), "hipMalloc nhits");
     chk(hipMalloc((void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
     chk(hipHostMalloc((void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
-    chk(hipMalloc((void**)&p->d_overflow, sizeof(unsigned int)), "hipMalloc overflow");
+    chk(hipMalloc((void**)&p->d_overflow, 2 * sizeof(unsigned int)), "hipMalloc overflow");
+    chk(hipMalloc((void**)&p->d_big_list, sizeof(int32_t) * p->hp.size()), "hipMalloc big list");
     chk(hipHostMalloc((void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
@@ -447,6 +453,8 @@ static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 /
 
 // clean_kernel's LDS: bitmap + 16-bit ranks + group sizes (+ staged hits).  Pairs cleaned out of LDS use
 // 16-bit group counters; pairs that stream their hits need 32-bit ones, which must fit as well.
+constexpr int CLEAN_BIG_GRID = 1024;      // clean_big_kernel walks its list with at most this many workgroups
+
 static size_t clean_fixed_bytes(int rw, bool wide)
 {
     const size_t g = (size_t)clean_groups_cap(rw);
@@ -470,7 +478,7 @@ static int clean_hcap(int range_words_cap, int want)
 
 static size_t clean_lds_bytes(int range_words_cap, int hcap)
 {
-    return std::max(clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 5, clean_fixed_bytes(range_words_cap, true));
+    return clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 5;
 }
 
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
@@ -479,7 +487,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
     hipStream_t st = c->stream;
     HIPCHK(hipEventRecord(p->ev_t0, st));
     HIPCHK(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), st));
-    HIPCHK(hipMemsetAsync(p->d_overflow, 0, sizeof(unsigned int), st));
+    HIPCHK(hipMemsetAsync(p->d_overflow, 0, 2 * sizeof(unsigned int), st));
     HIPCHK(hipEventRecord(p->ev[0], st));       // join time = first join launch .. last join end (no memsets)
     for (const Launch& L : p->launches) {
         if (L.bps == 2) {
@@ -499,10 +507,16 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
     if (p->n_pairs > 0) {
         int hcap = clean_hcap(p->range_words_cap, p->hcap_want);
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
-        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st, p->set->d_seqs,
+        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st,
                            p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
-                           p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap, p->d_overflow);
+                           p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap, p->d_overflow, p->d_big_list);
         HIPCHK(hipGetLastError());
+#ifndef VAPOR_AB_NOBIG
+        hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(p->n_pairs, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
+                           clean_fixed_bytes(p->range_words_cap, true), st, p->d_pairs, p->d_nhits, p->d_hits, p->d_hflags,
+                           p->d_stats, p->range_words_cap, clean_groups_cap(p->range_words_cap), p->d_overflow, p->d_big_list);
+        HIPCHK(hipGetLastError());
+#endif
     }
     HIPCHK(hipEventRecord(p->ev[2], st));
     if (p->n_pairs > 0 && fetch_stats)
@@ -691,7 +705,6 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t tot = off[n_lists];
     if (tot && !hits_ji) return fail(VAPOR_E_ARG, "vapor_clean_hits: null hit list");
-    std::vector<SeqDesc> sd((size_t)n_lists * 2);
     std::vector<DPair> dp((size_t)n_lists);
     std::vector<unsigned long long> nh((size_t)n_lists);
     std::vector<uint32_t> packed((size_t)std::max<int64_t>(tot, 1));
@@ -705,46 +718,48 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
             mi = std::max(mi, i); mj = std::max(mj, j);
             packed[h] = ((uint32_t)j << 16) | (uint32_t)i;
         }
-        memset(&sd[2 * t], 0, 2 * sizeof(SeqDesc));
-        sd[2 * t].len = mi + 1;
-        sd[2 * t + 1].len = mj + 1;
         DPair& d = dp[t];
         d.seq1 = (int32_t)(2 * t); d.seq2 = (int32_t)(2 * t + 1); d.off2 = 0; d.k = 10;
+        d.len1 = mi + 1; d.len2 = mj + 1;
         d.flags = flags ? flags[t] : 3u;
         d.cap = (uint32_t)(off[t + 1] - off[t]);
         d.hit_off = off[t];
         nh[t] = (unsigned long long)(off[t + 1] - off[t]);
         rw = std::max(rw, (mi + mj + 4 + 31) / 32);
     }
-    SeqDesc* d_sd = nullptr; DPair* d_dp = nullptr; unsigned long long* d_nh = nullptr;
+    DPair* d_dp = nullptr; unsigned long long* d_nh = nullptr; unsigned int* d_ov = nullptr; int32_t* d_big = nullptr;
     uint32_t* d_hits = nullptr; uint8_t* d_fl = nullptr; long long* d_st = nullptr;
     int rc = VAPOR_OK;
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
     hipStream_t st = ctx->stream;
-    chk(hipMalloc((void**)&d_sd, sizeof(SeqDesc) * sd.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_ov, 2 * sizeof(unsigned int)), "hipMalloc");
+    chk(hipMalloc((void**)&d_big, sizeof(int32_t) * dp.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_dp, sizeof(DPair) * dp.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_nh, sizeof(unsigned long long) * nh.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_hits, sizeof(uint32_t) * packed.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_fl, packed.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_st, sizeof(long long) * 16 * (size_t)n_lists), "hipMalloc");
     if (rc == VAPOR_OK) {
-        chk(hipMemcpyAsync(d_sd, sd.data(), sizeof(SeqDesc) * sd.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemsetAsync(d_ov, 0, 2 * sizeof(unsigned int), st), "memset");
         chk(hipMemcpyAsync(d_dp, dp.data(), sizeof(DPair) * dp.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_nh, nh.data(), sizeof(unsigned long long) * nh.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice, st), "copy");
     }
     if (rc == VAPOR_OK) {
         int hcap = clean_hcap(rw, 4096);
-        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_sd, d_dp,
-                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), hcap, (unsigned int*)nullptr);
+        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_dp,
+                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), hcap, d_ov, d_big);
+        chk(hipGetLastError(), "clean launch");
+        hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
+                           clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);
         chk(hipGetLastError(), "clean launch");
         chk(hipMemcpyAsync(stats, d_st, sizeof(long long) * 16 * (size_t)n_lists, hipMemcpyDeviceToHost, st), "copy");
         if (hit_flags && tot) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)tot, hipMemcpyDeviceToHost, st), "copy");
         chk(hipStreamSynchronize(st), "sync");
     }
-    (void)hipFree(d_sd); (void)hipFree(d_dp); (void)hipFree(d_nh); (void)hipFree(d_hits); (void)hipFree(d_fl); (void)hipFree(d_st);
+    (void)hipFree(d_ov); (void)hipFree(d_big); (void)hipFree(d_dp); (void)hipFree(d_nh); (void)hipFree(d_hits); (void)hipFree(d_fl); (void)hipFree(d_st);
     return rc;
 }
 
@@ -838,3 +853,17 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     }
     return VAPOR_OK;
 }
+
+
+#ifdef VAPOR_PHASE_TIMING
+// developer build only: read (and clear) the per-phase tick sums
+extern "C" int vapor_debug_phases(double* out, int32_t n)
+{
+    unsigned long long h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vapor::g_phase), sizeof(h)) != hipSuccess) return -1;
+    for (int x = 0; x < n && x < 64; ++x) out[x] = (double)h[x];
+    memset(h, 0, sizeof(h));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vapor::g_phase), h, sizeof(h)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -34,10 +34,11 @@ struct SeqDesc {       // 32 B
     uint32_t pad[2];
 };
 
-struct DPair {         // 32 B
+struct DPair {         // 40 B
     int32_t seq1, seq2, off2, k;
     uint32_t flags, cap;
     int64_t hit_off;
+    int32_t len1, len2;  // sequence lengths (the clean kernels need nothing else of the sequences)
 };
 
 struct DTask {         // 16 B: pairs task_pairs[first .. first + n_reads) of one launch, sorted by allele
@@ -314,6 +315,48 @@ __device__ __forceinline__ T wave_scan(T v, T identity)
     return v;
 }
 
+// Developer build only (-DVAPOR_PHASE_TIMING, tools/phase_timing.py): shader-clock ticks per kernel phase, summed
+// over the stamping lanes into g_phase[].  Compiled out of the product library.
+#ifdef VAPOR_PHASE_TIMING
+__device__ unsigned long long g_phase[64];
+// ticks are summed in (scalar) registers and flushed once per stamping lane, so the stamps cost a few SALU
+// instructions and do not queue atomics behind the phase being measured
+template <int BASE, int N>
+struct PhaseClockT {
+    long long last;
+    unsigned long long acc[N];
+    __device__ __forceinline__ PhaseClockT() : last(clock64())
+    {
+#pragma unroll
+        for (int x = 0; x < N; ++x) acc[x] = 0;
+    }
+    __device__ __forceinline__ void mark(int k, bool)
+    {
+        const long long t = clock64();
+#pragma unroll
+        for (int x = 0; x < N; ++x)
+            if (x == k - BASE) acc[x] += (unsigned long long)(t - last);
+        last = t;
+    }
+    __device__ __forceinline__ void flush(bool who)
+    {
+        if (who) {
+#pragma unroll
+            for (int x = 0; x < N; ++x)
+                if (acc[x]) atomicAdd(&g_phase[BASE + x], acc[x]);
+        }
+    }
+};
+#else
+template <int BASE, int N>
+struct PhaseClockT {
+    __device__ __forceinline__ void mark(int, bool) {}
+    __device__ __forceinline__ void flush(bool) {}
+};
+#endif
+using JoinClock = PhaseClockT<0, 7>;
+using CleanClock = PhaseClockT<8, 28>;
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
     return wave_scan<OpAdd>(v, 0u);
@@ -416,6 +459,8 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
     uint32_t* rbuf = rbufs + wave * rbuf_words<BPS>();
 
     if (tid < MAX_READS_PER_TASK) cnt[tid] = 0ULL;
+    JoinClock pc;
+    const bool pw = lane == 0;                     // one stamping lane per wave
 
     int g0 = 0;
     while (g0 < task.n_reads) {
@@ -507,6 +552,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                 cstart[g1 - g0] = acc;
             }
             __syncthreads();
+            pc.mark(0, pw);                        // table build (incl. waiting for the slowest wave of the last probe)
             const int total_strips = cstart[g1 - g0];
             {
                 constexpr int NWIN = ((15 + K) * BPS + 31) / 32;
@@ -544,6 +590,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                     for (int x = 0; x < NWIN; ++x) W[x] = rbuf[lane * WPL + x];
                     W[NWIN] = 0u;
                     KT kr;
+                    pc.mark(1, pw);                        // strip staging
                     for (int g = 0; g < 4; ++g) {
                         if (BPS == 4 && g == 2) {                  // positions 8..15 start one word further on
 #pragma unroll
@@ -580,12 +627,14 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                             const uint32_t s0 = start16[h], s1v = start16[h + 1];
                             sc[t4] = valid ? (s0 | ((s1v - s0) << 16)) : 0u;
                         }
+                        pc.mark(2, pw);                    // keys + bucket bounds issued
                         // ---- four wave prefix sums of the bucket sizes, interleaved -------------------------
                         uint32_t incl[4];
 #pragma unroll
                         for (int x = 0; x < 4; ++x) incl[x] = sc[x] >> 16;
 #pragma unroll
                         for (int x = 0; x < 4; ++x) incl[x] = wave_scan<OpAdd>(incl[x], 0u);
+                        pc.mark(3, pw);                    // scans (waits for the bucket reads)
                         // ---- fill the queue position by position; verify 128 candidates whenever they are there
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
@@ -625,21 +674,27 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                             }
                             qlen += (int)tot;
                             if (qlen >= 128) {
+                                pc.mark(4, pw);            // queue fill
                                 join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, &cnt[r],
                                                     pr.cap, out);
                                 qlen -= 128;
+                                pc.mark(5, pw);            // verify + store
                             }
                         }
+                        pc.mark(4, pw);
                     }
                     // the strip changes: drain
                     if (qlen > 0)
                         join_verify<BPS, K>(myq, 0, qlen, entries, rbuf, tile, cb, ts, pr.off2, &cnt[r], pr.cap, out);
+                    pc.mark(5, pw);
                 }
             }
         }
         g0 = g1;
     }
     __syncthreads();
+    pc.mark(6, pw);                                // waiting for the block's last wave
+    pc.flush(pw);
     if (tid < task.n_reads) n_hits[task_pairs[task.first + tid]] = cnt[tid];
 }
 
@@ -727,7 +782,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanSh
 template <bool AXIS_A, bool NARROW, bool HAVE_BM, bool FINAL, typename HP, typename FP>
 __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
                                              uint16_t* wrank, uint32_t* gcnt, CleanShared* sh,
-                                             uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule)
+                                             uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule, CleanClock& pc, int phase0 = 16)
 {
     const int tid = threadIdx.x;
     uint32_t* sb = bm;                               // the start bits replace the occupancy bits in place
@@ -758,10 +813,11 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
         for (int q = 0; q < CU; ++q) head[q] = run_head_len(v[q]);
 #pragma unroll
         for (int q = 0; q < CU; ++q)
-            if (head[q]) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
+            if (head[q] && !(bm[v[q] >> 5] & (1u << (v[q] & 31)))) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
     }
     }
     __syncthreads();
+    pc.mark(phase0 + 0, tid == 0);
     // 2. group starts and their ranks
     const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
     const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
@@ -795,6 +851,7 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     }
     for (uint32_t g = tid; g < (NARROW ? (ng + 1) / 2 : ng); g += CLEAN_THREADS) gcnt[g] = 0;
     __syncthreads();
+    pc.mark(phase0 + 1, tid == 0);
     // 3. group sizes (one atomic per run of equal group ids)
     for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
         uint32_t g[CU];
@@ -810,6 +867,22 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
             const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
             g[q] = act ? gid : INACTIVE_KEY;
         }
+#ifdef VAPOR_AB_PEEL
+#pragma unroll
+        for (int q = 0; q < CU; ++q) {
+            const unsigned long long am = __ballot(g[q] != INACTIVE_KEY);
+            if (am) {
+                const int fl = __ffsll((long long)am) - 1;
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)g[q], fl);
+                const unsigned long long m = __ballot(g[q] == lead);
+                if ((tid & 63) == fl) {
+                    if (NARROW) atomicAdd(&gcnt[lead >> 1], (uint32_t)__popcll(m) << ((lead & 1u) * 16));
+                    else atomicAdd(&gcnt[lead], (uint32_t)__popcll(m));
+                }
+                if (g[q] == lead) g[q] = INACTIVE_KEY;
+            }
+        }
+#endif
         int len[CU];
 #pragma unroll
         for (int q = 0; q < CU; ++q) len[q] = run_head_len(g[q]);
@@ -829,6 +902,7 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
         __syncthreads();
     }
     const uint32_t mx = sh->max_group;
+    pc.mark(phase0 + 2, tid == 0);
     // 4. flags (and, for the last step of a pair, the reductions over the finished flags)
     int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
     long long sabs = 0;
@@ -872,6 +946,7 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
         }
     }
     __syncthreads();
+    pc.mark(phase0 + 3, tid == 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -893,28 +968,81 @@ __device__ __forceinline__ int r4_bin(int v, int lo, int range)
     return range > 0 ? (int)((unsigned)(10 * (v - lo)) / (unsigned)range) : 10;
 }
 
+// the same quotient without an integer division per dot: a = 10*(v-lo) <= 10*131070 < 2^24 is exact in float,
+// the product with the rounded reciprocal is within 2e-6 of a/range, so the truncated value is off by at most
+// one and one exact integer remainder test repairs it.  lo <= v <= lo + range.
+struct R4Div {
+    int lo, range;
+    float inv;
+    __device__ __forceinline__ R4Div(int lo_, int range_) : lo(lo_), range(range_), inv(range_ > 0 ? 1.0f / (float)range_ : 0.0f) {}
+    __device__ __forceinline__ int bin(int v) const
+    {
+        if (range <= 0) return 10;
+        const int a = 10 * (v - lo);
+        int q = (int)((float)a * inv);
+        const int r = a - q * range;
+        q += (r >= range) ? 1 : 0;
+        q -= (r < 0) ? 1 : 0;
+        return q;
+    }
+};
+
+// c[b] += lanes whose key is b, b = 0..10; wave-uniform counters (ballots and scalar popcounts, no atomics)
+__device__ __forceinline__ void wave_hist11(uint32_t key, int (&c)[11])
+{
+#pragma unroll
+    for (int b = 0; b < 11; ++b) c[b] += __popcll(__ballot(key == (uint32_t)b));
+}
+__device__ __forceinline__ void flush_hist11(const int (&c)[11], int* dst)
+{
+    const int lane = threadIdx.x & 63;
+    int v = 0;
+#pragma unroll
+    for (int b = 0; b < 11; ++b) v = (lane == b) ? c[b] : v;
+    if (lane < 11 && v) atomicAdd(&dst[lane], v);
+}
+
 // kd_lo / kd_hi (min and max of i-j over the kept dots) must already be in *sh.
-template <typename HP, typename FP>
-__device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32_t* counters, CleanShared* sh)
+// CACHE: the level-1 list of every kept dot is parked in the upper nibble of its flag byte (LDS copy only; the
+// write-back masks it off), so the later passes neither divide again nor touch the dots of other lists.
+template <bool CACHE, typename HP, typename FP>
+__device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32_t* counters, CleanShared* sh, CleanClock& pc)
 {
     const int tid = threadIdx.x;
+    constexpr int CU = 4;
     if (tid == 0) { sh->n_lists = 0; sh->c2x = 0; sh->dir_n = 0; sh->dir_sum2 = 0; sh->win_w = -1; }
     if (tid < 11) sh->cnt1[tid] = 0;
     __syncthreads();
     const int lo1 = sh->kd_lo, range1 = sh->kd_hi - sh->kd_lo;
     if (range1 < 0) return;                        // no kept dots (uniform)
+    const R4Div d1(lo1, range1);
     // level 1: sizes of the eleven lists
-    for (int base = 0; base < n; base += CLEAN_THREADS) {
-        const int h = base + tid;
-        uint32_t key = INACTIVE_KEY;
-        if (h < n && (hflags[h] & HF_C1)) {
-            uint32_t x = hits[h];
-            key = (uint32_t)r4_bin((int)(x & 0xFFFFu) - (int)(x >> 16), lo1, range1);
+    {
+        int c[11];
+#pragma unroll
+        for (int b = 0; b < 11; ++b) c[b] = 0;
+        for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+            uint32_t key[CU];
+#pragma unroll
+            for (int q = 0; q < CU; ++q) {
+                const int h = base + q * CLEAN_THREADS + tid;
+                key[q] = INACTIVE_KEY;
+                if (h < n) {
+                    const uint32_t f = hflags[h];
+                    if (f & HF_C1) {
+                        const uint32_t x = hits[h];
+                        key[q] = (uint32_t)d1.bin((int)(x & 0xFFFFu) - (int)(x >> 16));
+                        if (CACHE) hflags[h] = (uint8_t)(f | (key[q] << 4));
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CU; ++q) wave_hist11(key[q], c);
         }
-        int len = run_head_len(key);
-        if (len) atomicAdd(&sh->cnt1[key], len);
+        flush_hist11(c, sh->cnt1);
     }
     __syncthreads();
+    pc.mark(32, tid == 0);
     int best1 = 0;
     for (int b = 0; b < 11; ++b) best1 = max(best1, sh->cnt1[b]);
     for (int w = 0; w < 11; ++w) {
@@ -923,30 +1051,43 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
         if (tid == 0) { sh->bin_lo = 0x7FFFFFFF; sh->bin_hi = -0x7FFFFFFF; }
         if (tid < 11) sh->cnt2[tid] = 0;
         __syncthreads();
+        auto in_list = [&](int h, int* d) -> bool {   // kept dot h belongs to list w; *d = its i - j
+            const uint32_t f = hflags[h];
+            if (!(f & HF_C1)) return false;
+            if (CACHE && (int)(f >> 4) != w) return false;
+            const uint32_t x = hits[h];
+            *d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+            return CACHE ? true : d1.bin(*d) == w;
+        };
         {
             int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+#pragma unroll 4
             for (int h = tid; h < n; h += CLEAN_THREADS) {
-                if (!(hflags[h] & HF_C1)) continue;
-                uint32_t x = hits[h];
-                int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-                if (r4_bin(d, lo1, range1) != w) continue;
-                lo = min(lo, d); hi = max(hi, d);
+                int d;
+                if (in_list(h, &d)) { lo = min(lo, d); hi = max(hi, d); }
             }
             lo = wave_min_i32(lo); hi = wave_max_i32(hi);
             if ((tid & 63) == 0) { atomicMin(&sh->bin_lo, lo); atomicMax(&sh->bin_hi, hi); }
         }
         __syncthreads();
         const int lo2 = sh->bin_lo, range2 = sh->bin_hi - sh->bin_lo;
-        for (int base = 0; base < n; base += CLEAN_THREADS) {
-            const int h = base + tid;
-            uint32_t key = INACTIVE_KEY;
-            if (h < n && (hflags[h] & HF_C1)) {
-                uint32_t x = hits[h];
-                int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-                if (r4_bin(d, lo1, range1) == w) key = (uint32_t)r4_bin(d, lo2, range2);
+        const R4Div d2(lo2, range2);
+        {
+            int c[11];
+#pragma unroll
+            for (int b = 0; b < 11; ++b) c[b] = 0;
+            for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+                uint32_t key[CU];
+#pragma unroll
+                for (int q = 0; q < CU; ++q) {
+                    const int h = base + q * CLEAN_THREADS + tid;
+                    int d;
+                    key[q] = (h < n && in_list(h, &d)) ? (uint32_t)d2.bin(d) : INACTIVE_KEY;
+                }
+#pragma unroll
+                for (int q = 0; q < CU; ++q) wave_hist11(key[q], c);
             }
-            int len = run_head_len(key);
-            if (len) atomicAdd(&sh->cnt2[key], len);
+            flush_hist11(c, sh->cnt2);
         }
         __syncthreads();
         if (tid == 0) {
@@ -960,45 +1101,69 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
         }
         __syncthreads();
     }
+    pc.mark(33, tid == 0);
     if (sh->n_lists == 1) {
         // median of the single longest sub-list: per-value counters over its value span
         const int w = sh->win_w, b = sh->win_b, lo2 = sh->win_lo2, range2 = sh->win_r2, m = sh->win_n;
+        const R4Div d2(lo2, range2);
         // values of sub-list b: 10*(v-lo2) in [b*range2, (b+1)*range2)  ->  v in [vlo, vhi]
         const int vlo = range2 > 0 ? lo2 + (b * range2 + 9) / 10 : lo2;
         const int vhi = range2 > 0 ? min(lo2 + range2, lo2 + ((b + 1) * range2 + 9) / 10 - 1) : lo2;
         const int width = vhi - vlo + 1;
         for (int q = tid; q < width; q += CLEAN_THREADS) counters[q] = 0;
         __syncthreads();
-        for (int base = 0; base < n; base += CLEAN_THREADS) {
-            const int h = base + tid;
-            uint32_t key = INACTIVE_KEY;
-            if (h < n && (hflags[h] & HF_C1)) {
-                uint32_t x = hits[h];
-                int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-                if (d >= vlo && d <= vhi && r4_bin(d, lo1, range1) == w && r4_bin(d, lo2, range2) == b)
-                    key = (uint32_t)(d - vlo);
+        for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+            uint32_t key[CU];
+#pragma unroll
+            for (int q = 0; q < CU; ++q) {
+                const int h = base + q * CLEAN_THREADS + tid;
+                key[q] = INACTIVE_KEY;
+                if (h < n) {
+                    const uint32_t f = hflags[h];
+                    if ((f & HF_C1) && (!CACHE || (int)(f >> 4) == w)) {
+                        const uint32_t x = hits[h];
+                        const int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
+                        if (d >= vlo && d <= vhi && (CACHE || d1.bin(d) == w) && d2.bin(d) == b) key[q] = (uint32_t)(d - vlo);
+                    }
+                }
             }
-            int len = run_head_len(key);
-            if (len) atomicAdd(&counters[key], (uint32_t)len);
+            int len[CU];
+#pragma unroll
+            for (int q = 0; q < CU; ++q) len[q] = run_head_len(key[q]);
+#pragma unroll
+            for (int q = 0; q < CU; ++q)
+                if (len[q]) atomicAdd(&counters[key[q]], (uint32_t)len[q]);
         }
         __syncthreads();
-        if (tid == 0) {
-            // order statistics (m-1)/2 and m/2, 0-based: np.median is their mean
-            int k0 = (m - 1) / 2, k1 = m / 2, acc = 0, v0 = 0, v1 = 0;
-            bool g0 = false, g1 = false;
-            for (int q = 0; q < width && !g1; ++q) {
-                acc += (int)counters[q];
-                if (!g0 && acc > k0) { v0 = vlo + q; g0 = true; }
-                if (!g1 && acc > k1) { v1 = vlo + q; g1 = true; }
+        // order statistics (m-1)/2 and m/2, 0-based: np.median is their mean.  Block prefix over the counters,
+        // the thread whose span holds a statistic walks its few counters.
+        {
+            const int per = (width + CLEAN_THREADS - 1) / CLEAN_THREADS;
+            const int q0 = min(tid * per, width), q1 = min(q0 + per, width);
+            uint32_t local = 0;
+            for (int q = q0; q < q1; ++q) local += counters[q];
+            uint32_t tot;
+            const uint32_t run = block_exclusive_scan(local, sh, &tot);
+            const uint32_t ks[2] = {(uint32_t)((m - 1) / 2), (uint32_t)(m / 2)};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (ks[t] >= run && ks[t] < run + local) {
+                    uint32_t acc = run;
+                    for (int q = q0; q < q1; ++q) {
+                        acc += counters[q];
+                        if (acc > ks[t]) { atomicAdd(&sh->c2x, vlo + q); break; }
+                    }
+                }
             }
-            sh->c2x = v0 + v1;
         }
     }
     __syncthreads();
+    pc.mark(34, tid == 0);
     {
         const int c2x = sh->c2x;
         int cn = 0;
         long long cs = 0;
+#pragma unroll 4
         for (int h = tid; h < n; h += CLEAN_THREADS) {
             if (!(hflags[h] & HF_C1)) continue;
             uint32_t x = hits[h];
@@ -1012,29 +1177,30 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
         if ((tid & 63) == 0) { atomicAdd(&sh->dir_n, cn); atomicAdd((unsigned long long*)&sh->dir_sum2, (unsigned long long)cs); }
     }
     __syncthreads();
+    pc.mark(35, tid == 0);
 }
 
 // everything after the hits are in place (LDS copy or global), for one pair
 template <bool NARROW, typename HP, typename FP>
 __device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPair& pr, int len2, int range_words,
-                                           uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, CleanShared* sh, long long* st)
+                                           uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, CleanShared* sh, long long* st, CleanClock& pc)
 {
     const int tid = threadIdx.x;
     const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u, s3 = (pr.flags & 4u) && c1;
     // i - j over all dots (its bitmap was filled while the hits were staged): C1's diagonal groups (>10)
     // and C2's diagonal step; then i + j over all dots (C1) and / or over the dots the diagonal step left (C2)
     if (c1 && c2) {
-        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D);
-        cluster_axis<true, NARROW, false, false>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u);
-        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
+        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
+        cluster_axis<true, NARROW, false, false>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
+        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     } else if (c1) {
-        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u);
-        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u);
+        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
+        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
     } else if (c2) {
-        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D);
-        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A);
+        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
+        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     }
-    if (s3) directed_stats(hits, hflags, n, gcnt, sh);
+    if (s3) directed_stats<NARROW>(hits, hflags, n, gcnt, sh, pc);
     if (tid == 0) {
         st[0] = n; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
         st[5] = sh->c2_kept; st[6] = sh->c2_count10; st[7] = sh->n_diag; st[8] = sh->n_lower; st[9] = sh->c2_kept_diag;
@@ -1043,52 +1209,39 @@ __device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPai
     }
 }
 
-// One workgroup per pair.  Dynamic LDS: bitmap (range_words_cap words) | wrank (u16 each) | group sizes
-// | hit copy (hcap words) | flag bytes (hcap).  Pairs with at most hcap hits are cleaned entirely out of
-// LDS with 16-bit group counters (groups_cap / 2 words); larger ones stream their hits from L2/HBM on
-// every pass and use 32-bit counters (the region then extends over the unused hit copy).
-__global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
-    const SeqDesc* __restrict__ seqs, const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
-    const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
-    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
-    unsigned int* __restrict__ overflow)
+// One pair.  Dynamic LDS: bitmap (range_words_cap words) | wrank (u16 each) | group sizes | (IN_LDS: hit copy
+// (hcap words) | flag bytes (hcap)).
+template <bool IN_LDS>
+__device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh, const DPair& pr, int n, int len2,
+                                           int range_words, const uint32_t* __restrict__ hits_all,
+                                           uint8_t* __restrict__ hflags_all, long long* __restrict__ stats,
+                                           int range_words_cap, int groups_cap, int hcap)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    __shared__ CleanShared sh;
     const int tid = threadIdx.x;
-    const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
-    const DPair pr = pairs[p];
     long long* st = stats + (size_t)p * 16;
-    const unsigned long long nh = n_hits[p];
-    if (nh > (unsigned long long)pr.cap || nh == 0ULL) {
-        if (tid < 16) {
-            long long v = 0;
-            if (tid == 0) v = (long long)nh;
-            if (tid == 1 || tid == 2) v = -1;
-            if (tid == 15 && nh) v = -2;      // VAPOR_E_OVERFLOW: rerun with cap >= n_hits
-            st[tid] = v;
-        }
-        if (tid == 0 && nh && overflow) atomicAdd(overflow, 1u);
-        return;
-    }
-    const int n = (int)nh;                     // cap < 2^31
+    CleanClock pc;
     const uint32_t* ghits = hits_all + pr.hit_off;
     uint8_t* gflags = hflags_all + pr.hit_off;
-    const int len1 = seqs[pr.seq1].len, len2 = seqs[pr.seq2].len;
-    const int range_words = min((len1 + len2 + 2 + 31) >> 5, range_words_cap);
+    // the first dots of every thread are requested before anything else touches memory: global latency, not
+    // bandwidth, is what this pass waits for
+    constexpr int CU = 4;
+    uint32_t x[CU];
+#pragma unroll
+    for (int q = 0; q < CU; ++q) {
+        const int h = q * CLEAN_THREADS + tid;
+        x[q] = h < n ? ghits[h] : 0u;
+    }
     uint32_t* bm = lds;
     uint16_t* wrank = reinterpret_cast<uint16_t*>(bm + range_words_cap);
     uint32_t* gcnt = bm + range_words_cap + (range_words_cap + 1) / 2;
     uint32_t* lhits = gcnt + (groups_cap + 1) / 2;
     uint8_t* lflags = reinterpret_cast<uint8_t*>(lhits + hcap);
-    const bool in_lds = n <= hcap;
 
     if (tid == 0) {
         sh.min_j = 0x7FFFFFFF; sh.max_j = -1; sh.n_diag = 0; sh.n_lower = 0;
         sh.c1_kept = 0; sh.c2_kept = 0; sh.c2_count10 = 0; sh.c2_kept_diag = 0; sh.c1_sum_abs = 0ULL;
         sh.kd_lo = 0x7FFFFFFF; sh.kd_hi = -0x7FFFFFFF;
     }
-    __syncthreads();
     // pass 0: first/last j, diagonal and lower-triangle counts; stage the hits, clear the flags, and fill
     // the occupancy bitmap of i - j for the first clustering step
     const bool any_axis = (pr.flags & 3u) != 0u;
@@ -1096,19 +1249,34 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     __syncthreads();
     {
         int mn = 0x7FFFFFFF, mx = -1, nd = 0, nl = 0;
-        for (int base = 0; base < n; base += CLEAN_THREADS) {
-            const int h = base + tid;
-            uint32_t v = INACTIVE_KEY;
-            if (h < n) {
-                uint32_t x = ghits[h];
-                int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-                mn = min(mn, j); mx = max(mx, j);
-                nd += (j == i); nl += (j > i);
-                if (in_lds) { lhits[h] = x; lflags[h] = 0; }
-                else gflags[h] = 0;
-                if (any_axis) v = (uint32_t)(i - j + len2);
+        for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
+            uint32_t v[CU];
+            if (base) {
+#pragma unroll
+                for (int q = 0; q < CU; ++q) {
+                    const int h = base + q * CLEAN_THREADS + tid;
+                    x[q] = h < n ? ghits[h] : 0u;
+                }
             }
-            if (run_head_len(v)) atomicOr(&bm[v >> 5], 1u << (v & 31));
+#pragma unroll
+            for (int q = 0; q < CU; ++q) {
+                const int h = base + q * CLEAN_THREADS + tid;
+                v[q] = INACTIVE_KEY;
+                if (h < n) {
+                    const int j = (int)(x[q] >> 16), i = (int)(x[q] & 0xFFFFu);
+                    mn = min(mn, j); mx = max(mx, j);
+                    nd += (j == i); nl += (j > i);
+                    if (IN_LDS) { lhits[h] = x[q]; lflags[h] = 0; }
+                    else gflags[h] = 0;
+                    if (any_axis) v[q] = (uint32_t)(i - j + len2);
+                }
+            }
+            int head[CU];
+#pragma unroll
+            for (int q = 0; q < CU; ++q) head[q] = run_head_len(v[q]);
+#pragma unroll
+            for (int q = 0; q < CU; ++q)
+                if (head[q] && !(bm[v[q] >> 5] & (1u << (v[q] & 31)))) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
         }
         mn = wave_min_i32(mn); mx = wave_max_i32(mx); nd = wave_sum_i32(nd); nl = wave_sum_i32(nl);
         if ((tid & 63) == 0) {
@@ -1117,12 +1285,72 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
         }
     }
     __syncthreads();
-    if (in_lds) {
-        clean_body<true>((const uint32_t*)lhits, lflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st);
+    pc.mark(8, tid == 0);                          // pass 0
+    if (IN_LDS) {
+        clean_body<true>((const uint32_t*)lhits, lflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
         __syncthreads();
-        for (int h = tid; h < n; h += CLEAN_THREADS) gflags[h] = lflags[h];
+        pc.mark(9, tid == 0);                      // what the nested stamps left of clean_body
+        for (int h = tid; h < n; h += CLEAN_THREADS) gflags[h] = lflags[h] & 7u;
+        pc.mark(10, tid == 0);
     } else {
-        clean_body<false>(ghits, gflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st);
+        clean_body<false>(ghits, gflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+    }
+    pc.flush(tid == 0);
+}
+
+// One workgroup per pair: pairs with at most hcap hits are cleaned entirely out of LDS with 16-bit group
+// counters; the others are appended to big_list for clean_big_kernel (or, without a list, reported in stats).
+// len2 and the value range come with the pair record, so the only dependent global reads before the dots are
+// the pair record and its hit count.
+__global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
+    const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
+    const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
+    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
+    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ CleanShared sh;
+    const int tid = threadIdx.x;
+    const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
+    const DPair pr = pairs[p];
+    const unsigned long long nh = n_hits[p];
+    if (nh > (unsigned long long)pr.cap || nh == 0ULL) {
+        long long* st = stats + (size_t)p * 16;
+        if (tid < 16) {
+            long long v = 0;
+            if (tid == 0) v = (long long)nh;
+            if (tid == 1 || tid == 2) v = -1;
+            if (tid == 15 && nh) v = -2;      // VAPOR_E_OVERFLOW: rerun with cap >= n_hits
+            st[tid] = v;
+        }
+        if (tid == 0 && nh && overflow) atomicAdd(&overflow[0], 1u);
+        return;
+    }
+    const int n = (int)nh;                     // cap < 2^31
+    if (n > hcap) {
+        if (tid == 0) big_list[atomicAdd(&overflow[1], 1u)] = p;
+        return;
+    }
+    clean_pair<true>(p, lds, sh, pr, n, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap), hits_all, hflags_all,
+                     stats, range_words_cap, groups_cap, hcap);
+}
+
+// The pairs clean_kernel left (more dots than the LDS copy holds): the dots stream from L2/HBM on every pass,
+// group sizes are 32-bit.  A fixed grid walks the list; workgroups beyond its length leave at once.
+__global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
+    const DPair* __restrict__ pairs, const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
+    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap,
+    const unsigned int* __restrict__ overflow, const int32_t* __restrict__ big_list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ CleanShared sh;
+    const unsigned int n_big = overflow[1];
+    for (unsigned int b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const int p = big_list[b];
+        const DPair pr = pairs[p];
+        __syncthreads();                       // the previous pair's statistics have been read
+        clean_pair<false>(p, lds, sh, pr, (int)n_hits[p], pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
+                          hits_all, hflags_all, stats, range_words_cap, groups_cap, 0);
     }
 }
 
