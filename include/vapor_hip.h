@@ -118,6 +118,9 @@ int vapor_plan_run(vapor_plan* plan, int64_t* stats);
  * library's stream: ms[0] = join kernels, ms[1] = clean kernel, ms[2] = whole run incl. copies,
  * ms[3] = number of join launches, ms[4] = number of retried pairs, ms[5] = finish kernel */
 int vapor_plan_timings(vapor_plan* plan, double* ms, int32_t n);
+/* run records the join of the last run wrote per pair (n_pairs int64): the device keeps runs of consecutive
+ * dots (j+t, i+t) / (j-t, i+t) as one record; stats[0] stays the number of dots */
+int vapor_plan_record_counts(vapor_plan* plan, int64_t* records);
 /* algorithmic bytes of one run: sum over pairs of packed read + packed allele
  * + 8 B per hit + 128 B statistics record, using the hit counts of the last run */
 int vapor_plan_algorithmic_bytes(vapor_plan* plan, int64_t* bytes, int64_t* cells);

@@ -71,8 +71,8 @@ struct vapor_plan {
     DPair* d_pairs = nullptr;
     DTask* d_tasks = nullptr;
     int32_t* d_task_pairs = nullptr;
-    uint32_t* d_hits = nullptr;
-    uint8_t* d_hflags = nullptr;
+    unsigned long long* d_hits = nullptr;   // run records (VREC_*), hp[].cap slots per pair
+    uint8_t* d_hflags = nullptr;            // one flag byte per record
     unsigned long long* d_nhits = nullptr;
     long long* d_stats = nullptr;
     long long* h_stats = nullptr;  // pinned
@@ -312,7 +312,7 @@ static int plan_alloc_hits(vapor_plan* p)
     tot += 4;
     (void)hipFree(p->d_hits); p->d_hits = nullptr;
     (void)hipFree(p->d_hflags); p->d_hflags = nullptr;
-    HIPCHK(hipMalloc((void**)&p->d_hits, (size_t)tot * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&p->d_hits, (size_t)tot * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void**)&p->d_hflags, (size_t)tot));
     p->total_cap = tot;
     HIPCHK(hipMemcpyAsync(p->d_pairs, p->hp.data(), sizeof(DPair) * p->hp.size(), hipMemcpyHostToDevice, p->ctx->stream));
@@ -358,7 +358,8 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         d.cap = (uint32_t)std::min<int64_t>(cap, ctx->max_pair_cap);
         mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : 2;
         rw = std::max(rw, (s1.len + s2.len + 2 + 31) / 32);
-        hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 2 + ((n1 * n2) >> 19) + 256);
+        // records expected: the shared diagonal in runs of a few dots plus the chance dots
+        hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 8 + ((n1 * n2) >> 19) + 256);
         if (s1.len - a.k + 1 > 0 && s2.len - a.k + 1 > 0) order.push_back((int32_t)i);
     }
     p->range_words_cap = rw;
@@ -470,7 +471,7 @@ static int clean_hcap(int range_words_cap, int want)
     for (int per_cu = 4; per_cu >= 1; --per_cu) {
         const size_t share = (size_t)(160 * 1024) / per_cu - 512;
         if (share <= fixed) continue;
-        const int cap = (int)std::min<size_t>(std::min<size_t>((share - fixed) / 5, (size_t)want), 65532) & ~3;
+        const int cap = (int)std::min<size_t>(std::min<size_t>((share - fixed) / 9, (size_t)want), 65532) & ~3;
         if (cap >= want * 9 / 10 || per_cu == 1) { best = cap; break; }
     }
     return std::max(best, 0);
@@ -478,7 +479,7 @@ static int clean_hcap(int range_words_cap, int want)
 
 static size_t clean_lds_bytes(int range_words_cap, int hcap)
 {
-    return clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 5;
+    return clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 9 + 8;
 }
 
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
@@ -549,8 +550,8 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
         int64_t grow = 0;
         for (int64_t i = 0; i < p->n_pairs; ++i) {
             const long long* s = p->h_stats + 16 * i;
-            if (s[15] == VAPOR_E_OVERFLOW && s[0] <= p->ctx->max_pair_cap && (uint32_t)s[0] > p->hp[i].cap) {
-                p->hp[i].cap = (uint32_t)s[0];
+            if (s[15] == VAPOR_E_OVERFLOW && s[14] <= p->ctx->max_pair_cap && (uint32_t)s[14] > p->hp[i].cap) {
+                p->hp[i].cap = (uint32_t)s[14];     // records the pair produced
                 ++grow;
             }
         }
@@ -578,6 +579,17 @@ extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
     double v[6] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish};
     for (int i = 0; i < n && i < 6; ++i) ms[i] = v[i];
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_record_counts(vapor_plan* p, int64_t* records)
+{
+    if (!p || !records) return fail(VAPOR_E_ARG, "vapor_plan_record_counts: null argument");
+    if (!p->ran) return fail(VAPOR_E_ARG, "vapor_plan_record_counts: plan has not been run");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    std::vector<unsigned long long> cnt((size_t)std::max<int64_t>(p->n_pairs, 1));
+    HIPCHK(hipMemcpy(cnt.data(), p->d_nhits, sizeof(unsigned long long) * (size_t)p->n_pairs, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < p->n_pairs; ++i) records[i] = (int64_t)(uint32_t)cnt[i];
     return VAPOR_OK;
 }
 
@@ -616,7 +628,13 @@ extern "C" int vapor_plan_fetch_hits(vapor_plan* p, int64_t n_sel, const int64_t
     if (off[n_sel] > capacity) return fail(VAPOR_E_OVERFLOW, "hit buffer too small");
     if (n_sel == 0 || off[n_sel] == 0) return VAPOR_OK;
     if (!hits_ji) return fail(VAPOR_E_ARG, "null hit buffer");
-    long long *d_sel = nullptr, *d_off = nullptr;
+    // record counts of the selected pairs (the low half of the join's packed counters)
+    std::vector<unsigned long long> cnt((size_t)p->n_pairs);
+    HIPCHK(hipMemcpy(cnt.data(), p->d_nhits, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost));
+    std::vector<long long> nrec((size_t)n_sel, 0);
+    for (int64_t q = 0; q < n_sel; ++q)
+        if (off[q + 1] > off[q]) nrec[q] = (long long)(uint32_t)cnt[sel[q]];
+    long long *d_sel = nullptr, *d_off = nullptr, *d_nrec = nullptr;
     int32_t* d_ji = nullptr;
     uint8_t* d_fl = nullptr;
     int rc = VAPOR_OK;
@@ -626,21 +644,23 @@ extern "C" int vapor_plan_fetch_hits(vapor_plan* p, int64_t n_sel, const int64_t
     hipStream_t st = p->ctx->stream;
     chk(hipMalloc((void**)&d_sel, sizeof(long long) * sel.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_off, sizeof(long long) * off.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_nrec, sizeof(long long) * nrec.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_ji, sizeof(int32_t) * 2 * (size_t)off[n_sel]), "hipMalloc");
     if (hit_flags) chk(hipMalloc((void**)&d_fl, (size_t)off[n_sel]), "hipMalloc");
     if (rc == VAPOR_OK) {
         chk(hipMemcpyAsync(d_sel, sel.data(), sizeof(long long) * sel.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemcpyAsync(d_nrec, nrec.data(), sizeof(long long) * nrec.size(), hipMemcpyHostToDevice, st), "copy");
     }
     if (rc == VAPOR_OK) {
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, p->d_pairs, d_sel, d_off, p->d_hits,
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, p->d_pairs, d_sel, d_off, d_nrec, p->d_hits,
                            p->d_hflags, d_ji, d_fl);
         chk(hipGetLastError(), "gather launch");
         chk(hipMemcpyAsync(hits_ji, d_ji, sizeof(int32_t) * 2 * (size_t)off[n_sel], hipMemcpyDeviceToHost, st), "copy");
         if (hit_flags) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)off[n_sel], hipMemcpyDeviceToHost, st), "copy");
         chk(hipStreamSynchronize(st), "sync");
     }
-    (void)hipFree(d_sel); (void)hipFree(d_off); (void)hipFree(d_ji); (void)hipFree(d_fl);
+    (void)hipFree(d_sel); (void)hipFree(d_off); (void)hipFree(d_nrec); (void)hipFree(d_ji); (void)hipFree(d_fl);
     return rc;
 }
 
@@ -707,7 +727,11 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     if (tot && !hits_ji) return fail(VAPOR_E_ARG, "vapor_clean_hits: null hit list");
     std::vector<DPair> dp((size_t)n_lists);
     std::vector<unsigned long long> nh((size_t)n_lists);
-    std::vector<uint32_t> packed((size_t)std::max<int64_t>(tot, 1));
+    // device layout: one record per dot, every list's slot padded to a multiple of four records (the kernels
+    // store flag bytes four at a time)
+    std::vector<int64_t> poff((size_t)n_lists + 1, 0);
+    for (int64_t t = 0; t < n_lists; ++t) poff[t + 1] = poff[t] + ((off[t + 1] - off[t] + 3) & ~(int64_t)3);
+    std::vector<unsigned long long> packed((size_t)std::max<int64_t>(poff[n_lists], 4), 0ull);
     int rw = 1;
     for (int64_t t = 0; t < n_lists; ++t) {
         int mi = 0, mj = 0;
@@ -716,19 +740,19 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
             if (j < 0 || i < 0 || j > VAPOR_MAX_SEQ_LEN || i > VAPOR_MAX_SEQ_LEN)
                 return fail(VAPOR_E_ARG, "vapor_clean_hits: coordinate out of range");
             mi = std::max(mi, i); mj = std::max(mj, j);
-            packed[h] = ((uint32_t)j << 16) | (uint32_t)i;
+            packed[poff[t] + (h - off[t])] = (unsigned long long)(((uint32_t)j << 16) | (uint32_t)i) | (1ull << 32);
         }
         DPair& d = dp[t];
         d.seq1 = (int32_t)(2 * t); d.seq2 = (int32_t)(2 * t + 1); d.off2 = 0; d.k = 10;
         d.len1 = mi + 1; d.len2 = mj + 1;
         d.flags = flags ? flags[t] : 3u;
         d.cap = (uint32_t)(off[t + 1] - off[t]);
-        d.hit_off = off[t];
-        nh[t] = (unsigned long long)(off[t + 1] - off[t]);
+        d.hit_off = poff[t];
+        nh[t] = (unsigned long long)(off[t + 1] - off[t]) * 0x100000001ull;   // records | dots << 32
         rw = std::max(rw, (mi + mj + 4 + 31) / 32);
     }
     DPair* d_dp = nullptr; unsigned long long* d_nh = nullptr; unsigned int* d_ov = nullptr; int32_t* d_big = nullptr;
-    uint32_t* d_hits = nullptr; uint8_t* d_fl = nullptr; long long* d_st = nullptr;
+    unsigned long long* d_hits = nullptr; uint8_t* d_fl = nullptr; long long* d_st = nullptr;
     int rc = VAPOR_OK;
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -738,14 +762,14 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     chk(hipMalloc((void**)&d_big, sizeof(int32_t) * dp.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_dp, sizeof(DPair) * dp.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_nh, sizeof(unsigned long long) * nh.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_hits, sizeof(uint32_t) * packed.size()), "hipMalloc");
+    chk(hipMalloc((void**)&d_hits, sizeof(unsigned long long) * packed.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_fl, packed.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_st, sizeof(long long) * 16 * (size_t)n_lists), "hipMalloc");
     if (rc == VAPOR_OK) {
         chk(hipMemsetAsync(d_ov, 0, 2 * sizeof(unsigned int), st), "memset");
         chk(hipMemcpyAsync(d_dp, dp.data(), sizeof(DPair) * dp.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_nh, nh.data(), sizeof(unsigned long long) * nh.size(), hipMemcpyHostToDevice, st), "copy");
-        chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(uint32_t) * packed.size(), hipMemcpyHostToDevice, st), "copy");
+        chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(unsigned long long) * packed.size(), hipMemcpyHostToDevice, st), "copy");
     }
     if (rc == VAPOR_OK) {
         int hcap = clean_hcap(rw, 4096);
@@ -756,8 +780,11 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);
         chk(hipGetLastError(), "clean launch");
         chk(hipMemcpyAsync(stats, d_st, sizeof(long long) * 16 * (size_t)n_lists, hipMemcpyDeviceToHost, st), "copy");
-        if (hit_flags && tot) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)tot, hipMemcpyDeviceToHost, st), "copy");
+        std::vector<uint8_t> fl(hit_flags && tot ? packed.size() : 0);
+        if (!fl.empty()) chk(hipMemcpyAsync(fl.data(), d_fl, fl.size(), hipMemcpyDeviceToHost, st), "copy");
         chk(hipStreamSynchronize(st), "sync");
+        if (!fl.empty() && rc == VAPOR_OK)
+            for (int64_t t = 0; t < n_lists; ++t) memcpy(hit_flags + off[t], fl.data() + poff[t], (size_t)(off[t + 1] - off[t]));
     }
     (void)hipFree(d_ov); (void)hipFree(d_big); (void)hipFree(d_dp); (void)hipFree(d_nh); (void)hipFree(d_hits); (void)hipFree(d_fl); (void)hipFree(d_st);
     return rc;

@@ -362,19 +362,53 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
     return wave_scan<OpAdd>(v, 0u);
 }
 
+// ------------------------------------------------------------------------------------------
+// Dot records.  The join does not write single dots but RUNS of dots: a dot (j, i) of the same strand is
+// followed by (j+1, i+1) exactly when read[i+K] == allele[j+K], a reverse-complement dot by (j-1, i+1) exactly
+// when allele[j-1] == comp(read[i+K]); long reads make such runs several dots long (tens for accurate reads).
+//   bits  0..15  i of the first dot        bits 32..47  number of dots (1..32)
+//   bits 16..31  j of the first dot        bit  48      0: (j+t, i+t)   1: (j-t, i+t)
+// A run never crosses a 32-aligned read position of its strip nor an allele tile, so whether a dot starts a
+// run is decided from the two sequences alone (the symbol before it differs, or it sits on such a boundary)
+// and every dot belongs to exactly one record.  All dots of a record share their diagonal group AND their
+// anti-diagonal group (consecutive values differ by 0 or 2 < 10), so the cleaning flags are per record.
+// The join forms runs only of same-strand dots and only in the plain case (2-bit planes, no exception symbol on
+// either side); every other dot is its own record (the format and the cleaning kernels take reverse-complement
+// runs all the same).
+#define VREC_I(r) ((int)((r) & 0xFFFFull))
+#define VREC_J(r) ((int)(((r) >> 16) & 0xFFFFull))
+#define VREC_LEN(r) ((int)(((r) >> 32) & 0xFFFFull))
+#define VREC_RC(r) ((bool)(((r) >> 48) & 1ull))
+#define VREC_MAX_LEN 32
+
+__device__ __forceinline__ uint32_t sym2(const uint32_t* plane, uint32_t pos)
+{
+    return (plane[pos >> 4] >> ((pos & 15u) * 2u)) & 3u;
+}
+// the 32 symbols from position pos of a 2-bit plane (reads three words)
+__device__ __forceinline__ unsigned long long win2(const uint32_t* plane, uint32_t pos)
+{
+    const uint32_t wi = pos >> 4, sh = (pos & 15u) * 2u;
+    const uint32_t w0 = plane[wi], w1 = plane[wi + 1], w2 = plane[wi + 2];
+    return ((unsigned long long)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+}
+
 // verify queued candidates [from, from+n), n <= 128, two per lane so that their LDS reads overlap.
-// item = local read position << 16 | entry slot.  The entry's k-mer is compared with the read
-// k-mer in both orientations; hits are compacted with ballots, staged in the (already consumed)
-// queue slots and written out as one contiguous run with ONE counter update per call.
+// item = local read position << 16 | entry slot.  The entry's k-mer is compared with the read k-mer in both
+// orientations.  Same-strand dots (about a third of the candidates) are compacted into the queue slots this
+// call has consumed, and 64 of them at a time decide whether they start a run, measure it and write the
+// records as one contiguous piece.  Reverse-complement dots are few outside inversions and are written as
+// single-dot records at once.  The counter moves once per piece: cnt += records | dots << 32.
 template <int BPS, int K>
 __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
-                                            const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2,
-                                            unsigned long long* cnt_r, uint32_t cap, uint32_t* out)
+                                            const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
+                                            int nk1, bool merge, unsigned long long* cnt_r, uint32_t cap,
+                                            unsigned long long* out)
 {
     using KT = KeyT<BPS, K>;
     const int lane = threadIdx.x & 63;
-    bool hf[2] = {false, false}, hr[2] = {false, false};
-    uint32_t val[2] = {0, 0};
+    bool hit[4] = {false, false, false, false};    // q * 2 + orientation
+    uint32_t who[2] = {0u, 0u};                    // il | e << 11
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int idx = q * 64 + lane;
@@ -385,54 +419,73 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
             KT kf = extract_key<BPS, K>(rbuf, il);
             KT a = extract_key<BPS, K>(tile, e);
             KT kr = revcomp_key<BPS, K>(kf);
-            const int jf = ts + (int)e;
-            const bool in = jf >= off2;
-            hf[q] = in && (a == kf);
-            hr[q] = in && (a == kr);
-            val[q] = ((uint32_t)(jf - off2) << 16) | (uint32_t)(cb + (int)il);
+            const bool in = ts + (int)e >= off2;
+            hit[q * 2] = in && (a == kf);
+            hit[q * 2 + 1] = in && (a == kr);
+            who[q] = il | (e << 11);
         }
     }
-    const unsigned long long m0 = __ballot(hf[0]), m1 = __ballot(hr[0]), m2 = __ballot(hf[1]), m3 = __ballot(hr[1]);
+    const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]), m2 = __ballot(hit[2]), m3 = __ballot(hit[3]);
     const uint32_t n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-    const uint32_t tot = n0 + n1 + n2 + n3;
-    if (tot == 0) return;
-    // stage the hits contiguously (tot <= 256 <= 2 * 128 queue slots; the items are in registers now)
-    uint32_t* stage = myq + from;
-    const bool fits = tot <= (uint32_t)n;
+    uint32_t dots = n0 + n1 + n2 + n3;             // not yet added to the counter
+    if (dots == 0) return;
     auto rank = [&](unsigned long long m) {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
-    const uint32_t r0 = rank(m0), r1 = n0 + rank(m1), r2 = n0 + n1 + rank(m2), r3 = n0 + n1 + n2 + rank(m3);
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(cnt_r, (unsigned long long)tot);
-    base = __shfl(base, 0, 64);
-    if (fits) {
-        if (hf[0]) stage[r0] = val[0];
-        if (hr[0]) stage[r1] = val[0];
-        if (hf[1]) stage[r2] = val[1];
-        if (hr[1]) stage[r3] = val[1];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t x = q * 64 + lane;
-            if (x < tot) {
-                const uint32_t v = stage[x];
-                const unsigned long long sl = base + x;
-                if (sl < cap) out[sl] = v;
-            }
+    auto record = [&](uint32_t w, int len, uint32_t rc) -> unsigned long long {
+        const uint32_t il = w & 0x7FFu, e = (w >> 11) & 0x7FFFu;
+        return (unsigned long long)(((uint32_t)(ts + (int)e - off2) << 16) | (uint32_t)(cb + (int)il)) |
+               ((unsigned long long)len << 32) | ((unsigned long long)rc << 48);
+    };
+    uint32_t n_rc = n1 + n3;                        // reverse-complement records not yet written
+    const uint32_t r1 = rank(m1), r3 = n1 + rank(m3);
+    const uint32_t cnt = n0 + n2;                   // same-strand dots: at most 128, the slots [from, from+128) are free
+    uint32_t* stage = myq + from;
+    if (hit[0]) stage[rank(m0)] = who[0];
+    if (hit[2]) stage[n0 + rank(m2)] = who[1];
+    const int emin = max(0, off2 - ts);            // first allele position of this tile that may carry a dot
+    uint32_t c0 = 0;
+    do {
+        const bool act = c0 + (uint32_t)lane < cnt;
+        const uint32_t w = act ? stage[c0 + lane] : 0u;
+        bool head = act;
+        int len = 1;
+        if (BPS == 2 && merge) {
+            const uint32_t il = w & 0x7FFu, e = (w >> 11) & 0x7FFFu;
+            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
+            const bool pred = (il & (VREC_MAX_LEN - 1)) && (int)e > emin && sym2(rbuf, il ? il - 1u : 0u) == sym2(tile, e ? e - 1u : 0u);
+            head = act && !pred;
+            // length: the symbols after the k-mer, compared 32 at a time
+            const unsigned long long x = win2(rbuf, il + K) ^ win2(tile, e + K);
+            const int ext = x ? ((__ffsll((long long)x) - 1) >> 1) : 32;
+            len = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e));
         }
-    } else {
-        if (hf[0] && base + r0 < cap) out[base + r0] = val[0];
-        if (hr[0] && base + r1 < cap) out[base + r1] = val[0];
-        if (hf[1] && base + r2 < cap) out[base + r2] = val[1];
-        if (hr[1] && base + r3 < cap) out[base + r3] = val[1];
-    }
+        const unsigned long long hm = __ballot(head);
+        const uint32_t nh = __popcll(hm);
+        if (nh + n_rc) {
+            unsigned long long old = 0;
+            if (lane == 0) old = atomicAdd(cnt_r, (unsigned long long)(nh + n_rc) | ((unsigned long long)dots << 32));
+            dots = 0;
+            uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
+            if (n_rc) {
+                if (hit[1] && base + r1 < cap) out[base + r1] = record(who[0], 1, 1u);
+                if (hit[3] && base + r3 < cap) out[base + r3] = record(who[1], 1, 1u);
+                base += n_rc;
+                n_rc = 0;
+            }
+            const uint32_t slot = base + rank(hm);
+            if (head && slot < cap) out[slot] = record(w, len, 0u);
+        }
+        c0 += 64;
+    } while (c0 < cnt);
+    if (dots && lane == 0) atomicAdd(cnt_r, (unsigned long long)dots << 32);   // a piece of continuation dots only
 }
 
 template <typename C, int BPS, int K>
 __global__ __launch_bounds__(C::THREADS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
-    const int32_t* __restrict__ task_pairs, uint32_t* __restrict__ hits, unsigned long long* __restrict__ n_hits)
+    const int32_t* __restrict__ task_pairs, unsigned long long* __restrict__ hits, unsigned long long* __restrict__ n_hits)
 {
     using KT = KeyT<BPS, K>;
     constexpr int TA = tile_pos<C, BPS>();
@@ -568,7 +621,8 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                     const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
                     const uint32_t* re = e1 + (size_t)s1.chunk0;
                     const bool exc1 = (BPS == 2) && s1.n_exc > 0;
-                    uint32_t* out = hits + pr.hit_off;
+                    unsigned long long* out = hits + pr.hit_off;
+                    const bool merge = (BPS == 2) && !exc1 && !exc2;
                     // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
                     {
                         const int nw = min(rbuf_words<BPS>(), (int)((((size_t)(nk1 + K - 1 - cb)) * BPS + 31) >> 5) + 2);
@@ -655,8 +709,8 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                                     }
                                     qlen += __popcll(m);
                                     if (qlen >= 128) {
-                                        join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2,
-                                                            &cnt[r], pr.cap, out);
+                                        join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, tn,
+                                                            nk1, merge, &cnt[r], pr.cap, out);
                                         qlen -= 128;
                                     }
                                 }
@@ -675,8 +729,8 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                             qlen += (int)tot;
                             if (qlen >= 128) {
                                 pc.mark(4, pw);            // queue fill
-                                join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, &cnt[r],
-                                                    pr.cap, out);
+                                join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, tn, nk1,
+                                                    merge, &cnt[r], pr.cap, out);
                                 qlen -= 128;
                                 pc.mark(5, pw);            // verify + store
                             }
@@ -685,7 +739,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                     }
                     // the strip changes: drain
                     if (qlen > 0)
-                        join_verify<BPS, K>(myq, 0, qlen, entries, rbuf, tile, cb, ts, pr.off2, &cnt[r], pr.cap, out);
+                        join_verify<BPS, K>(myq, 0, qlen, entries, rbuf, tile, cb, ts, pr.off2, tn, nk1, merge, &cnt[r], pr.cap, out);
                     pc.mark(5, pw);
                 }
             }
@@ -699,7 +753,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// clean kernel
+// clean kernels
 // ------------------------------------------------------------------------------------------
 // wave reductions: every lane gets the result
 __device__ __forceinline__ int wave_sum_i32(int v)
@@ -733,23 +787,6 @@ struct CleanShared {
     long long dir_sum2;
 };
 
-#define INACTIVE_KEY 0xFFFFFFFFu
-
-// Lanes of a wave hold `key` for consecutive hits.  For every maximal run of equal keys the
-// run's first lane gets the run length, every other lane 0 (runs of INACTIVE_KEY get 0 too), so
-// one LDS atomic per run replaces one per lane: dots on one diagonal come in long runs, and
-// same-address LDS atomics serialise.  Must be called by all 64 lanes.
-__device__ __forceinline__ int run_head_len(uint32_t key)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, false);   // wave_shr:1
-    bool head = (lane == 0) || (key != prev);
-    unsigned long long m = __ballot(head);
-    unsigned long long above = (lane == 63) ? 0ULL : (m >> (lane + 1));
-    int len = above ? __ffsll((long long)above) : (64 - lane);
-    return (head && key != INACTIVE_KEY) ? len : 0;
-}
-
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanShared* sh, uint32_t* total)
 {
     const int tid = threadIdx.x;
@@ -767,20 +804,54 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t local, CleanSh
     return base + incl - local;
 }
 
+// The cleaning works on the join's run records (see VREC_*): `len` dots (j0 + s*t, i0 + t), s = +1 or -1.
+// Along a record i - j is constant (s = +1) or grows by 2 per dot (s = -1); i + j the other way round.
+struct RecV {
+    int i0, j0, len;
+    bool rc;
+};
+__device__ __forceinline__ RecV rec_decode(unsigned long long r)
+{
+    RecV v;
+    v.i0 = VREC_I(r); v.j0 = VREC_J(r); v.len = VREC_LEN(r); v.rc = VREC_RC(r);
+    return v;
+}
+
+// marks the values v0, v0 + 2, ... (len of them; a single value when !strided) in an occupancy bitmap.
+// Most values are marked already: look before the atomic (a stale look only costs a redundant atomic).
+__device__ __forceinline__ void mark_values(uint32_t* bm, uint32_t v0, int len, bool strided)
+{
+    const uint32_t w = v0 >> 5, sh = v0 & 31u;
+    if (!strided || len == 1) {
+        const uint32_t bit = 1u << sh;
+        if (!(bm[w] & bit)) atomicOr(&bm[w], bit);
+        return;
+    }
+    const unsigned long long pat = 0x5555555555555555ull >> (64 - 2 * len);     // len <= 32
+    const uint32_t lo = (uint32_t)pat, hi = (uint32_t)(pat >> 32);
+    const uint32_t m0 = lo << sh;
+    const uint32_t m1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
+    const uint32_t m2 = sh ? (hi >> (32u - sh)) : 0u;
+    if (m0 & ~bm[w]) atomicOr(&bm[w], m0);
+    if (m1 && (m1 & ~bm[w + 1])) atomicOr(&bm[w + 1], m1);
+    if (m2 && (m2 & ~bm[w + 2])) atomicOr(&bm[w + 2], m2);
+}
+
 // One pass of 1-D gap clustering (dis_cluster SF:551-564 / dis_cluster_2 SF:566-580) over the
-// hits selected by (flags & need_clear) == 0, on value v = AXIS_A ? i + j : i - j + vbias.
+// dots of the records selected by (flags & need_clear) == 0, on value v = AXIS_A ? i + j : i - j + vbias.
 // Values closer than 10 to their sorted predecessor join its group: an occupancy bitmap over the
 // value range, group starts = occupied bins with no occupied bin among the 9 below, gid(v) = rank
-// of the group's start.  Afterwards, for every selected hit, set_gt10 is OR-ed into its flag byte
-// when its group has more than 10 members, and set_rule when the group passes dis_cluster's rule
-// (more than 50 members, or maximal size when no group has more than 50).
-// NARROW (hits staged in LDS, so n < 65536): group sizes are 16-bit counters, two per LDS word.
+// of the group's start.  All dots of a record fall into one group (their values differ by 0 or 2), so
+// group sizes are summed per record and, afterwards, set_gt10 is OR-ed into the record's flag byte
+// when its group has more than 10 dots, and set_rule when the group passes dis_cluster's rule
+// (more than 50 dots, or maximal size when no group has more than 50).
+// NARROW (pair with fewer than 65536 dots): group sizes are 16-bit counters, two per LDS word.
 // HAVE_BM: the caller has already filled the occupancy bitmap (fused with the staging pass).
 // FINAL: this is the last clustering step of the pair; its flag pass also does the reductions over the
 // finished flags (kept counts, sum |j-i|, count10, range of i-j over the C1-kept dots) and leaves the
 // public VAPOR_HF_* bits in the flag bytes.
 template <bool AXIS_A, bool NARROW, bool HAVE_BM, bool FINAL, typename HP, typename FP>
-__device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
+__device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
                                              uint16_t* wrank, uint32_t* gcnt, CleanShared* sh,
                                              uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule, CleanClock& pc, int phase0 = 16)
 {
@@ -789,32 +860,20 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     auto gsize = [&](uint32_t g) -> uint32_t {
         return NARROW ? ((gcnt[g >> 1] >> ((g & 1u) * 16)) & 0xFFFFu) : gcnt[g];
     };
-    constexpr int CU = 4;
+    auto first_value = [&](const RecV& r) -> int { return AXIS_A ? (r.i0 + r.j0) : (r.i0 - r.j0 + vbias); };
+    auto group_of = [&](int v) -> uint32_t {
+        return (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
+    };
     if (tid == 0) sh->max_group = 0;
     if (!HAVE_BM) {
-    for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
-    __syncthreads();
-    // 1. occupancy bitmap (one atomic per run of equal values); CU hits per thread and trip so that
-    // their LDS reads, shuffles and atomics overlap (the passes are latency-bound, not issue-bound)
-    for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-        uint32_t v[CU];
-#pragma unroll
-        for (int q = 0; q < CU; ++q) {
-            const int h = base + q * CLEAN_THREADS + tid;
-            bool act = h < n;
-            uint32_t x = 0, f = 0;
-            if (act) { x = hits[h]; if (need_clear) f = hflags[h]; }
-            if (need_clear && (f & need_clear)) act = false;
-            const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            v[q] = act ? (uint32_t)(AXIS_A ? (i + j) : (i - j + vbias)) : INACTIVE_KEY;
+        for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
+        __syncthreads();
+        // 1. occupancy bitmap
+        for (int h = tid; h < n; h += CLEAN_THREADS) {
+            if (need_clear && (hflags[h] & need_clear)) continue;
+            const RecV r = rec_decode(recs[h]);
+            mark_values(bm, (uint32_t)first_value(r), r.len, AXIS_A ? !r.rc : r.rc);
         }
-        int head[CU];
-#pragma unroll
-        for (int q = 0; q < CU; ++q) head[q] = run_head_len(v[q]);
-#pragma unroll
-        for (int q = 0; q < CU; ++q)
-            if (head[q] && !(bm[v[q] >> 5] & (1u << (v[q] & 31)))) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
-    }
     }
     __syncthreads();
     pc.mark(phase0 + 0, tid == 0);
@@ -822,18 +881,20 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
     const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
     uint32_t local = 0;
-    constexpr int PER_MAX = 8;                       // range_words_cap <= 4096, CLEAN_THREADS = 512
+    constexpr int PER_MAX = (4096 + CLEAN_THREADS - 1) / CLEAN_THREADS;   // range_words_cap <= 4096
     uint32_t stv[PER_MAX];
 #pragma unroll
     for (int q = 0; q < PER_MAX; ++q) {
         const int w = w0 + q;
         uint32_t st = 0;
         if (w < w1) {
-            uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
-            unsigned long long y = ((unsigned long long)cur << 32) | prev;
-            unsigned long long sm = (y << 1) | (y << 2) | (y << 3) | (y << 4) | (y << 5) | (y << 6) | (y << 7) |
-                                    (y << 8) | (y << 9);
-            st = cur & ~(uint32_t)(sm >> 32);
+            // occupied, and none of the 9 values below occupied: OR of the word shifted up by 1..9 with the
+            // previous word's top bits coming in (funnel shifts)
+            const uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
+            uint32_t below = 0;
+#pragma unroll
+            for (int s = 1; s <= 9; ++s) below |= __builtin_amdgcn_alignbit(cur, prev, 32 - s);
+            st = cur & ~below;
         }
         stv[q] = st;
         local += __popc(st);
@@ -852,46 +913,13 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     for (uint32_t g = tid; g < (NARROW ? (ng + 1) / 2 : ng); g += CLEAN_THREADS) gcnt[g] = 0;
     __syncthreads();
     pc.mark(phase0 + 1, tid == 0);
-    // 3. group sizes (one atomic per run of equal group ids)
-    for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-        uint32_t g[CU];
-#pragma unroll
-        for (int q = 0; q < CU; ++q) {
-            const int h = base + q * CLEAN_THREADS + tid;
-            bool act = h < n;
-            uint32_t x = 0, f = 0;
-            if (act) { x = hits[h]; if (need_clear) f = hflags[h]; }
-            if (need_clear && (f & need_clear)) act = false;
-            const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-            const int v = act ? (AXIS_A ? (i + j) : (i - j + vbias)) : 0;
-            const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
-            g[q] = act ? gid : INACTIVE_KEY;
-        }
-#ifdef VAPOR_AB_PEEL
-#pragma unroll
-        for (int q = 0; q < CU; ++q) {
-            const unsigned long long am = __ballot(g[q] != INACTIVE_KEY);
-            if (am) {
-                const int fl = __ffsll((long long)am) - 1;
-                const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)g[q], fl);
-                const unsigned long long m = __ballot(g[q] == lead);
-                if ((tid & 63) == fl) {
-                    if (NARROW) atomicAdd(&gcnt[lead >> 1], (uint32_t)__popcll(m) << ((lead & 1u) * 16));
-                    else atomicAdd(&gcnt[lead], (uint32_t)__popcll(m));
-                }
-                if (g[q] == lead) g[q] = INACTIVE_KEY;
-            }
-        }
-#endif
-        int len[CU];
-#pragma unroll
-        for (int q = 0; q < CU; ++q) len[q] = run_head_len(g[q]);
-#pragma unroll
-        for (int q = 0; q < CU; ++q)
-            if (len[q]) {
-                if (NARROW) atomicAdd(&gcnt[g[q] >> 1], (uint32_t)len[q] << ((g[q] & 1u) * 16));
-                else atomicAdd(&gcnt[g[q]], (uint32_t)len[q]);
-            }
+    // 3. group sizes
+    for (int h = tid; h < n; h += CLEAN_THREADS) {
+        if (need_clear && (hflags[h] & need_clear)) continue;
+        const RecV r = rec_decode(recs[h]);
+        const uint32_t g = group_of(first_value(r));
+        if (NARROW) atomicAdd(&gcnt[g >> 1], (uint32_t)r.len << ((g & 1u) * 16));
+        else atomicAdd(&gcnt[g], (uint32_t)r.len);
     }
     __syncthreads();
     if (set_rule) {
@@ -906,35 +934,43 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
     // 4. flags (and, for the last step of a pair, the reductions over the finished flags)
     int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
     long long sabs = 0;
-    for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-#pragma unroll
-        for (int q = 0; q < CU; ++q) {
-            const int h = base + q * CLEAN_THREADS + tid;
-            if (h < n) {
-                uint32_t f = hflags[h];
-                const bool sel = !(need_clear && (f & need_clear));
-                if (sel || FINAL) {
-                    const uint32_t x = hits[h];
-                    const int j = (int)(x >> 16), i = (int)(x & 0xFFFFu);
-                    if (sel) {
-                        const int v = AXIS_A ? (i + j) : (i - j + vbias);
-                        const uint32_t gid = (uint32_t)wrank[v >> 5] + __popc(sb[v >> 5] & (0xFFFFFFFFu >> (31 - (v & 31)))) - 1u;
-                        const uint32_t c = gsize(gid);
-                        if (set_gt10 && c > 10u) f |= set_gt10;
-                        if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
-                    }
-                    if (FINAL) {
-                        const int ad = j > i ? j - i : i - j;
-                        uint32_t pub = f & (HF_C2D | HF_C2A);
-                        if (f & (WF_D1 | WF_A1)) { pub |= HF_C1; ++k1; sabs += ad; dlo = min(dlo, i - j); dhi = max(dhi, i - j); }
-                        if (f & (HF_C2D | HF_C2A)) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
-                        kd += (f & HF_C2D) ? 1 : 0;
-                        f = pub;
-                    }
-                    hflags[h] = (uint8_t)f;
-                }
-            }
+    for (int h = tid; h < n; h += CLEAN_THREADS) {
+        uint32_t f = hflags[h];
+        const bool sel = !(need_clear && (f & need_clear));
+        if (!(sel || FINAL)) continue;
+        const RecV r = rec_decode(recs[h]);
+        if (sel) {
+            const uint32_t c = gsize(group_of(first_value(r)));
+            if (set_gt10 && c > 10u) f |= set_gt10;
+            if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
         }
+        if (FINAL) {
+            uint32_t pub = f & (HF_C2D | HF_C2A);
+            const bool c1k = (f & (WF_D1 | WF_A1)) != 0u, c2k = pub != 0u;
+            if (c1k) pub |= HF_C1;
+            const int d0 = r.i0 - r.j0;
+            if (!r.rc) {
+                // i - j is the same for all dots of the record
+                const int ad = d0 < 0 ? -d0 : d0;
+                if (c1k) { k1 += r.len; sabs += (long long)r.len * ad; dlo = min(dlo, d0); dhi = max(dhi, d0); }
+                if (c2k) {
+                    // dots with j > 0 and 25*|j-i| < 4*j, j = j0 .. j0+len-1:  j >= floor(25*ad/4) + 1
+                    const int jmin = max(1, (25 * ad) / 4 + 1);
+                    k2 += r.len;
+                    c10 += max(0, r.j0 + r.len - max(r.j0, jmin));
+                }
+            } else if (c1k || c2k) {
+                for (int t = 0; t < r.len; ++t) {
+                    const int j = r.j0 - t, i = r.i0 + t, ad = j > i ? j - i : i - j;
+                    if (c1k) { ++k1; sabs += ad; }
+                    if (c2k) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
+                }
+                if (c1k) { dlo = min(dlo, d0); dhi = max(dhi, d0 + 2 * (r.len - 1)); }
+            }
+            kd += (f & HF_C2D) ? r.len : 0;
+            f = pub;
+        }
+        hflags[h] = (uint8_t)f;
     }
     if (FINAL) {
         k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
@@ -963,14 +999,10 @@ __device__ __forceinline__ void cluster_axis(HP hits, FP hflags, int n, int vbia
 // sub-list is the longest overall is its median the new intercept c, else c = 0.
 // Outputs: c2x = 2*c (c is a multiple of 0.5), and over dots (x, y) = (j + c, i) with
 // abs(x-y)/abs(x) > 0.1 (x == 0: y/1 > 0.1) the count and the doubled sum of x - y.
-__device__ __forceinline__ int r4_bin(int v, int lo, int range)
-{
-    return range > 0 ? (int)((unsigned)(10 * (v - lo)) / (unsigned)range) : 10;
-}
-
-// the same quotient without an integer division per dot: a = 10*(v-lo) <= 10*131070 < 2^24 is exact in float,
-// the product with the rounded reciprocal is within 2e-6 of a/range, so the truncated value is off by at most
-// one and one exact integer remainder test repairs it.  lo <= v <= lo + range.
+//
+// The quotient is taken without an integer division per dot: a = 10*(v-lo) <= 10*131070 < 2^24 is exact in
+// float, the product with the rounded reciprocal is within 2e-6 of a/range, so the truncated value is off by
+// at most one and one exact integer remainder test repairs it.  lo <= v <= lo + range.
 struct R4Div {
     int lo, range;
     float inv;
@@ -987,29 +1019,21 @@ struct R4Div {
     }
 };
 
-// c[b] += lanes whose key is b, b = 0..10; wave-uniform counters (ballots and scalar popcounts, no atomics)
-__device__ __forceinline__ void wave_hist11(uint32_t key, int (&c)[11])
+// number of t in [0, len) with x0 + 2*t < bound
+__device__ __forceinline__ int count_below(int x0, int len, int bound)
 {
-#pragma unroll
-    for (int b = 0; b < 11; ++b) c[b] += __popcll(__ballot(key == (uint32_t)b));
-}
-__device__ __forceinline__ void flush_hist11(const int (&c)[11], int* dst)
-{
-    const int lane = threadIdx.x & 63;
-    int v = 0;
-#pragma unroll
-    for (int b = 0; b < 11; ++b) v = (lane == b) ? c[b] : v;
-    if (lane < 11 && v) atomicAdd(&dst[lane], v);
+    return min(max((bound - x0 + 1) >> 1, 0), len);
 }
 
 // kd_lo / kd_hi (min and max of i-j over the kept dots) must already be in *sh.
-// CACHE: the level-1 list of every kept dot is parked in the upper nibble of its flag byte (LDS copy only; the
-// write-back masks it off), so the later passes neither divide again nor touch the dots of other lists.
+// Same-strand records carry one value of i - j for all their dots and add their length wherever a dot
+// would add one; reverse-complement records (rare) are walked dot by dot.
+// CACHE: the level-1 list of every kept same-strand record is parked in the upper nibble of its flag byte
+// (LDS copy only; the write-back masks it off; 15 = walk the record), so the later passes do not divide again.
 template <bool CACHE, typename HP, typename FP>
-__device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32_t* counters, CleanShared* sh, CleanClock& pc)
+__device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32_t* counters, CleanShared* sh, CleanClock& pc)
 {
     const int tid = threadIdx.x;
-    constexpr int CU = 4;
     if (tid == 0) { sh->n_lists = 0; sh->c2x = 0; sh->dir_n = 0; sh->dir_sum2 = 0; sh->win_w = -1; }
     if (tid < 11) sh->cnt1[tid] = 0;
     __syncthreads();
@@ -1017,29 +1041,19 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
     if (range1 < 0) return;                        // no kept dots (uniform)
     const R4Div d1(lo1, range1);
     // level 1: sizes of the eleven lists
-    {
-        int c[11];
-#pragma unroll
-        for (int b = 0; b < 11; ++b) c[b] = 0;
-        for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-            uint32_t key[CU];
-#pragma unroll
-            for (int q = 0; q < CU; ++q) {
-                const int h = base + q * CLEAN_THREADS + tid;
-                key[q] = INACTIVE_KEY;
-                if (h < n) {
-                    const uint32_t f = hflags[h];
-                    if (f & HF_C1) {
-                        const uint32_t x = hits[h];
-                        key[q] = (uint32_t)d1.bin((int)(x & 0xFFFFu) - (int)(x >> 16));
-                        if (CACHE) hflags[h] = (uint8_t)(f | (key[q] << 4));
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < CU; ++q) wave_hist11(key[q], c);
+    for (int h = tid; h < n; h += CLEAN_THREADS) {
+        const uint32_t f = hflags[h];
+        if (!(f & HF_C1)) continue;
+        const RecV r = rec_decode(recs[h]);
+        const int d0 = r.i0 - r.j0;
+        if (!r.rc) {
+            const int b = d1.bin(d0);
+            atomicAdd(&sh->cnt1[b], r.len);
+            if (CACHE) hflags[h] = (uint8_t)(f | ((uint32_t)b << 4));
+        } else {
+            for (int t = 0; t < r.len; ++t) atomicAdd(&sh->cnt1[d1.bin(d0 + 2 * t)], 1);
+            if (CACHE) hflags[h] = (uint8_t)(f | 0xF0u);
         }
-        flush_hist11(c, sh->cnt1);
     }
     __syncthreads();
     pc.mark(32, tid == 0);
@@ -1051,20 +1065,22 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
         if (tid == 0) { sh->bin_lo = 0x7FFFFFFF; sh->bin_hi = -0x7FFFFFFF; }
         if (tid < 11) sh->cnt2[tid] = 0;
         __syncthreads();
-        auto in_list = [&](int h, int* d) -> bool {   // kept dot h belongs to list w; *d = its i - j
-            const uint32_t f = hflags[h];
-            if (!(f & HF_C1)) return false;
-            if (CACHE && (int)(f >> 4) != w) return false;
-            const uint32_t x = hits[h];
-            *d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-            return CACHE ? true : d1.bin(*d) == w;
-        };
         {
             int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
-#pragma unroll 4
             for (int h = tid; h < n; h += CLEAN_THREADS) {
-                int d;
-                if (in_list(h, &d)) { lo = min(lo, d); hi = max(hi, d); }
+                const uint32_t f = hflags[h];
+                if (!(f & HF_C1)) continue;
+                if (CACHE && (f >> 4) != 15u && (int)(f >> 4) != w) continue;
+                const RecV r = rec_decode(recs[h]);
+                const int d0 = r.i0 - r.j0;
+                if (!r.rc) {
+                    if (CACHE || d1.bin(d0) == w) { lo = min(lo, d0); hi = max(hi, d0); }
+                } else {
+                    for (int t = 0; t < r.len; ++t) {
+                        const int d = d0 + 2 * t;
+                        if (d1.bin(d) == w) { lo = min(lo, d); hi = max(hi, d); }
+                    }
+                }
             }
             lo = wave_min_i32(lo); hi = wave_max_i32(hi);
             if ((tid & 63) == 0) { atomicMin(&sh->bin_lo, lo); atomicMax(&sh->bin_hi, hi); }
@@ -1072,22 +1088,20 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
         __syncthreads();
         const int lo2 = sh->bin_lo, range2 = sh->bin_hi - sh->bin_lo;
         const R4Div d2(lo2, range2);
-        {
-            int c[11];
-#pragma unroll
-            for (int b = 0; b < 11; ++b) c[b] = 0;
-            for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-                uint32_t key[CU];
-#pragma unroll
-                for (int q = 0; q < CU; ++q) {
-                    const int h = base + q * CLEAN_THREADS + tid;
-                    int d;
-                    key[q] = (h < n && in_list(h, &d)) ? (uint32_t)d2.bin(d) : INACTIVE_KEY;
+        for (int h = tid; h < n; h += CLEAN_THREADS) {
+            const uint32_t f = hflags[h];
+            if (!(f & HF_C1)) continue;
+            if (CACHE && (f >> 4) != 15u && (int)(f >> 4) != w) continue;
+            const RecV r = rec_decode(recs[h]);
+            const int d0 = r.i0 - r.j0;
+            if (!r.rc) {
+                if (CACHE || d1.bin(d0) == w) atomicAdd(&sh->cnt2[d2.bin(d0)], r.len);
+            } else {
+                for (int t = 0; t < r.len; ++t) {
+                    const int d = d0 + 2 * t;
+                    if (d1.bin(d) == w) atomicAdd(&sh->cnt2[d2.bin(d)], 1);
                 }
-#pragma unroll
-                for (int q = 0; q < CU; ++q) wave_hist11(key[q], c);
             }
-            flush_hist11(c, sh->cnt2);
         }
         __syncthreads();
         if (tid == 0) {
@@ -1112,27 +1126,21 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
         const int width = vhi - vlo + 1;
         for (int q = tid; q < width; q += CLEAN_THREADS) counters[q] = 0;
         __syncthreads();
-        for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-            uint32_t key[CU];
-#pragma unroll
-            for (int q = 0; q < CU; ++q) {
-                const int h = base + q * CLEAN_THREADS + tid;
-                key[q] = INACTIVE_KEY;
-                if (h < n) {
-                    const uint32_t f = hflags[h];
-                    if ((f & HF_C1) && (!CACHE || (int)(f >> 4) == w)) {
-                        const uint32_t x = hits[h];
-                        const int d = (int)(x & 0xFFFFu) - (int)(x >> 16);
-                        if (d >= vlo && d <= vhi && (CACHE || d1.bin(d) == w) && d2.bin(d) == b) key[q] = (uint32_t)(d - vlo);
-                    }
+        for (int h = tid; h < n; h += CLEAN_THREADS) {
+            const uint32_t f = hflags[h];
+            if (!(f & HF_C1)) continue;
+            if (CACHE && (f >> 4) != 15u && (int)(f >> 4) != w) continue;
+            const RecV r = rec_decode(recs[h]);
+            const int d0 = r.i0 - r.j0;
+            if (!r.rc) {
+                if (d0 >= vlo && d0 <= vhi && (CACHE || d1.bin(d0) == w) && d2.bin(d0) == b)
+                    atomicAdd(&counters[d0 - vlo], (uint32_t)r.len);
+            } else {
+                for (int t = 0; t < r.len; ++t) {
+                    const int d = d0 + 2 * t;
+                    if (d >= vlo && d <= vhi && d1.bin(d) == w && d2.bin(d) == b) atomicAdd(&counters[d - vlo], 1u);
                 }
             }
-            int len[CU];
-#pragma unroll
-            for (int q = 0; q < CU; ++q) len[q] = run_head_len(key[q]);
-#pragma unroll
-            for (int q = 0; q < CU; ++q)
-                if (len[q]) atomicAdd(&counters[key[q]], (uint32_t)len[q]);
         }
         __syncthreads();
         // order statistics (m-1)/2 and m/2, 0-based: np.median is their mean.  Block prefix over the counters,
@@ -1160,18 +1168,32 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
     __syncthreads();
     pc.mark(34, tid == 0);
     {
+        // dots with 10 * |X - Y| > |X| (X == 0: i >= 1), X = 2*j + c2x, Y = 2*i: count and sum of X - Y
         const int c2x = sh->c2x;
         int cn = 0;
         long long cs = 0;
-#pragma unroll 4
         for (int h = tid; h < n; h += CLEAN_THREADS) {
             if (!(hflags[h] & HF_C1)) continue;
-            uint32_t x = hits[h];
-            int i = (int)(x & 0xFFFFu), j = (int)(x >> 16);
-            int X = 2 * j + c2x, Y = 2 * i;
-            int df = X - Y, adf = df < 0 ? -df : df, aX = X < 0 ? -X : X;
-            bool far = (X == 0) ? (i >= 1) : (10 * adf > aX);
-            if (far) { ++cn; cs += df; }
+            const RecV r = rec_decode(recs[h]);
+            if (!r.rc) {
+                // X - Y = df is the same for all dots, X = X0 + 2*t:  |X| < 10*|df|  <=>  -B < X < B
+                const int X0 = 2 * r.j0 + c2x, df = X0 - 2 * r.i0, B = 10 * (df < 0 ? -df : df);
+                int far = B > 0 ? count_below(X0, r.len, B) - count_below(X0, r.len, -B + 1) : 0;
+                // the dot with X == 0 follows the other rule
+                if (X0 <= 0 && !(X0 & 1) && (-X0 >> 1) < r.len) {
+                    const int t0 = -X0 >> 1;
+                    far += (int)(r.i0 + t0 >= 1) - (int)(B > 0);
+                }
+                cn += far; cs += (long long)far * df;
+            } else {
+                for (int t = 0; t < r.len; ++t) {
+                    const int i = r.i0 + t, j = r.j0 - t;
+                    const int X = 2 * j + c2x, Y = 2 * i;
+                    const int df = X - Y, adf = df < 0 ? -df : df, aX = X < 0 ? -X : X;
+                    const bool far = (X == 0) ? (i >= 1) : (10 * adf > aX);
+                    if (far) { ++cn; cs += df; }
+                }
+            }
         }
         cn = wave_sum_i32(cn); cs = wave_sum_i64(cs);
         if ((tid & 63) == 0) { atomicAdd(&sh->dir_n, cn); atomicAdd((unsigned long long*)&sh->dir_sum2, (unsigned long long)cs); }
@@ -1180,104 +1202,99 @@ __device__ __forceinline__ void directed_stats(HP hits, FP hflags, int n, uint32
     pc.mark(35, tid == 0);
 }
 
-// everything after the hits are in place (LDS copy or global), for one pair
+// everything after the records are in place (LDS copy or global), for one pair
 template <bool NARROW, typename HP, typename FP>
-__device__ __forceinline__ void clean_body(HP hits, FP hflags, int n, const DPair& pr, int len2, int range_words,
+__device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots, const DPair& pr, int len2, int range_words,
                                            uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, CleanShared* sh, long long* st, CleanClock& pc)
 {
     const int tid = threadIdx.x;
     const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u, s3 = (pr.flags & 4u) && c1;
-    // i - j over all dots (its bitmap was filled while the hits were staged): C1's diagonal groups (>10)
+    // i - j over all dots (its bitmap was filled while the records were staged): C1's diagonal groups (>10)
     // and C2's diagonal step; then i + j over all dots (C1) and / or over the dots the diagonal step left (C2)
     if (c1 && c2) {
-        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
-        cluster_axis<true, NARROW, false, false>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
-        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
+        cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
+        cluster_axis<true, NARROW, false, false>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
+        cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     } else if (c1) {
-        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
-        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
+        cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
+        cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
     } else if (c2) {
-        cluster_axis<false, NARROW, true, false>(hits, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
-        cluster_axis<true, NARROW, false, true>(hits, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
+        cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
+        cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     }
-    if (s3) directed_stats<NARROW>(hits, hflags, n, gcnt, sh, pc);
+    if (s3) directed_stats<NARROW>(recs, hflags, n, gcnt, sh, pc);
     if (tid == 0) {
-        st[0] = n; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
+        st[0] = n_dots; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
         st[5] = sh->c2_kept; st[6] = sh->c2_count10; st[7] = sh->n_diag; st[8] = sh->n_lower; st[9] = sh->c2_kept_diag;
         st[10] = s3 ? sh->c2x : 0; st[11] = s3 ? sh->dir_n : 0; st[12] = s3 ? sh->dir_sum2 : 0; st[13] = s3 ? sh->n_lists : 0;
         st[14] = 0; st[15] = 0;
     }
 }
 
-// One pair.  Dynamic LDS: bitmap (range_words_cap words) | wrank (u16 each) | group sizes | (IN_LDS: hit copy
-// (hcap words) | flag bytes (hcap)).
+// One pair of n records / n_dots dots.  Dynamic LDS: bitmap (range_words_cap words) | wrank (u16 each) | group
+// sizes | (IN_LDS: record copy (hcap x 8 B, 8-byte aligned) | flag bytes (hcap)).
 template <bool IN_LDS>
-__device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh, const DPair& pr, int n, int len2,
-                                           int range_words, const uint32_t* __restrict__ hits_all,
+__device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh, const DPair& pr, int n, int n_dots, int len2,
+                                           int range_words, const unsigned long long* __restrict__ recs_all,
                                            uint8_t* __restrict__ hflags_all, long long* __restrict__ stats,
                                            int range_words_cap, int groups_cap, int hcap)
 {
     const int tid = threadIdx.x;
     long long* st = stats + (size_t)p * 16;
     CleanClock pc;
-    const uint32_t* ghits = hits_all + pr.hit_off;
+    const unsigned long long* grecs = recs_all + pr.hit_off;
     uint8_t* gflags = hflags_all + pr.hit_off;
-    // the first dots of every thread are requested before anything else touches memory: global latency, not
+    // the first records of every thread are requested before anything else touches memory: global latency, not
     // bandwidth, is what this pass waits for
-    constexpr int CU = 4;
-    uint32_t x[CU];
+    constexpr int PF = 4;
+    unsigned long long x[PF];
 #pragma unroll
-    for (int q = 0; q < CU; ++q) {
+    for (int q = 0; q < PF; ++q) {
         const int h = q * CLEAN_THREADS + tid;
-        x[q] = h < n ? ghits[h] : 0u;
+        x[q] = h < n ? grecs[h] : 0ull;
     }
     uint32_t* bm = lds;
     uint16_t* wrank = reinterpret_cast<uint16_t*>(bm + range_words_cap);
     uint32_t* gcnt = bm + range_words_cap + (range_words_cap + 1) / 2;
-    uint32_t* lhits = gcnt + (groups_cap + 1) / 2;
-    uint8_t* lflags = reinterpret_cast<uint8_t*>(lhits + hcap);
+    const int rec_word = (range_words_cap + (range_words_cap + 1) / 2 + (groups_cap + 1) / 2 + 1) & ~1;
+    unsigned long long* lrecs = reinterpret_cast<unsigned long long*>(lds + rec_word);
+    uint8_t* lflags = reinterpret_cast<uint8_t*>(lrecs + hcap);
 
     if (tid == 0) {
         sh.min_j = 0x7FFFFFFF; sh.max_j = -1; sh.n_diag = 0; sh.n_lower = 0;
         sh.c1_kept = 0; sh.c2_kept = 0; sh.c2_count10 = 0; sh.c2_kept_diag = 0; sh.c1_sum_abs = 0ULL;
         sh.kd_lo = 0x7FFFFFFF; sh.kd_hi = -0x7FFFFFFF;
     }
-    // pass 0: first/last j, diagonal and lower-triangle counts; stage the hits, clear the flags, and fill
+    // pass 0: first/last j, diagonal and lower-triangle counts; stage the records, clear the flags, and fill
     // the occupancy bitmap of i - j for the first clustering step
     const bool any_axis = (pr.flags & 3u) != 0u;
     for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
     __syncthreads();
     {
         int mn = 0x7FFFFFFF, mx = -1, nd = 0, nl = 0;
-        for (int base = 0; base < n; base += CLEAN_THREADS * CU) {
-            uint32_t v[CU];
-            if (base) {
-#pragma unroll
-                for (int q = 0; q < CU; ++q) {
-                    const int h = base + q * CLEAN_THREADS + tid;
-                    x[q] = h < n ? ghits[h] : 0u;
-                }
+        auto take = [&](int h, unsigned long long xr) {
+            const RecV r = rec_decode(xr);
+            if (!r.rc) {
+                mn = min(mn, r.j0); mx = max(mx, r.j0 + r.len - 1);
+                nd += (r.j0 == r.i0) ? r.len : 0;
+                nl += (r.j0 > r.i0) ? r.len : 0;
+            } else {
+                // j = j0 - t, i = i0 + t:  j == i for 2t == D, j > i for 2t < D, D = j0 - i0
+                const int D = r.j0 - r.i0;
+                mn = min(mn, r.j0 - r.len + 1); mx = max(mx, r.j0);
+                nd += (D >= 0 && !(D & 1) && (D >> 1) < r.len) ? 1 : 0;
+                nl += D > 0 ? min(r.len, (D + 1) >> 1) : 0;
             }
+            if (IN_LDS) { lrecs[h] = xr; lflags[h] = 0; }
+            else gflags[h] = 0;
+            if (any_axis) mark_values(bm, (uint32_t)(r.i0 - r.j0 + len2), r.len, r.rc);
+        };
 #pragma unroll
-            for (int q = 0; q < CU; ++q) {
-                const int h = base + q * CLEAN_THREADS + tid;
-                v[q] = INACTIVE_KEY;
-                if (h < n) {
-                    const int j = (int)(x[q] >> 16), i = (int)(x[q] & 0xFFFFu);
-                    mn = min(mn, j); mx = max(mx, j);
-                    nd += (j == i); nl += (j > i);
-                    if (IN_LDS) { lhits[h] = x[q]; lflags[h] = 0; }
-                    else gflags[h] = 0;
-                    if (any_axis) v[q] = (uint32_t)(i - j + len2);
-                }
-            }
-            int head[CU];
-#pragma unroll
-            for (int q = 0; q < CU; ++q) head[q] = run_head_len(v[q]);
-#pragma unroll
-            for (int q = 0; q < CU; ++q)
-                if (head[q] && !(bm[v[q] >> 5] & (1u << (v[q] & 31)))) atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
+        for (int q = 0; q < PF; ++q) {
+            const int h = q * CLEAN_THREADS + tid;
+            if (h < n) take(h, x[q]);
         }
+        for (int h = PF * CLEAN_THREADS + tid; h < n; h += CLEAN_THREADS) take(h, grecs[h]);
         mn = wave_min_i32(mn); mx = wave_max_i32(mx); nd = wave_sum_i32(nd); nl = wave_sum_i32(nl);
         if ((tid & 63) == 0) {
             atomicMin(&sh.min_j, mn); atomicMax(&sh.max_j, mx);
@@ -1287,24 +1304,29 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
     __syncthreads();
     pc.mark(8, tid == 0);                          // pass 0
     if (IN_LDS) {
-        clean_body<true>((const uint32_t*)lhits, lflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+        clean_body<true>((const unsigned long long*)lrecs, lflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
         __syncthreads();
         pc.mark(9, tid == 0);                      // what the nested stamps left of clean_body
-        for (int h = tid; h < n; h += CLEAN_THREADS) gflags[h] = lflags[h] & 7u;
+        // four flag bytes per store (the pair's slot and the LDS copy are both padded to a multiple of four)
+        {
+            const uint32_t* lf4 = reinterpret_cast<const uint32_t*>(lflags);
+            uint32_t* gf4 = reinterpret_cast<uint32_t*>(gflags);
+            for (int h = tid; h < (n + 3) / 4; h += CLEAN_THREADS) gf4[h] = lf4[h] & 0x07070707u;
+        }
         pc.mark(10, tid == 0);
     } else {
-        clean_body<false>(ghits, gflags, n, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+        clean_body<false>(grecs, gflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
     }
     pc.flush(tid == 0);
 }
 
-// One workgroup per pair: pairs with at most hcap hits are cleaned entirely out of LDS with 16-bit group
-// counters; the others are appended to big_list for clean_big_kernel (or, without a list, reported in stats).
-// len2 and the value range come with the pair record, so the only dependent global reads before the dots are
-// the pair record and its hit count.
+// One workgroup per pair: pairs with at most hcap records and fewer than 65536 dots are cleaned entirely out of
+// LDS with 16-bit group counters; the others are appended to big_list for clean_big_kernel.
+// n_hits[p] = records | dots << 32 (join_verify).  len2 and the value range come with the pair record, so the
+// only dependent global reads before the records are the pair record and its counts.
 __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
-    const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
+    const unsigned long long* __restrict__ n_hits, const unsigned long long* __restrict__ recs_all,
     uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
     unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list)
 {
@@ -1313,34 +1335,37 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const int tid = threadIdx.x;
     const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
     const DPair pr = pairs[p];
-    const unsigned long long nh = n_hits[p];
-    if (nh > (unsigned long long)pr.cap || nh == 0ULL) {
+    const unsigned long long cnt = n_hits[p];
+    const uint32_t nrec = (uint32_t)cnt, ndots = (uint32_t)(cnt >> 32);
+    if (nrec > pr.cap || nrec == 0u) {
         long long* st = stats + (size_t)p * 16;
         if (tid < 16) {
             long long v = 0;
-            if (tid == 0) v = (long long)nh;
+            if (tid == 0) v = (long long)ndots;
             if (tid == 1 || tid == 2) v = -1;
-            if (tid == 15 && nh) v = -2;      // VAPOR_E_OVERFLOW: rerun with cap >= n_hits
+            if (tid == 14) v = (long long)nrec;   // records: what the slot has to hold on the rerun
+            if (tid == 15 && nrec) v = -2;        // VAPOR_E_OVERFLOW
             st[tid] = v;
         }
-        if (tid == 0 && nh && overflow) atomicAdd(&overflow[0], 1u);
+        if (tid == 0 && nrec && overflow) atomicAdd(&overflow[0], 1u);
         return;
     }
-    const int n = (int)nh;                     // cap < 2^31
-    if (n > hcap) {
+    const int n = (int)nrec;                   // cap < 2^31
+    if (n > hcap || ndots > 65535u) {
         if (tid == 0) big_list[atomicAdd(&overflow[1], 1u)] = p;
         return;
     }
-    clean_pair<true>(p, lds, sh, pr, n, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap), hits_all, hflags_all,
-                     stats, range_words_cap, groups_cap, hcap);
+    clean_pair<true>(p, lds, sh, pr, n, (int)ndots, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
+                     recs_all, hflags_all, stats, range_words_cap, groups_cap, hcap);
 }
 
-// The pairs clean_kernel left (more dots than the LDS copy holds): the dots stream from L2/HBM on every pass,
-// group sizes are 32-bit.  A fixed grid walks the list; workgroups beyond its length leave at once.
+// The pairs clean_kernel left (more records than the LDS copy holds, or too many dots for 16-bit counters): the
+// records stream from L2/HBM on every pass, group sizes are 32-bit.  A fixed grid walks the list; workgroups
+// beyond its length leave at once.
 __global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
-    const DPair* __restrict__ pairs, const unsigned long long* __restrict__ n_hits, const uint32_t* __restrict__ hits_all,
-    uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap,
-    const unsigned int* __restrict__ overflow, const int32_t* __restrict__ big_list)
+    const DPair* __restrict__ pairs, const unsigned long long* __restrict__ n_hits,
+    const unsigned long long* __restrict__ recs_all, uint8_t* __restrict__ hflags_all, long long* __restrict__ stats,
+    int range_words_cap, int groups_cap, const unsigned int* __restrict__ overflow, const int32_t* __restrict__ big_list)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
@@ -1348,26 +1373,52 @@ __global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
     for (unsigned int b = blockIdx.x; b < n_big; b += gridDim.x) {
         const int p = big_list[b];
         const DPair pr = pairs[p];
+        const unsigned long long cnt = n_hits[p];
         __syncthreads();                       // the previous pair's statistics have been read
-        clean_pair<false>(p, lds, sh, pr, (int)n_hits[p], pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
-                          hits_all, hflags_all, stats, range_words_cap, groups_cap, 0);
+        clean_pair<false>(p, lds, sh, pr, (int)(uint32_t)cnt, (int)(uint32_t)(cnt >> 32), pr.len2,
+                          min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap), recs_all, hflags_all, stats,
+                          range_words_cap, groups_cap, 0);
     }
 }
 
-// copies the hits (unpacked to int32 j, i) and flag bytes of selected pairs to a dense buffer
+// expands the records of selected pairs to dots (int32 j, i) and per-dot flag bytes in a dense buffer; the dots
+// of a pair keep the record order, each record's dots in read order
 __global__ __launch_bounds__(256) void gather_kernel(const DPair* __restrict__ pairs, const long long* __restrict__ sel,
-                                                    const long long* __restrict__ out_off,
-                                                    const uint32_t* __restrict__ hits, const uint8_t* __restrict__ hflags,
+                                                    const long long* __restrict__ out_off, const long long* __restrict__ n_rec,
+                                                    const unsigned long long* __restrict__ recs, const uint8_t* __restrict__ hflags,
                                                     int32_t* __restrict__ out_ji, uint8_t* __restrict__ out_flags)
 {
+    __shared__ uint32_t wtot[4];
+    __shared__ long long run_base;
     const long long p = sel[blockIdx.x];
     const DPair pr = pairs[p];
-    const long long o = out_off[blockIdx.x], n = out_off[blockIdx.x + 1] - o;
-    for (long long h = threadIdx.x; h < n; h += blockDim.x) {
-        uint32_t x = hits[pr.hit_off + h];
-        out_ji[2 * (o + h)] = (int32_t)(x >> 16);
-        out_ji[2 * (o + h) + 1] = (int32_t)(x & 0xFFFFu);
-        if (out_flags) out_flags[o + h] = hflags[pr.hit_off + h];
+    const long long n = n_rec[blockIdx.x], n_out = out_off[blockIdx.x + 1] - out_off[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid == 0) run_base = out_off[blockIdx.x];
+    __syncthreads();
+    for (long long h0 = 0; h0 < n; h0 += 256) {
+        const long long h = h0 + tid;
+        const unsigned long long r = h < n ? recs[pr.hit_off + h] : 0ull;
+        const uint32_t len = h < n ? (uint32_t)VREC_LEN(r) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(len);
+        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+        __syncthreads();
+        long long o = run_base + (long long)(incl - len);
+        uint32_t tot = 0;
+        for (int q = 0; q < 4; ++q) { if (q < (tid >> 6)) o += wtot[q]; tot += wtot[q]; }
+        if (h < n) {
+            const uint8_t f = out_flags ? hflags[pr.hit_off + h] : (uint8_t)0;
+            const int s = VREC_RC(r) ? -1 : 1;
+            for (uint32_t t = 0; t < len; ++t) {
+                if (o + t - out_off[blockIdx.x] >= n_out) break;    // never past this pair's share of the buffer
+                out_ji[2 * (o + t)] = VREC_J(r) + s * (int)t;
+                out_ji[2 * (o + t) + 1] = VREC_I(r) + (int)t;
+                if (out_flags) out_flags[o + t] = f;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) run_base += tot;
+        __syncthreads();
     }
 }
 

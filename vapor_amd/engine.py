@@ -76,6 +76,12 @@ class Plan:
         return {"join_ms": ms[0], "clean_ms": ms[1], "total_ms": ms[2], "join_launches": int(ms[3]),
                 "retried_pairs": int(ms[4]), "finish_ms": ms[5]}
 
+    def record_counts(self) -> np.ndarray:
+        """Run records per pair of the last run (the device stores runs of consecutive dots as one record)."""
+        out = np.zeros(max(self.n, 1), dtype=np.int64)
+        L.check(L.load().vapor_plan_record_counts(self._h, L.ptr(out, ctypes.c_int64)))
+        return out[:self.n]
+
     def set_reads(self, reads: np.ndarray, n_loci: int) -> None:
         """Describe which pairs score which read of which locus (READ_DTYPE rows sorted by locus) so that
         run_loci() can finish on the device."""
