@@ -468,7 +468,7 @@ static int clean_hcap(int range_words_cap, int want)
 {
     const size_t fixed = clean_fixed_bytes(range_words_cap, false) + 512;
     int best = 0;
-    for (int per_cu = 4; per_cu >= 1; --per_cu) {
+    for (int per_cu = 2048 / CLEAN_THREADS; per_cu >= 1; --per_cu) {       // 32 waves per CU at most
         const size_t share = (size_t)(160 * 1024) / per_cu - 512;
         if (share <= fixed) continue;
         const int cap = (int)std::min<size_t>(std::min<size_t>((share - fixed) / 9, (size_t)want), 65532) & ~3;
@@ -512,12 +512,10 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
                            p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
                            p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap, p->d_overflow, p->d_big_list);
         HIPCHK(hipGetLastError());
-#ifndef VAPOR_AB_NOBIG
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(p->n_pairs, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(p->range_words_cap, true), st, p->d_pairs, p->d_nhits, p->d_hits, p->d_hflags,
                            p->d_stats, p->range_words_cap, clean_groups_cap(p->range_words_cap), p->d_overflow, p->d_big_list);
         HIPCHK(hipGetLastError());
-#endif
     }
     HIPCHK(hipEventRecord(p->ev[2], st));
     if (p->n_pairs > 0 && fetch_stats)

@@ -52,7 +52,10 @@ struct DTask {         // 16 B: pairs task_pairs[first .. first + n_reads) of on
 #define VP_PAD_CHUNKS 3  // zeroed chunks after each sequence: window reads may run this far
 
 constexpr int MAX_READS_PER_TASK = 64;
-constexpr int CLEAN_THREADS = 512;
+#ifndef VAPOR_CLEAN_THREADS
+#define VAPOR_CLEAN_THREADS 512
+#endif
+constexpr int CLEAN_THREADS = VAPOR_CLEAN_THREADS;
 constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
 
 // per-hit working flags inside clean_kernel (upper nibble) and the public ones (lower)
@@ -603,6 +606,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                     acc += nk > 0 ? (nk + JCHUNK - 1) / JCHUNK : 0;
                 }
                 cstart[g1 - g0] = acc;
+                wtot[2 * JOIN_WAVES] = 0u;                 // next strip to hand out
             }
             __syncthreads();
             pc.mark(0, pw);                        // table build (incl. waiting for the slowest wave of the last probe)
@@ -612,7 +616,12 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                 constexpr int WPL = BPS / 2;                      // plane words per 16 positions
                 constexpr uint32_t SYM = (1u << BPS) - 1u;
                 int r = g0;                                        // strips are visited in increasing order
-                for (int si = wave; si < total_strips; si += JOIN_WAVES) {
+                // strips differ in cost (dots per strip), so the waves take the next strip when they are free
+                for (;;) {
+                    uint32_t next = 0;
+                    if (lane == 0) next = atomicAdd(&wtot[2 * JOIN_WAVES], 1u);
+                    const int si = __builtin_amdgcn_readfirstlane((int)next);
+                    if (si >= total_strips) break;
                     while (si >= cstart[r - g0 + 1]) ++r;
                     const int cb = (si - cstart[r - g0]) * JCHUNK;
                     const DPair pr = pairs[task_pairs[task.first + r]];
