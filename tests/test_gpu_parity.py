@@ -280,3 +280,37 @@ def test_exception_paths_at_bench_shapes(eng, oracle):
                 rows.append((rd, al, 3 * rd, k, 7))
     rows += [(1, 1, 0, 10, 7), (1, 1, 0, 30, 7)]
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "exc_bench")
+
+
+def test_run_records_expand_to_the_oracle_dots(eng, oracle):
+    """The device stores runs of consecutive dots as one record.  Accurate reads (runs hit the 32-dot cap and
+    the strip / tile boundaries), an inverted segment (reverse-complement dots), an allele slice (miss_bp), a
+    two-tile allele and an N in the read (run forming is switched off for that pair): the expanded dot lists
+    must be exactly dotdata()'s, and the flags / statistics those records produce the oracle's."""
+    from vapor_amd import synth
+    rng = np.random.default_rng(31)
+    allele = synth.random_dna(rng, 6000)
+    exact = allele[700:5200]                                            # one 4 500-dot diagonal
+    nearly = synth.mutate(np.random.default_rng(5), allele[300:5600], 0.001, 0.002, 0.002)[0]
+    inv = allele[500:2000] + synth.revcomp(allele[2000:3500]) + allele[3500:5000]
+    with_n = exact[:2000] + "N" + exact[2001:]
+    big = synth.random_dna(rng, 36000)                                  # 31 744-position tiles: two of them
+    long_read = big[30000:35500]
+    seqs = [allele, exact, nearly, inv, with_n, big, long_read]
+    rows = [(1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (3, 0, 0, 10, 7), (1, 0, 913, 10, 3), (4, 0, 0, 10, 7),
+            (6, 5, 0, 10, 7), (1, 0, 0, 20, 7), (2, 0, 0, 40, 3), (6, 5, 31000, 30, 1)]
+    ss = eng.seqset(seqs)
+    plan = eng.plan(ss, eng.make_pairs(rows))
+    st = plan.run().copy()
+    rec = plan.record_counts()
+    hits, _fl, off = plan.fetch_hits(range(len(rows)), want_flags=True)
+    for t, (s1, s2, off2, k, _f) in enumerate(rows):
+        exp = oracle.dotdata_array(k, seqs[s1], seqs[s2][off2:])
+        got = hits[off[t]:off[t + 1]]
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert st[t, 0] == len(exp) and got.tolist() == exp.tolist(), (t, rows[t])
+        assert 0 < rec[t] <= st[t, 0]
+    assert rec[0] * 20 < st[0, 0]                 # an exact copy: 32 dots per record
+    assert rec[4] == st[4, 0]                     # the N switches run forming off for this pair
+    plan.close()
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "runs")
