@@ -351,3 +351,41 @@ def test_inprocess_bam_reader_equals_memory_backend(tmp_path):
         seqio.set_backend(None)
         assert sorted(e1) == sorted(e2) and len(e1) > 3
         assert r1 == r2
+
+
+def test_workflow_sorted_bgzipped_indexed_table(fake, tmp_path):
+    """§8f-4: the node launcher's gather side - the CLI's table, version-sorted, block-gzipped and tabix-indexed
+    (what the reference's WDL does with sort -V | bgzip | tabix -p bed)."""
+    import gzip
+    from vapor_amd import workflow
+    assert sorted(["chr10", "chr2", "chrX", "chr1", "chr2_alt"], key=workflow.version_key) == ["chr1", "chr2", "chr2_alt", "chr10", "chrX"]
+    world = synth.make_world_from_bed(CFG1["bed_rows"], seed=CFG1["seed"])
+    seqio.set_backend(seqio.MemorySamtools(world))
+    bed = tmp_path / "vapor_test.bed"
+    bed.write_text(CFG1["bed"])
+    out = tmp_path / "s1.vapor"
+    assert workflow.main(["--prefix", str(tmp_path / "s1"), "bed", "--sv-input", str(bed), "--reference", "hg19.fa",
+                          "--pacbio-input", "x.bam", "--output-path", str(tmp_path / "figs"), "--output-file", str(out),
+                          "--no-figures"]) == 0
+    table = out.read_text().splitlines()
+    assert out.read_text() == CFG1["cases"][0]["vapor_text"]
+    gz = str(tmp_path / "s1.bed.gz")
+    rows = gzip.open(gz, "rt").read().splitlines()
+    assert rows == workflow.sort_rows(table[1:]) and len(rows) == len(table) - 1
+    assert open(gz, "rb").read().endswith(workflow._BGZF_EOF)
+    # every row is found through the index by its own interval, and only overlapping rows come back
+    for ln in rows:
+        f = ln.split("\t")
+        got = workflow.tabix_query(gz, f[0], int(f[1]) + 1, max(int(f[2]), int(f[1]) + 1))
+        assert ln in got
+        for g in got:
+            h = g.split("\t")
+            assert h[0] == f[0] and int(h[1]) < max(int(f[2]), int(f[1]) + 1) and max(int(h[2]), int(h[1]) + 1) > int(f[1])
+    assert workflow.tabix_query(gz, "chrNope", 1, 10) == []
+    # a larger synthetic table: many blocks, several contigs
+    big = ["chr%d\t%d\t%d\tDEL\tid%d" % (c, p, p + 50 + (p % 700), p) for c in (1, 2, 10) for p in range(5, 3000000, 1371)]
+    workflow.write_bed_gz_with_index(str(tmp_path / "big.bed.gz"), workflow.sort_rows(big))
+    assert gzip.open(str(tmp_path / "big.bed.gz"), "rt").read().splitlines() == workflow.sort_rows(big)
+    for chrom, a, b in (("chr2", 100000, 120000), ("chr10", 1, 5000), ("chr1", 2999000, 3100000)):
+        exp = [r for r in workflow.sort_rows(big) if r.split("\t")[0] == chrom and int(r.split("\t")[1]) < b and int(r.split("\t")[2]) > a - 1]
+        assert workflow.tabix_query(str(tmp_path / "big.bed.gz"), chrom, a, b) == exp

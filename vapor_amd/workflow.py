@@ -1,0 +1,254 @@
+"""Single-node workflow layer.
+
+The reference scales out with a WDL workflow: split the BED per contig, run `vapor bed` once per contig,
+then concatenate the per-contig tables, drop the header, `sort -Vk1,1 -k2,2n -k3,3n`, `bgzip` and `tabix -p bed`
+(wdl/VaPoRBedPerContig.wdl:45-85, wdl/TasksBenchmark.wdl:249-313).  On one node with several GPUs none of
+the scatter is needed - `vapor_amd.cli` shards the loci over the ranks of a torchrun launch - so this module
+is the gather side only: the same sorted, block-gzipped table plus its tabix index, written in-process
+(no bgzip / tabix binaries), and a launcher that runs the CLI on N GPUs and then produces them.
+
+    python -m vapor_amd.workflow --gpus 8 --prefix sample1 bed --sv-input x.bed --reference ref.fa \\
+           --pacbio-input reads.bam --output-path figs/ --output-file sample1.vapor
+
+writes sample1.vapor (the CLI's table, unchanged), sample1.bed.gz and sample1.bed.gz.tbi.
+
+Deliberate difference: the WDL's `tail -n+2` removes only the first shard's header line, so its merged table
+keeps one stray header row per further contig; here the header is dropped once and for all.
+"""
+from __future__ import annotations
+
+import os
+import re
+import struct
+import subprocess
+import sys
+import zlib
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+from .bamio import _BGZF_EOF, BgzfReader, reg2bin, reg2bins
+
+_BLOCK = 0xFF00            # uncompressed bytes per BGZF block, as bgzip writes them
+_NUM = re.compile(r"(\d+)")
+
+
+# ---------------------------------------------------------------------------------------------
+# sort -Vk1,1 -k2,2n -k3,3n
+# ---------------------------------------------------------------------------------------------
+def version_key(s: str):
+    """GNU `sort -V` on contig names: digit runs compare as numbers, the rest byte-wise (chr2 < chr10 < chrX)."""
+    parts = _NUM.split(s)
+    return [(0, int(p)) if k % 2 else (1, p) for k, p in enumerate(parts) if p != ""]
+
+
+def _num(field: str) -> float:
+    """`sort -n`: leading number, 0 when there is none."""
+    m = re.match(r"\s*-?\d+(\.\d+)?", field)
+    return float(m.group(0)) if m else 0.0
+
+
+def sort_rows(lines: Iterable[str]) -> List[str]:
+    def key(ln: str):
+        f = ln.split("\t")
+        return (version_key(f[0]), _num(f[1]) if len(f) > 1 else 0.0, _num(f[2]) if len(f) > 2 else 0.0, ln)
+    return sorted((ln for ln in lines if ln), key=key)
+
+
+# ---------------------------------------------------------------------------------------------
+# BGZF + tabix
+# ---------------------------------------------------------------------------------------------
+def _block(data: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(data) + comp.flush()
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25)
+            + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def write_bgzf(path: str, payload: bytes) -> List[int]:
+    """Writes `payload` as BGZF; returns the compressed offset of every block (for virtual offsets)."""
+    offs, out = [], bytearray()
+    for o in range(0, len(payload), _BLOCK):
+        offs.append(len(out))
+        out += _block(payload[o:o + _BLOCK])
+    offs.append(len(out))          # where the next block would start (the EOF block)
+    out += _BGZF_EOF
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+    return offs
+
+
+def _voff(block_offs: Sequence[int], u: int) -> int:
+    b = u // _BLOCK
+    if u % _BLOCK == 0 and b >= len(block_offs) - 1:
+        return block_offs[-1] << 16
+    return (block_offs[b] << 16) | (u % _BLOCK)
+
+
+def write_bed_gz_with_index(path: str, lines: Sequence[str], index: bool = True) -> None:
+    """`bgzip -c > path` and `tabix -f -p bed path` for already sorted BED-like rows (0-based start in column 2,
+    end in column 3, as tabix's bed preset reads them)."""
+    text = "".join(ln + "\n" for ln in lines).encode()
+    offs = write_bgzf(path, text)
+    if not index:
+        open(path + ".tbi", "wb").close()            # the WDL touches an empty index in that case
+        return
+    names: List[str] = []
+    bins: List[Dict[int, List[List[int]]]] = []
+    linear: List[List[int]] = []
+    pos = 0
+    for ln in lines:
+        n = len(ln.encode()) + 1
+        f = ln.split("\t")
+        if ln.startswith("#") or len(f) < 3:
+            pos += n
+            continue
+        if not names or names[-1] != f[0]:
+            if f[0] in names:
+                raise ValueError("rows are not grouped by contig: " + f[0])
+            names.append(f[0]); bins.append({}); linear.append([])
+        beg, end = int(_num(f[1])), int(_num(f[2]))
+        if end <= beg:
+            end = beg + 1
+        vs, ve = _voff(offs, pos), _voff(offs, pos + n)
+        ch = bins[-1].setdefault(reg2bin(beg, end), [])
+        if ch and ch[-1][1] == vs:
+            ch[-1][1] = ve
+        else:
+            ch.append([vs, ve])
+        lin = linear[-1]
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            while len(lin) <= w:
+                lin.append(0)
+            if lin[w] == 0:
+                lin[w] = vs
+        pos += n
+    nm = b"".join(x.encode() + b"\0" for x in names)
+    # format 0x10000 = UCSC/BED coordinates (0-based, half-open); columns 1, 2, 3; comment char '#'; skip 0
+    raw = b"TBI\x01" + struct.pack("<iiiiiiii", len(names), 0x10000, 1, 2, 3, ord("#"), 0, len(nm)) + nm
+    for t in range(len(names)):
+        lin, last = linear[t], 0
+        for w in range(len(lin)):
+            if lin[w] == 0:
+                lin[w] = last
+            last = lin[w]
+        raw += struct.pack("<i", len(bins[t]))
+        for b, ch in sorted(bins[t].items()):
+            raw += struct.pack("<Ii", b, len(ch)) + b"".join(struct.pack("<QQ", s, e) for s, e in ch)
+        raw += struct.pack("<i", len(lin)) + b"".join(struct.pack("<Q", v) for v in lin)
+    write_bgzf(path + ".tbi", raw)
+
+
+def read_bgzf(path: str) -> bytes:
+    """Whole content of a BGZF file (any gzip reader can do this; used by the tests and tabix_query)."""
+    import gzip
+    with gzip.open(path, "rb") as f:
+        return f.read()
+
+
+def tabix_query(path: str, chrom: str, start: int, end: int) -> List[str]:
+    """Rows of `path` overlapping chrom:start-end (1-based inclusive, like `tabix path chrom:start-end`), found
+    through the .tbi index."""
+    raw = read_bgzf(path + ".tbi")
+    if raw[:4] != b"TBI\x01":
+        raise ValueError("not a tabix index")
+    n_ref, _fmt, c_seq, c_beg, c_end, _meta, _skip, l_nm = struct.unpack_from("<iiiiiiii", raw, 4)
+    p = 36
+    names = raw[p:p + l_nm].split(b"\0")[:-1]
+    p += l_nm
+    want = names.index(chrom.encode()) if chrom.encode() in names else -1
+    chunks: List[Tuple[int, int]] = []
+    min_off = 0
+    beg, stop = max(start - 1, 0), end
+    for t in range(n_ref):
+        n_bin = struct.unpack_from("<i", raw, p)[0]; p += 4
+        d = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", raw, p); p += 8
+            d[b] = list(struct.iter_unpack("<QQ", raw[p:p + 16 * n_chunk])); p += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", raw, p)[0]; p += 4
+        lin = struct.unpack_from("<%dQ" % n_intv, raw, p) if n_intv else ()
+        p += 8 * n_intv
+        if t == want:
+            min_off = lin[min(beg >> 14, len(lin) - 1)] if lin else 0
+            for b in reg2bins(beg, stop):
+                chunks += [(max(s, min_off), e) for s, e in d.get(b, ()) if e > min_off]
+    out: List[str] = []
+    rd = BgzfReader(path)
+    merged: List[Tuple[int, int]] = []
+    for cs, ce in sorted(set(chunks)):
+        if merged and cs <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(merged[-1][1], ce))
+        else:
+            merged.append((cs, ce))
+    for cs, ce in merged:
+        cur = rd.read_from(cs)
+        buf = b""
+        while cur.tell() < ce:
+            piece = cur.read(1)
+            if not piece:
+                break
+            buf += piece
+            if piece == b"\n":
+                f = buf[:-1].decode().split("\t")
+                if f[c_seq - 1] == chrom and int(_num(f[c_beg - 1])) < stop and max(int(_num(f[c_end - 1])), int(_num(f[c_beg - 1])) + 1) > beg:
+                    out.append(buf[:-1].decode())
+                buf = b""
+    return out
+
+
+def merge_tables(tables: Sequence[str], prefix: str, index: bool = True) -> str:
+    """ConcatVaPoR (TasksBenchmark.wdl:249-313) for tables on local disk: header lines dropped, rows sorted,
+    written as <prefix>.bed.gz (+ .tbi).  Returns the path."""
+    rows: List[str] = []
+    for t in tables:
+        with open(t) as f:
+            for k, ln in enumerate(f):
+                ln = ln.rstrip("\n")
+                if k == 0 and ln.lstrip("#").startswith("CHR"):
+                    continue
+                rows.append(ln)
+    out = prefix + ".bed.gz"
+    write_bed_gz_with_index(out, sort_rows(rows), index)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------
+def main(argv: List[str] = None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    gpus, prefix, index = 1, None, True
+    while argv and argv[0].startswith("--"):
+        if argv[0] == "--gpus":
+            gpus = int(argv[1]); argv = argv[2:]
+        elif argv[0] == "--prefix":
+            prefix = argv[1]; argv = argv[2:]
+        elif argv[0] == "--no-index":
+            index = False; argv = argv[1:]
+        else:
+            break
+    if not argv or argv[0] not in ("bed", "vcf", "svelter"):
+        print(__doc__)
+        return 2
+    mode = argv[0]
+
+    def opt(name):
+        return argv[argv.index(name) + 1] if name in argv else None
+    table = opt("--sv-input") + ".vapor" if mode == "vcf" else opt("--output-file")
+    if prefix is None:
+        prefix = re.sub(r"\.vapor$", "", table)
+    if gpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29513"),
+               "-m", "vapor_amd.cli"] + argv
+        rc = subprocess.call(cmd)
+    else:
+        from . import cli
+        rc = cli.main(argv)
+    if rc != 0:
+        return rc
+    print(merge_tables([table], prefix, index))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
