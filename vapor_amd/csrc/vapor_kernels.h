@@ -410,23 +410,26 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
 {
     using KT = KeyT<BPS, K>;
     const int lane = threadIdx.x & 63;
-    bool hit[4] = {false, false, false, false};    // q * 2 + orientation
-    uint32_t who[2] = {0u, 0u};                    // il | e << 11
+    // Both candidates of a lane go through the same straight-line code (a lane without a second candidate
+    // re-reads item 0 and masks the result): with a branch per candidate the LDS reads of the second would only
+    // start when the first is done.
+    bool hit[4];                                   // q * 2 + orientation
+    uint32_t who[2];                               // il | e << 11
+    uint32_t item[2], e[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) item[q] = myq[from + ((q * 64 + lane < n) ? q * 64 + lane : 0)];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) e[q] = entries[item[q] & 0xFFFFu];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int idx = q * 64 + lane;
-        if (idx < n) {
-            const uint32_t item = myq[from + idx];
-            const uint32_t il = item >> 16;
-            const uint32_t e = entries[item & 0xFFFFu];
-            KT kf = extract_key<BPS, K>(rbuf, il);
-            KT a = extract_key<BPS, K>(tile, e);
-            KT kr = revcomp_key<BPS, K>(kf);
-            const bool in = ts + (int)e >= off2;
-            hit[q * 2] = in && (a == kf);
-            hit[q * 2 + 1] = in && (a == kr);
-            who[q] = il | (e << 11);
-        }
+        const uint32_t il = item[q] >> 16;
+        const KT kf = extract_key<BPS, K>(rbuf, il);
+        const KT a = extract_key<BPS, K>(tile, e[q]);
+        const KT kr = revcomp_key<BPS, K>(kf);
+        const bool in = (q * 64 + lane < n) && ts + (int)e[q] >= off2;
+        hit[q * 2] = in && (a == kf);
+        hit[q * 2 + 1] = in && (a == kr);
+        who[q] = il | (e[q] << 11);
     }
     const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]), m2 = __ballot(hit[2]), m3 = __ballot(hit[3]);
     const uint32_t n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
@@ -687,8 +690,10 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                                 valid = valid && (((EE >> t) & KM) == 0ULL);
                             }
                             const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(kf, kr);
+                            // unconditional reads and an arithmetic mask: a predicated read would put a wait
+                            // inside every position's own branch and serialise the four lookups
                             const uint32_t s0 = start16[h], s1v = start16[h + 1];
-                            sc[t4] = valid ? (s0 | ((s1v - s0) << 16)) : 0u;
+                            sc[t4] = (s0 | ((s1v - s0) << 16)) & (valid ? 0xFFFFFFFFu : 0u);
                         }
                         pc.mark(2, pw);                    // keys + bucket bounds issued
                         // ---- four wave prefix sums of the bucket sizes, interleaved -------------------------
