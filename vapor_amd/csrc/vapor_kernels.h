@@ -697,11 +697,25 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                         }
                         pc.mark(2, pw);                    // keys + bucket bounds issued
                         // ---- four wave prefix sums of the bucket sizes, interleaved -------------------------
+                        // Bucket sizes are tiny almost always, so the four sums share one register (8-bit fields: every
+                        // size below 4, totals below 256) or two (16-bit fields: sizes below 512); four separate
+                        // scans only where a repeat makes a bucket large.
                         uint32_t incl[4];
+                        {
+                            const uint32_t c0 = sc[0] >> 16, c1 = sc[1] >> 16, c2 = sc[2] >> 16, c3 = sc[3] >> 16;
+                            const uint32_t big = c0 | c1 | c2 | c3;
+                            if (!__ballot(big >= 4u)) {
+                                const uint32_t p = wave_scan<OpAdd>(c0 | (c1 << 8) | (c2 << 16) | (c3 << 24), 0u);
+                                incl[0] = p & 0xFFu; incl[1] = (p >> 8) & 0xFFu; incl[2] = (p >> 16) & 0xFFu; incl[3] = p >> 24;
+                            } else if (!__ballot(big >= 512u)) {
+                                const uint32_t p = wave_scan<OpAdd>(c0 | (c1 << 16), 0u), q = wave_scan<OpAdd>(c2 | (c3 << 16), 0u);
+                                incl[0] = p & 0xFFFFu; incl[1] = p >> 16; incl[2] = q & 0xFFFFu; incl[3] = q >> 16;
+                            } else {
+                                incl[0] = c0; incl[1] = c1; incl[2] = c2; incl[3] = c3;
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) incl[x] = sc[x] >> 16;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) incl[x] = wave_scan<OpAdd>(incl[x], 0u);
+                                for (int x = 0; x < 4; ++x) incl[x] = wave_scan<OpAdd>(incl[x], 0u);
+                            }
+                        }
                         pc.mark(3, pw);                    // scans (waits for the bucket reads)
                         // ---- fill the queue position by position; verify 128 candidates whenever they are there
 #pragma unroll
