@@ -294,7 +294,7 @@ def test_run_records_expand_to_the_oracle_dots(eng, oracle):
     nearly = synth.mutate(np.random.default_rng(5), allele[300:5600], 0.001, 0.002, 0.002)[0]
     inv = allele[500:2000] + synth.revcomp(allele[2000:3500]) + allele[3500:5000]
     with_n = exact[:2000] + "N" + exact[2001:]
-    big = synth.random_dna(rng, 36000)                                  # 31 744-position tiles: two of them
+    big = synth.random_dna(rng, 36000)                                  # 24 576-position tiles: two of them
     long_read = big[30000:35500]
     seqs = [allele, exact, nearly, inv, with_n, big, long_read]
     rows = [(1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (3, 0, 0, 10, 7), (1, 0, 913, 10, 3), (4, 0, 0, 10, 7),

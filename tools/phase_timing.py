@@ -28,7 +28,7 @@ from vapor_amd import workload as wl
 from vapor_amd.engine import Engine
 
 NAMES = {0: "join: table build (+wait prev probe)", 1: "join: strip staging", 2: "join: keys + bucket reads issued",
-         3: "join: scans", 4: "join: queue fill", 5: "join: verify + store", 6: "join: tail wait",
+         3: "join: scans", 4: "join: queue fill", 5: "join: verify + store", 6: "join: tail wait", 7: "join: CANDIDATES (count, not ticks)",
          8: "clean: pass 0 (stage, bitmap i-j)", 9: "clean: body total", 10: "clean: flag write-back",
          16: "clean: axis1 bitmap", 17: "clean: axis1 starts+ranks", 18: "clean: axis1 sizes", 19: "clean: axis1 flags",
          20: "clean: axis2 bitmap", 21: "clean: axis2 starts+ranks", 22: "clean: axis2 sizes", 23: "clean: axis2 flags",

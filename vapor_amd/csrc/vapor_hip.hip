@@ -421,6 +421,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     chk(hipMalloc((void**)&p->d_tasks, sizeof(DTask) * std::max<size_t>(p->tasks.size(), 1)), "hipMalloc tasks");
     chk(hipMalloc((void**)&p->d_task_pairs, sizeof(int32_t) * std::max<size_t>(order.size(), 1)), "hipMalloc task_pairs");
     chk(hipMalloc((void**)&p->d_nhits, sizeof(unsigned long long) * p->hp.size()), "hipMalloc nhits");
+    if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), ctx->stream), "memset nhits");
     chk(hipMalloc((void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
     chk(hipHostMalloc((void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
     chk(hipMalloc((void**)&p->d_overflow, 2 * sizeof(unsigned int)), "hipMalloc overflow");
@@ -442,12 +443,12 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
 }
 
 template <int BPS, int K>
-static void launch_join(vapor_plan* p, const Launch& L)
+static void launch_join(vapor_plan* p, const Launch& L, bool first)
 {
     const vapor_seqset* s = p->set;
     hipLaunchKernelGGL((join_kernel<JoinBig, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinBig::THREADS), (join_lds_bytes<JoinBig, BPS>()),
                        p->ctx->stream, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
-                       p->d_task_pairs, p->d_hits, p->d_nhits);
+                       p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }
 
 static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 / 10 + 8; }
@@ -486,22 +487,24 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = c->stream;
-    HIPCHK(hipEventRecord(p->ev_t0, st));
-    HIPCHK(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), st));
-    HIPCHK(hipMemsetAsync(p->d_overflow, 0, 2 * sizeof(unsigned int), st));
-    HIPCHK(hipEventRecord(p->ev[0], st));       // join time = first join launch .. last join end (no memsets)
+    // no memsets in the steady state: the pair counts are stored whole by the join, the clean kernels' two
+    // counters are cleared by the first join launch
+    if (p->launches.empty()) HIPCHK(hipMemsetAsync(p->d_overflow, 0, 2 * sizeof(unsigned int), st));
+    HIPCHK(hipEventRecord(p->ev[0], st));       // start of the run and of the join
+    bool first = true;
     for (const Launch& L : p->launches) {
         if (L.bps == 2) {
-            if (L.k == 10) launch_join<2, 10>(p, L);
-            else if (L.k == 20) launch_join<2, 20>(p, L);
-            else if (L.k == 30) launch_join<2, 30>(p, L);
-            else launch_join<2, 40>(p, L);
+            if (L.k == 10) launch_join<2, 10>(p, L, first);
+            else if (L.k == 20) launch_join<2, 20>(p, L, first);
+            else if (L.k == 30) launch_join<2, 30>(p, L, first);
+            else launch_join<2, 40>(p, L, first);
         } else {
-            if (L.k == 10) launch_join<4, 10>(p, L);
-            else if (L.k == 20) launch_join<4, 20>(p, L);
-            else if (L.k == 30) launch_join<4, 30>(p, L);
-            else launch_join<4, 40>(p, L);
+            if (L.k == 10) launch_join<4, 10>(p, L, first);
+            else if (L.k == 20) launch_join<4, 20>(p, L, first);
+            else if (L.k == 30) launch_join<4, 30>(p, L, first);
+            else launch_join<4, 40>(p, L, first);
         }
+        first = false;
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(p->ev[1], st));
@@ -523,7 +526,6 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
     if (!fetch_stats) {
         // device-side finishing: the statistics stay in HBM, only the overflow count comes back
         HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(p->ev[3], st));
         return VAPOR_OK;
     }
     HIPCHK(hipEventRecord(p->ev[3], st));
@@ -531,7 +533,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
     float a = 0, b = 0, t = 0;
     HIPCHK(hipEventElapsedTime(&a, p->ev[0], p->ev[1]));
     HIPCHK(hipEventElapsedTime(&b, p->ev[1], p->ev[2]));
-    HIPCHK(hipEventElapsedTime(&t, p->ev_t0, p->ev[3]));
+    HIPCHK(hipEventElapsedTime(&t, p->ev[0], p->ev[3]));
     p->t_join = a; p->t_clean = b; p->t_total = t;
     return VAPOR_OK;
 }
@@ -848,18 +850,16 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
         rc = plan_run_once(p, false);
         if (rc != VAPOR_OK) return rc;
     }
-    hipEvent_t e0 = p->ev_f[0], e1 = p->ev_f[1];
-    HIPCHK(hipEventRecord(e0, st));
+    hipEvent_t e1 = p->ev_f[1];                  // the finish kernel starts where the clean kernels end (ev[2])
+    double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
     if (p->n_loci > 0) {
         hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, st, p->d_reads, p->d_locus_first, p->d_stats,
-                           p->d_gt, p->d_read_scores, p->d_loci);
+                           p->d_gt, p->d_read_scores, d_out);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(e1, st));
-    if (d_loci_out && p->n_loci)
-        HIPCHK(hipMemcpyAsync(d_loci_out, p->d_loci, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToDevice, st));
     if (loci_out && p->n_loci)
-        HIPCHK(hipMemcpyAsync(loci_out, p->d_loci, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(loci_out, d_out, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
     if (read_scores && p->n_reads)
         HIPCHK(hipMemcpyAsync(read_scores, p->d_read_scores, sizeof(double) * (size_t)p->n_reads, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -870,10 +870,10 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
         return vapor_plan_run_loci(p, d_loci_out, loci_out, read_scores);
     }
     float f = 0, a = 0, b = 0, t = 0;
-    HIPCHK(hipEventElapsedTime(&f, e0, e1));
+    HIPCHK(hipEventElapsedTime(&f, p->ev[2], e1));
     p->t_finish = f;
     if (hipEventElapsedTime(&a, p->ev[0], p->ev[1]) == hipSuccess && hipEventElapsedTime(&b, p->ev[1], p->ev[2]) == hipSuccess &&
-        hipEventElapsedTime(&t, p->ev_t0, e1) == hipSuccess) {
+        hipEventElapsedTime(&t, p->ev[0], e1) == hipSuccess) {
         p->t_join = a; p->t_clean = b; p->t_total = t;
     }
     return VAPOR_OK;

@@ -248,10 +248,10 @@ __device__ __forceinline__ bool any_exc(P plane, uint32_t pos)
 // the table is rebuilt only when the allele changes inside the range.
 constexpr int JCHUNK = 1024;                      // read positions per wave pass (16 per lane)
 
-// Geometry of the join workgroup: it owns a whole CU's LDS (16 waves, one table of up to 31744 positions
+// Geometry of the join workgroup: it owns a whole CU's LDS (16 waves, one table of up to 24576 positions
 // in 32768 buckets).  Smaller tables would not raise residency: at ~117 VGPRs four waves per SIMD is the
 // register limit as well.
-struct JoinBig { static constexpr int THREADS = 1024, TA2 = 31744, TA4 = 16384, NB_LOG2 = 15, QCAP = 256; };
+struct JoinBig { static constexpr int THREADS = 1024, TA2 = 24576, TA4 = 16384, NB_LOG2 = 15, FILT_LOG2 = 17, QCAP = 256; };
 
 template <typename C, int BPS> __host__ __device__ constexpr int tile_pos() { return BPS == 2 ? C::TA2 : C::TA4; }
 template <typename C, int BPS> __host__ __device__ constexpr int tile_words() { return ((tile_pos<C, BPS>() + 64) * BPS) / 32 + 8; }
@@ -261,7 +261,8 @@ template <int BPS> __host__ __device__ constexpr int rbuf_words() { return ((JCH
 template <typename C, int BPS>
 constexpr size_t join_lds_bytes()
 {
-    return sizeof(uint32_t) * ((1 << C::NB_LOG2) / 2 + 2) + sizeof(uint32_t) * tile_words<C, BPS>() +
+    return sizeof(uint32_t) * ((1 << C::NB_LOG2) / 2 + 2) + sizeof(uint32_t) * ((1 << C::FILT_LOG2) / 32) +
+           sizeof(uint32_t) * tile_words<C, BPS>() +
            sizeof(uint32_t) * etile_words<C, BPS>() + sizeof(unsigned long long) * MAX_READS_PER_TASK +
            sizeof(uint32_t) * (C::THREADS / 64) * C::QCAP + sizeof(uint32_t) * (C::THREADS / 64) * rbuf_words<BPS>() +
            sizeof(uint32_t) * (2 * (C::THREADS / 64) + 4 + MAX_READS_PER_TASK + 2) + sizeof(uint16_t) * tile_pos<C, BPS>();
@@ -279,8 +280,10 @@ __device__ __forceinline__ bool key_less(const KeyT<BPS, K>& a, const KeyT<BPS, 
     return lt;
 }
 
-template <int NBL, int BPS, int K>
-__device__ __forceinline__ uint32_t canon_bucket(const KeyT<BPS, K>& k, const KeyT<BPS, K>& rc)
+// 32-bit hash of the canonical key: its top NB_LOG2 bits are the bucket, its top FILT_LOG2 bits the bit of the
+// occupancy filter (so a filter bit covers a quarter of a bucket's key space)
+template <int BPS, int K>
+__device__ __forceinline__ uint32_t canon_hash(const KeyT<BPS, K>& k, const KeyT<BPS, K>& rc)
 {
     using KT = KeyT<BPS, K>;
     const bool use_rc = key_less<BPS, K>(rc, k);
@@ -290,7 +293,7 @@ __device__ __forceinline__ uint32_t canon_bucket(const KeyT<BPS, K>& k, const Ke
     if (KT::NW > 3) x ^= (use_rc ? rc.w[3] : k.w[3]) * 0x27D4EB2Fu;
     if (KT::NW > 4) x ^= (use_rc ? rc.w[4] : k.w[4]) * 0x165667B1u;
     if (KT::NW > 1) { x ^= x >> 15; x *= 0x2C1B3C6Du; }
-    return x >> (32 - NBL);
+    return x;
 }
 
 // Cross-lane steps as DPP modifiers of VALU instructions (gfx9: row_shr, wave_shr, row_bcast15/31) instead of
@@ -341,6 +344,12 @@ struct PhaseClockT {
             if (x == k - BASE) acc[x] += (unsigned long long)(t - last);
         last = t;
     }
+    __device__ __forceinline__ void count(int k, unsigned long long v)
+    {
+#pragma unroll
+        for (int x = 0; x < N; ++x)
+            if (x == k - BASE) acc[x] += v;
+    }
     __device__ __forceinline__ void flush(bool who)
     {
         if (who) {
@@ -354,10 +363,11 @@ struct PhaseClockT {
 template <int BASE, int N>
 struct PhaseClockT {
     __device__ __forceinline__ void mark(int, bool) {}
+    __device__ __forceinline__ void count(int, unsigned long long) {}
     __device__ __forceinline__ void flush(bool) {}
 };
 #endif
-using JoinClock = PhaseClockT<0, 7>;
+using JoinClock = PhaseClockT<0, 8>;
 using CleanClock = PhaseClockT<8, 28>;
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
@@ -410,6 +420,9 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
 {
     using KT = KeyT<BPS, K>;
     const int lane = threadIdx.x & 63;
+#ifdef VAPOR_ABL_NOVERIFY
+    return;
+#endif
     // Both candidates of a lane go through the same straight-line code (a lane without a second candidate
     // re-reads item 0 and masks the result): with a branch per candidate the LDS reads of the second would only
     // start when the first is done.
@@ -491,16 +504,22 @@ template <typename C, int BPS, int K>
 __global__ __launch_bounds__(C::THREADS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
-    const int32_t* __restrict__ task_pairs, unsigned long long* __restrict__ hits, unsigned long long* __restrict__ n_hits)
+    const int32_t* __restrict__ task_pairs, unsigned long long* __restrict__ hits, unsigned long long* __restrict__ n_hits,
+    unsigned int* __restrict__ reset2)
 {
     using KT = KeyT<BPS, K>;
     constexpr int TA = tile_pos<C, BPS>();
+    // the first join launch of a run clears the two counters of the clean kernels (overflowed pairs, length of
+    // the big-pair list), which saves the run a memset; every count of a pair is stored whole at the end, so
+    // n_hits needs no clearing at all
+    if (reset2 && blockIdx.x == 0 && threadIdx.x < 2) reset2[threadIdx.x] = 0u;
     constexpr int JQCAP = C::QCAP;
     constexpr int JOIN_THREADS = C::THREADS, JOIN_WAVES = C::THREADS / 64;
     constexpr int JNB_LOG2 = C::NB_LOG2, JNB = 1 << C::NB_LOG2;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* start32 = lds;                                                  // JNB/2 + 2 words: u16 pairs
-    uint32_t* tile = start32 + (JNB / 2 + 2);
+    uint32_t* filt = start32 + (JNB / 2 + 2);                                // 2^FILT_LOG2 bits
+    uint32_t* tile = filt + (1 << C::FILT_LOG2) / 32;
     uint32_t* etile = tile + tile_words<C, BPS>();
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + etile_words<C, BPS>());
     uint32_t* queue = reinterpret_cast<uint32_t*>(cnt + MAX_READS_PER_TASK);   // JOIN_WAVES * JQCAP
@@ -534,7 +553,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
         for (int ts = 0; ts < nk2; ts += TA) {
             const int tn = min(TA, nk2 - ts);
             __syncthreads();                       // previous table fully probed
-            for (int x = tid; x < JNB / 2 + 2; x += JOIN_THREADS) start32[x] = 0u;
+            for (int x = tid; x < JNB / 2 + 2 + (1 << C::FILT_LOG2) / 32; x += JOIN_THREADS) start32[x] = 0u;   // counters and filter
             {
                 const uint32_t* src = plane + (size_t)s2.chunk0 * WPC + (((size_t)ts * BPS) >> 5);
                 const int nw = ((tn + K - 1) * BPS + 31) / 32 + 2;
@@ -554,8 +573,10 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                 else ok = !key_has_invalid<BPS, K>(key);
                 if (ok) {
                     KT rc = revcomp_key<BPS, K>(key);
-                    const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(key, rc);
+                    const uint32_t hx = canon_hash<BPS, K>(key, rc);
+                    const uint32_t h = hx >> (32 - JNB_LOG2), fb = hx >> (32 - C::FILT_LOG2);
                     atomicAdd(&start32[h >> 1], 1u << ((h & 1u) * 16));
+                    if (!(filt[fb >> 5] & (1u << (fb & 31u)))) atomicOr(&filt[fb >> 5], 1u << (fb & 31u));
                 }
             }
             __syncthreads();
@@ -592,7 +613,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                 else ok = !key_has_invalid<BPS, K>(key);
                 if (ok) {
                     KT rc = revcomp_key<BPS, K>(key);
-                    const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(key, rc);
+                    const uint32_t h = canon_hash<BPS, K>(key, rc) >> (32 - JNB_LOG2);
                     const uint32_t sh = (h & 1u) * 16;
                     uint32_t old = atomicSub(&start32[h >> 1], 1u << sh);
                     entries[((old >> sh) & 0xFFFFu) - 1u] = (uint16_t)p;
@@ -689,11 +710,17 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                                 constexpr unsigned long long KM = (1ULL << K) - 1ULL;
                                 valid = valid && (((EE >> t) & KM) == 0ULL);
                             }
-                            const uint32_t h = canon_bucket<JNB_LOG2, BPS, K>(kf, kr);
+                            const uint32_t hx = canon_hash<BPS, K>(kf, kr);
+                            const uint32_t h = hx >> (32 - JNB_LOG2), fb = hx >> (32 - C::FILT_LOG2);
                             // unconditional reads and an arithmetic mask: a predicated read would put a wait
-                            // inside every position's own branch and serialise the four lookups
-                            const uint32_t s0 = start16[h], s1v = start16[h + 1];
-                            sc[t4] = (s0 | ((s1v - s0) << 16)) & (valid ? 0xFFFFFFFFu : 0u);
+                            // inside every position's own branch and serialise the four lookups.  The filter bit
+                            // says whether any allele k-mer shares these 17 hash bits: without it two in three
+                            // candidates are mere bucket mates of nothing.
+                            const uint32_t s0 = start16[h], s1v = start16[h + 1], fw = filt[fb >> 5];
+                            sc[t4] = (s0 | ((s1v - s0) << 16)) & ((valid && ((fw >> (fb & 31u)) & 1u)) ? 0xFFFFFFFFu : 0u);
+#ifdef VAPOR_ABL_NOCAND
+                            sc[t4] &= 0xFFFFu;
+#endif
                         }
                         pc.mark(2, pw);                    // keys + bucket bounds issued
                         // ---- four wave prefix sums of the bucket sizes, interleaved -------------------------
@@ -722,6 +749,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                         for (int x = 0; x < 4; ++x) {
                             const uint32_t c = sc[x] >> 16, s0 = sc[x] & 0xFFFFu;
                             const uint32_t tot = __builtin_amdgcn_readlane(incl[x], 63);
+                            pc.count(7, tot);                  // candidates
                             if (tot == 0) continue;
                             const uint32_t il = (uint32_t)(16 * lane + g * 4 + x);
                             if (tot > (uint32_t)(JQCAP - 127)) {
@@ -752,7 +780,10 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                                 const uint32_t item = (il << 16) | s0;
                                 if (c > 0u) myq[pos] = item;
                                 if (c > 1u) myq[pos + 1] = item + 1u;
-                                for (uint32_t u = 2; u < c; ++u) myq[pos + u] = item + u;
+                                // larger buckets level by level, uniformly (a per-lane loop here compiles to a
+                                // long divergent sequence that nearly every step would enter for one lane)
+                                for (uint32_t u = 2; __ballot(c > u); ++u)
+                                    if (c > u) myq[pos + u] = item + u;
                             }
                             qlen += (int)tot;
                             if (qlen >= 128) {
