@@ -314,3 +314,23 @@ def test_run_records_expand_to_the_oracle_dots(eng, oracle):
     assert rec[4] == st[4, 0]                     # the N switches run forming off for this pair
     plan.close()
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "runs")
+
+
+def test_async_steps_equal_blocking_run(eng):
+    """vapor_plan_run_loci_async / vapor_plan_sync: the enqueue-only steps give the records of the blocking run,
+    more steps than event sets are fine, and the timings are per-step averages."""
+    from vapor_amd import workload as wl
+    w = wl.make_workload("tiny", seed=5, **wl.WORKLOADS["tiny"])
+    ss = eng.seqset(w.seqs)
+    plan = eng.plan(ss, w.pairs)
+    plan.set_reads(wl.read_table(w), w.n_loci)
+    with pytest.raises(Exception):
+        plan.run_loci_async()                      # needs one blocking run first
+    ref = plan.run_loci().copy()
+    for _ in range(70):
+        plan.run_loci_async()
+    got = plan.sync().copy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    tm = plan.timings()
+    assert 0 < tm["join_ms"] < 50 and 0 < tm["clean_ms"] < 50 and tm["total_ms"] >= tm["join_ms"]
+    plan.close()

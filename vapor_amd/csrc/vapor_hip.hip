@@ -14,6 +14,7 @@
 #include <new>
 #include <numeric>
 #include <string>
+#include <array>
 #include <vector>
 
 using namespace vapor;
@@ -36,6 +37,7 @@ static int fail(int code, const std::string& msg)
 struct vapor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;          // the stream vapor_init created (vapor_set_stream may replace `stream`)
     int reads_per_task = MAX_READS_PER_TASK;   // upper bound on pairs per join task
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
@@ -78,6 +80,12 @@ struct vapor_plan {
     long long* h_stats = nullptr;  // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_f[2] = {nullptr, nullptr};
+    // vapor_plan_run_loci_async: one set of four events per step in flight, summed by vapor_plan_sync
+    std::vector<std::array<hipEvent_t, 4>> ring;
+    int ring_n = 0;
+    double acc_ms[4] = {0, 0, 0, 0};           // join, clean, finish, total of the steps already folded in
+    int64_t acc_n = 0;
+    double* h_loci = nullptr;                  // pinned copy of the per-locus records of the last async step
     hipEvent_t ev_t0 = nullptr;
     double t_join = 0, t_clean = 0, t_total = 0;
     int n_retried = 0;
@@ -132,6 +140,7 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(clean): ") + hipGetErrorString(e)); }
+    c->own_stream = c->stream;
     *out = c;
     return VAPOR_OK;
 }
@@ -140,7 +149,7 @@ extern "C" int vapor_destroy(vapor_ctx* c)
 {
     if (!c) return VAPOR_OK;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return VAPOR_OK;
 }
@@ -292,6 +301,10 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
     (void)hipFree(p->d_big_list);
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& r : p->ring)
+        for (auto& e : r)
+            if (e) (void)hipEventDestroy(e);
+    if (p->h_loci) (void)hipHostFree(p->h_loci);
     for (auto& e : p->ev_f)
         if (e) (void)hipEventDestroy(e);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -424,7 +437,8 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), ctx->stream), "memset nhits");
     chk(hipMalloc((void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
     chk(hipHostMalloc((void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
-    chk(hipMalloc((void**)&p->d_overflow, 2 * sizeof(unsigned int)), "hipMalloc overflow");
+    chk(hipMalloc((void**)&p->d_overflow, 4 * sizeof(unsigned int)), "hipMalloc overflow");
+    if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_overflow, 0, 4 * sizeof(unsigned int), ctx->stream), "memset overflow");
     chk(hipMalloc((void**)&p->d_big_list, sizeof(int32_t) * p->hp.size()), "hipMalloc big list");
     chk(hipHostMalloc((void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
@@ -483,14 +497,15 @@ static size_t clean_lds_bytes(int range_words_cap, int hcap)
     return clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 9 + 8;
 }
 
-static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
+static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = c->stream;
+    hipEvent_t* ev = evs ? evs : p->ev;
     // no memsets in the steady state: the pair counts are stored whole by the join, the clean kernels' two
     // counters are cleared by the first join launch
     if (p->launches.empty()) HIPCHK(hipMemsetAsync(p->d_overflow, 0, 2 * sizeof(unsigned int), st));
-    HIPCHK(hipEventRecord(p->ev[0], st));       // start of the run and of the join
+    HIPCHK(hipEventRecord(ev[0], st));       // start of the run and of the join
     bool first = true;
     for (const Launch& L : p->launches) {
         if (L.bps == 2) {
@@ -507,7 +522,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
         first = false;
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(p->ev[1], st));
+    HIPCHK(hipEventRecord(ev[1], st));
     if (p->n_pairs > 0) {
         int hcap = clean_hcap(p->range_words_cap, p->hcap_want);
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
@@ -520,7 +535,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
                            p->d_stats, p->range_words_cap, clean_groups_cap(p->range_words_cap), p->d_overflow, p->d_big_list);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(p->ev[2], st));
+    HIPCHK(hipEventRecord(ev[2], st));
     if (p->n_pairs > 0 && fetch_stats)
         HIPCHK(hipMemcpyAsync(p->h_stats, p->d_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyDeviceToHost, st));
     if (!fetch_stats) {
@@ -528,12 +543,12 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true)
         HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         return VAPOR_OK;
     }
-    HIPCHK(hipEventRecord(p->ev[3], st));
+    HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipStreamSynchronize(st));
     float a = 0, b = 0, t = 0;
-    HIPCHK(hipEventElapsedTime(&a, p->ev[0], p->ev[1]));
-    HIPCHK(hipEventElapsedTime(&b, p->ev[1], p->ev[2]));
-    HIPCHK(hipEventElapsedTime(&t, p->ev[0], p->ev[3]));
+    HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
+    HIPCHK(hipEventElapsedTime(&t, ev[0], ev[3]));
     p->t_join = a; p->t_clean = b; p->t_total = t;
     return VAPOR_OK;
 }
@@ -758,7 +773,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
     hipStream_t st = ctx->stream;
-    chk(hipMalloc((void**)&d_ov, 2 * sizeof(unsigned int)), "hipMalloc");
+    chk(hipMalloc((void**)&d_ov, 4 * sizeof(unsigned int)), "hipMalloc");
     chk(hipMalloc((void**)&d_big, sizeof(int32_t) * dp.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_dp, sizeof(DPair) * dp.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_nh, sizeof(unsigned long long) * nh.size()), "hipMalloc");
@@ -766,7 +781,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     chk(hipMalloc((void**)&d_fl, packed.size()), "hipMalloc");
     chk(hipMalloc((void**)&d_st, sizeof(long long) * 16 * (size_t)n_lists), "hipMalloc");
     if (rc == VAPOR_OK) {
-        chk(hipMemsetAsync(d_ov, 0, 2 * sizeof(unsigned int), st), "memset");
+        chk(hipMemsetAsync(d_ov, 0, 4 * sizeof(unsigned int), st), "memset");
         chk(hipMemcpyAsync(d_dp, dp.data(), sizeof(DPair) * dp.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_nh, nh.data(), sizeof(unsigned long long) * nh.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(unsigned long long) * packed.size(), hipMemcpyHostToDevice, st), "copy");
@@ -879,6 +894,93 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     return VAPOR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same run without a host round trip per step: enqueue only, vapor_plan_sync() waits and reports.
+constexpr int ASYNC_RING = 64;
+
+extern "C" int vapor_set_stream(vapor_ctx* c, void* hip_stream)
+{
+    if (!c) return fail(VAPOR_E_ARG, "vapor_set_stream: null context");
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return VAPOR_OK;
+}
+
+// waits for the steps in flight and adds their event times to the accumulators
+static int async_fold(vapor_plan* p)
+{
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    for (int i = 0; i < p->ring_n; ++i) {
+        float x = 0;
+        hipEvent_t* ev = p->ring[(size_t)i].data();
+        HIPCHK(hipEventElapsedTime(&x, ev[0], ev[1])); p->acc_ms[0] += x;
+        HIPCHK(hipEventElapsedTime(&x, ev[1], ev[2])); p->acc_ms[1] += x;
+        HIPCHK(hipEventElapsedTime(&x, ev[2], ev[3])); p->acc_ms[2] += x;
+        HIPCHK(hipEventElapsedTime(&x, ev[0], ev[3])); p->acc_ms[3] += x;
+    }
+    p->acc_n += p->ring_n;
+    p->ring_n = 0;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
+{
+    if (!p) return fail(VAPOR_E_ARG, "vapor_plan_run_loci_async: null plan");
+    if (!p->d_reads) return fail(VAPOR_E_ARG, "vapor_plan_run_loci_async: call vapor_plan_set_reads first");
+    if (!p->ran) return fail(VAPOR_E_ARG, "vapor_plan_run_loci_async: run the plan once with vapor_plan_run_loci first (it sizes the slots)");
+    for (int64_t i = 0; i < p->n_pairs; ++i)
+        if (p->status[i] != 0) return fail(VAPOR_E_ARG, "vapor_plan_run_loci_async: the plan holds pairs the host rejected; use vapor_plan_run_loci");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    if (p->ring_n >= ASYNC_RING) {              // every event set is in use: wait for those steps, keep their times
+        int rc0 = async_fold(p);
+        if (rc0 != VAPOR_OK) return rc0;
+    }
+    hipStream_t st = p->ctx->stream;
+    if (p->ring.empty()) {
+        p->ring.resize(ASYNC_RING);
+        for (auto& r : p->ring)
+            for (auto& e : r) { e = nullptr; HIPCHK(hipEventCreate(&e)); }
+        HIPCHK(hipHostMalloc((void**)&p->h_loci, sizeof(double) * 8 * (size_t)std::max<int64_t>(p->n_loci, 1)));
+    }
+    hipEvent_t* ev = p->ring[(size_t)p->ring_n].data();
+    int rc = plan_run_once(p, false, ev);
+    if (rc != VAPOR_OK) return rc;
+    double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
+    if (p->n_loci > 0) {
+        hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, st, p->d_reads, p->d_locus_first, p->d_stats,
+                           p->d_gt, p->d_read_scores, d_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(p->h_loci, d_out, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipEventRecord(ev[3], st));
+    ++p->ring_n;
+    return VAPOR_OK;
+}
+
+// waits for the steps in flight; timings() then reports their averages; loci_out (may be NULL) receives the
+// records of the last step.  VAPOR_E_OVERFLOW if a pair outgrew its slot in one of them (run vapor_plan_run_loci).
+extern "C" int vapor_plan_sync(vapor_plan* p, double* loci_out)
+{
+    if (!p) return fail(VAPOR_E_ARG, "vapor_plan_sync: null plan");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const int had = p->ring_n;
+    int rc0 = async_fold(p);
+    if (rc0 != VAPOR_OK) return rc0;
+    if (p->acc_n > 0) {
+        p->t_join = (float)(p->acc_ms[0] / p->acc_n); p->t_clean = (float)(p->acc_ms[1] / p->acc_n);
+        p->t_finish = (float)(p->acc_ms[2] / p->acc_n); p->t_total = (float)(p->acc_ms[3] / p->acc_n);
+        if (loci_out && p->n_loci && (had > 0 || p->h_loci)) memcpy(loci_out, p->h_loci, sizeof(double) * 8 * (size_t)p->n_loci);
+    }
+    p->acc_ms[0] = p->acc_ms[1] = p->acc_ms[2] = p->acc_ms[3] = 0;
+    p->acc_n = 0;
+    unsigned int sticky = 0;
+    HIPCHK(hipMemcpy(&sticky, p->d_overflow + 2, sizeof(unsigned int), hipMemcpyDeviceToHost));
+    if (sticky) {
+        HIPCHK(hipMemset(p->d_overflow + 2, 0, sizeof(unsigned int)));
+        return fail(VAPOR_E_OVERFLOW, "a pair outgrew its record slot during the asynchronous steps; run vapor_plan_run_loci (it resizes)");
+    }
+    return VAPOR_OK;
+}
 
 #ifdef VAPOR_PHASE_TIMING
 // developer build only: read (and clear) the per-phase tick sums

@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
             if (tid == 15 && nrec) v = -2;        // VAPOR_E_OVERFLOW
             st[tid] = v;
         }
-        if (tid == 0 && nrec && overflow) atomicAdd(&overflow[0], 1u);
+        if (tid == 0 && nrec && overflow) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }   // [2]: never cleared by the join
         return;
     }
     const int n = (int)nrec;                   // cap < 2^31

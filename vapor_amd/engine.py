@@ -102,6 +102,15 @@ class Plan:
                                              L.ptr(self.read_scores, ctypes.c_double) if want_scores else None))
         return self.loci[:self.n_loci]
 
+    def run_loci_async(self, device_out: int = 0) -> None:
+        """Enqueue join -> clean -> finish without waiting (after one run_loci(), which sizes the slots)."""
+        L.check(L.load().vapor_plan_run_loci_async(self._h, ctypes.c_void_p(device_out) if device_out else None))
+
+    def sync(self, want_host: bool = True):
+        """Wait for the enqueued steps; timings() then holds their averages.  Returns the last step's records."""
+        L.check(L.load().vapor_plan_sync(self._h, L.ptr(self.loci, ctypes.c_double) if want_host else None))
+        return self.loci[:self.n_loci]
+
     def algorithmic(self) -> Tuple[int, int]:
         b = ctypes.c_int64()
         c = ctypes.c_int64()
@@ -145,6 +154,10 @@ class Engine:
 
     def set_param(self, name: str, value: int) -> None:
         L.check(L.load().vapor_set_param(self._ctx, name.encode(), int(value)))
+
+    def set_stream(self, hip_stream: int) -> None:
+        """Enqueue on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0: the library's own."""
+        L.check(L.load().vapor_set_stream(self._ctx, ctypes.c_void_p(hip_stream) if hip_stream else None))
 
     def seqset(self, seqs: Sequence, upper: Optional[Sequence[bool]] = None) -> SeqSet:
         return SeqSet(self, seqs, upper)
