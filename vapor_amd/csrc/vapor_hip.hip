@@ -538,11 +538,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
     HIPCHK(hipEventRecord(ev[2], st));
     if (p->n_pairs > 0 && fetch_stats)
         HIPCHK(hipMemcpyAsync(p->h_stats, p->d_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyDeviceToHost, st));
-    if (!fetch_stats) {
-        // device-side finishing: the statistics stay in HBM, only the overflow count comes back
-        HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        return VAPOR_OK;
-    }
+    if (!fetch_stats) return VAPOR_OK;          // device-side finishing: the statistics stay in HBM
     HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipStreamSynchronize(st));
     float a = 0, b = 0, t = 0;
@@ -855,7 +851,8 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     for (int64_t i = 0; i < p->n_pairs; ++i)
         if (p->status[i] != 0) { host_status = true; break; }
     int rc;
-    if (host_status || !p->ran) {
+    const bool light = !(host_status || !p->ran);
+    if (!light) {
         // first run, or pairs the host marked as failed: full path once (statistics to the host, slots grown)
         rc = vapor_plan_run(p, p->last_stats.data());
         if (rc != VAPOR_OK) return rc;
@@ -873,12 +870,14 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(e1, st));
+    // only the overflow count has to come back (after the finish kernel, so that nothing sits between the kernels)
+    HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (loci_out && p->n_loci)
         HIPCHK(hipMemcpyAsync(loci_out, d_out, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
     if (read_scores && p->n_reads)
         HIPCHK(hipMemcpyAsync(read_scores, p->d_read_scores, sizeof(double) * (size_t)p->n_reads, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (!(host_status) && p->ran && *p->h_overflow != 0) {
+    if (light && *p->h_overflow != 0) {
         // some pair outgrew its hit slot on this run: redo through the full path, which resizes
         rc = vapor_plan_run(p, p->last_stats.data());
         if (rc != VAPOR_OK) return rc;
