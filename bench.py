@@ -45,12 +45,22 @@ def main() -> None:
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    # VAPOR_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on one GPU (RCCL wants a GPU per rank)
+    backend = os.environ.get("VAPOR_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    # one explicit stream for everything timed: the library's kernels and the all-gather are enqueued on it in
+    # program order (the legacy default stream cannot be handed to the library)
+    work_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(work_stream)
 
     from vapor_amd import workload as wl
     from vapor_amd.engine import Engine
@@ -76,7 +86,7 @@ def main() -> None:
 
     # The library enqueues on torch's current stream, so its kernels, the all-gather and torch.cuda.synchronize()
     # order themselves; HIP events on that stream time the kernels.
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_stream(work_stream.cuda_stream)
 
     def gather():
         if dist is not None:
