@@ -19,6 +19,15 @@
 
 using namespace vapor;
 
+// Cost of building an allele's table relative to probing one read base against it, in eighths.  Measured on cfg2
+// (tools/ab.py, 0 .. 16 eighths): the build is cheap next to the probes, and any weight that moves a pair from
+// a one-allele range to a two-allele range makes the slowest workgroup slower (0 or 1: 215 us, 2 .. 6: 234 us,
+// 16: 247 us); 1 keeps it as a tie-breaker.
+#ifndef VAPOR_BUILD_COST_X8
+#define VAPOR_BUILD_COST_X8 1
+#endif
+
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string& msg)
@@ -402,7 +411,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         for (size_t t = q; t < e; ++t) {
             const DPair& d = p->hp[order[t]];
             int64_t c = (int64_t)set->h[d.seq1].len * tiles_of(d.seq2, k, m) + 256;
-            if (t == q || p->hp[order[t - 1]].seq2 != d.seq2) c += 2 * (int64_t)set->h[d.seq2].len;
+            if (t == q || p->hp[order[t - 1]].seq2 != d.seq2) c += (VAPOR_BUILD_COST_X8 * (int64_t)set->h[d.seq2].len) / 8;
             cost[t - q] = c;
             total += c;
         }
