@@ -55,3 +55,10 @@ for grp, ks in (("join", range(0, 8)), ("clean", (8, 9, 10)), ("clean.axis", ran
     for k in ks:
         if out[k]:
             print("%-40s %14.0f ticks/run  %5.1f %% of %s" % (NAMES.get(k, str(k)), out[k] / N, 100 * out[k] / tot, grp))
+
+lib.vapor_debug_block_ticks.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int32]
+bt = np.zeros(4096)
+lib.vapor_debug_block_ticks(L.ptr(bt, ctypes.c_double), 4096)
+bt = bt[bt > 0]
+if len(bt):
+    print("join workgroups: %d  ticks min %.0f  mean %.0f  p90 %.0f  max %.0f   max/mean %.3f" % (len(bt), bt.min(), bt.mean(), np.percentile(bt, 90), bt.max(), bt.max() / bt.mean()))

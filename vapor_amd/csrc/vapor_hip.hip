@@ -20,11 +20,10 @@
 using namespace vapor;
 
 // Cost of building an allele's table relative to probing one read base against it, in eighths.  Measured on cfg2
-// (tools/ab.py, 0 .. 16 eighths): the build is cheap next to the probes, and any weight that moves a pair from
-// a one-allele range to a two-allele range makes the slowest workgroup slower (0 or 1: 215 us, 2 .. 6: 234 us,
-// 16: 247 us); 1 keeps it as a tie-breaker.
+// (tools/tasks_sweep.py, tools/block_times.py): a table of 20 000 positions builds in about 10 us, a 10 000-base
+// read is probed against it in about 12 us, i.e. 0.4 per allele base.
 #ifndef VAPOR_BUILD_COST_X8
-#define VAPOR_BUILD_COST_X8 1
+#define VAPOR_BUILD_COST_X8 3
 #endif
 
 
@@ -405,33 +404,55 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         size_t e = q;
         const int m = mode[order[q]], k = p->hp[order[q]].k;
         while (e < order.size() && mode[order[e]] == m && p->hp[order[e]].k == k) ++e;
-        // cost of a pair: its probe passes, plus the table build when it opens a new allele
-        std::vector<int64_t> cost(e - q);
-        int64_t total = 0;
+        // Cost of a range of consecutive pairs = its probe passes + one table build for its first allele + one for
+        // every further allele it reaches into.  The ranges are the contiguous partition into at most `want`
+        // pieces whose most expensive piece is cheapest (binary search on that bound, greedy packing under it).
+        const size_t n = e - q;
+        std::vector<int64_t> probe(n), build(n);
+        int64_t total = 0, biggest = 0;
         for (size_t t = q; t < e; ++t) {
             const DPair& d = p->hp[order[t]];
-            int64_t c = (int64_t)set->h[d.seq1].len * tiles_of(d.seq2, k, m) + 256;
-            if (t == q || p->hp[order[t - 1]].seq2 != d.seq2) c += (VAPOR_BUILD_COST_X8 * (int64_t)set->h[d.seq2].len) / 8;
-            cost[t - q] = c;
-            total += c;
+            probe[t - q] = (int64_t)set->h[d.seq1].len * tiles_of(d.seq2, k, m) + 256;
+            build[t - q] = (VAPOR_BUILD_COST_X8 * (int64_t)set->h[d.seq2].len) / 8;
+            total += probe[t - q] + build[t - q];
+            biggest = std::max(biggest, probe[t - q] + build[t - q]);
         }
-        const int64_t want = std::max<int64_t>(1, std::min<int64_t>((int64_t)(e - q), ctx->join_tasks));
-        const int64_t target = (total + want - 1) / want;
-        p->launches.push_back(Launch{m, k, (int)p->tasks.size(), 0});
-        size_t t0 = q;
-        int64_t acc = 0;
-        for (size_t t = q; t < e; ++t) {
-            acc += cost[t - q];
-            const bool full = (int)(t + 1 - t0) >= ctx->reads_per_task;
-            if (acc >= target || full || t + 1 == e) {
-                DTask tk;
-                tk.seq2 = p->hp[order[t0]].seq2; tk.k = k; tk.n_reads = (int32_t)(t + 1 - t0); tk.first = (int32_t)t0;
-                p->tasks.push_back(tk);
-                p->launches.back().n_tasks++;
-                // a range that stopped short of its share only shifts the remainder to the next one
-                acc = 0;
-                t0 = t + 1;
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>((int64_t)n, ctx->join_tasks));
+        auto new_allele = [&](size_t t) { return p->hp[order[q + t]].seq2 != p->hp[order[q + t - 1]].seq2; };
+        // number of ranges a bound needs (cuts[] = first pair of every range when asked for)
+        auto pack = [&](int64_t bound, std::vector<size_t>* cuts) {
+            int64_t ranges = 0, acc = 0;
+            size_t t0 = 0;
+            for (size_t t = 0; t < n; ++t) {
+                const int64_t add = probe[t] + ((t == t0 || new_allele(t)) ? build[t] : 0);
+                const bool full = (int)(t - t0) >= ctx->reads_per_task;
+                if (t > t0 && (acc + add > bound || full)) {
+                    ++ranges;
+                    if (cuts) cuts->push_back(t0);
+                    t0 = t;
+                    acc = probe[t] + build[t];
+                } else {
+                    acc += add;
+                }
             }
+            ++ranges;
+            if (cuts) cuts->push_back(t0);
+            return ranges;
+        };
+        int64_t lo = biggest, hi = total;
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (pack(mid, nullptr) <= want) hi = mid; else lo = mid + 1;
+        }
+        std::vector<size_t> cuts;
+        pack(lo, &cuts);
+        p->launches.push_back(Launch{m, k, (int)p->tasks.size(), 0});
+        for (size_t c = 0; c < cuts.size(); ++c) {
+            const size_t t0 = q + cuts[c], t1 = q + (c + 1 < cuts.size() ? cuts[c + 1] : n);
+            DTask tk;
+            tk.seq2 = p->hp[order[t0]].seq2; tk.k = k; tk.n_reads = (int32_t)(t1 - t0); tk.first = (int32_t)t0;
+            p->tasks.push_back(tk);
+            p->launches.back().n_tasks++;
         }
         q = e;
     }
@@ -990,6 +1011,15 @@ extern "C" int vapor_plan_sync(vapor_plan* p, double* loci_out)
     return VAPOR_OK;
 }
 
+#if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
+extern "C" int vapor_debug_block_ticks(double* out, int32_t n)
+{
+    std::vector<unsigned long long> h(4096);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vapor::g_block_ticks), sizeof(unsigned long long) * 4096) != hipSuccess) return -1;
+    for (int x = 0; x < n && x < 4096; ++x) out[x] = (double)h[(size_t)x];
+    return 0;
+}
+#endif
 #ifdef VAPOR_PHASE_TIMING
 // developer build only: read (and clear) the per-phase tick sums
 extern "C" int vapor_debug_phases(double* out, int32_t n)

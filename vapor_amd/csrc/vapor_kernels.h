@@ -323,6 +323,9 @@ __device__ __forceinline__ T wave_scan(T v, T identity)
 
 // Developer build only (-DVAPOR_PHASE_TIMING, tools/phase_timing.py): shader-clock ticks per kernel phase, summed
 // over the stamping lanes into g_phase[].  Compiled out of the product library.
+#if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
+__device__ unsigned long long g_block_ticks[4096];     // join_kernel: 100 MHz ticks from start to end of every workgroup
+#endif
 #ifdef VAPOR_PHASE_TIMING
 __device__ unsigned long long g_phase[64];
 // ticks are summed in (scalar) registers and flushed once per stamping lane, so the stamps cost a few SALU
@@ -539,6 +542,9 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
     if (tid < MAX_READS_PER_TASK) cnt[tid] = 0ULL;
     JoinClock pc;
     const bool pw = lane == 0;                     // one stamping lane per wave
+#if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
+    const long long t_block0 = wall_clock64();     // constant-rate clock: comparable between CUs
+#endif
 
     int g0 = 0;
     while (g0 < task.n_reads) {
@@ -808,6 +814,9 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
     __syncthreads();
     pc.mark(6, pw);                                // waiting for the block's last wave
     pc.flush(pw);
+#if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
+    if (tid == 0 && blockIdx.x < 4096) g_block_ticks[blockIdx.x] = (unsigned long long)(wall_clock64() - t_block0);
+#endif
     if (tid < task.n_reads) n_hits[task_pairs[task.first + tid]] = cnt[tid];
 }
 
