@@ -389,3 +389,53 @@ def test_workflow_sorted_bgzipped_indexed_table(fake, tmp_path):
     for chrom, a, b in (("chr2", 100000, 120000), ("chr10", 1, 5000), ("chr1", 2999000, 3100000)):
         exp = [r for r in workflow.sort_rows(big) if r.split("\t")[0] == chrom and int(r.split("\t")[1]) < b and int(r.split("\t")[2]) > a - 1]
         assert workflow.tabix_query(str(tmp_path / "big.bed.gz"), chrom, a, b) == exp
+
+
+def _world_to_files(world, d):
+    """FASTA + .fai and BAM + .bai of a synthetic world (no samtools involved)."""
+    from vapor_amd import bamio
+    fa = str(d / "ref.fa")
+    names = list(world.contigs)
+    with open(fa, "w") as f, open(fa + ".fai", "w") as fi:
+        off = 0
+        for n in names:
+            seq = world.contigs[n]
+            hdr = ">" + n + "\n"
+            f.write(hdr)
+            off += len(hdr)
+            fi.write("%s\t%d\t%d\t60\t61\n" % (n, len(seq), off))
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + "\n")
+            off += len(seq) + (len(seq) + 59) // 60
+    recs = [(r.qname, names.index(c), r.pos - 1, r.cigar, r.seq) for c, rs in world.reads.items() for r in rs]
+    bam = str(d / "reads.bam")
+    bamio.write_bam(bam, [(n, len(world.contigs[n])) for n in names], recs, block_size=8192)
+    return fa, bam
+
+
+@pytest.mark.parametrize("case", [c for c in LOCUS if not [p for p in c["per_locus"] if "error" in p["scores"]]][:3],
+                         ids=lambda c: c["name"])
+def test_bed_cli_from_files_without_samtools(fake, case, tmp_path):
+    """The same table from files on disk: reference windows through the .fai index, reads through the
+    in-process BGZF/BAM/BAI reader - no samtools process anywhere.  A BAM is coordinate-sorted,
+    so the expectation is the in-memory run over the same reads in coordinate order."""
+    world = synth.world_from_json(case["world"])
+    for c in world.reads:
+        world.reads[c] = sorted(world.reads[c], key=lambda r: r.pos)          # stable: ties keep their order
+    bed = tmp_path / "in.bed"
+    bed.write_text(case["bed"])
+
+    def run(ref, bam, out):
+        assert cli.main(["bed", "--sv-input", str(bed), "--reference", ref, "--pacbio-input", bam,
+                         "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+        return out.read_text()
+
+    seqio.set_backend(seqio.MemorySamtools(world))
+    exp = run("ref.fa", "x.bam", tmp_path / "mem.vapor")
+    fa, bam = _world_to_files(world, tmp_path)
+    seqio.set_backend(seqio.InProcessBam())
+    try:
+        got = run(fa, bam, tmp_path / "files.vapor")
+    finally:
+        seqio.set_backend(None)
+    assert got == exp and len(exp.splitlines()) == len(case["vapor_text"].splitlines())
