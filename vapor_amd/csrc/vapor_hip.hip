@@ -380,7 +380,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : 2;
         rw = std::max(rw, (s1.len + s2.len + 2 + 31) / 32);
         // records expected: the shared diagonal in runs of a few dots plus the chance dots
-        hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 8 + ((n1 * n2) >> 19) + 256);
+        hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 10 + ((n1 * n2) >> 19) + 192);
         if (s1.len - a.k + 1 > 0 && s2.len - a.k + 1 > 0) order.push_back((int32_t)i);
     }
     p->range_words_cap = rw;
@@ -501,30 +501,38 @@ static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 /
 // 16-bit group counters; pairs that stream their hits need 32-bit ones, which must fit as well.
 constexpr int CLEAN_BIG_GRID = 1024;      // clean_big_kernel walks its list with at most this many workgroups
 
+// clean_big_kernel: bitmap + 16-bit ranks + 32-bit group sizes (as many groups as the value range can hold)
 static size_t clean_fixed_bytes(int rw, bool wide)
 {
     const size_t g = (size_t)clean_groups_cap(rw);
     return sizeof(uint32_t) * ((size_t)rw + ((size_t)rw + 1) / 2 + (wide ? g : (g + 1) / 2)) + 64;
 }
 
-// The kernel is latency-bound, so residency matters: take the largest number of workgroups per CU
-// (4, 3, 2, 1) whose share of the 160 KB still stages at least ~90 % of the expected hit count.
+// clean_kernel: 16-bit group sizes.  A pair staged in LDS has at most hcap records and every group holds at least
+// one, so hcap counters do; the same region later holds the per-value counters of the median (value span / 100).
+static int clean_groups_lds(int rw, int hcap)
+{
+    const int g = std::min(clean_groups_cap(rw), std::max(hcap, 1));
+    return 2 * std::max((g + 1) / 2, rw * 32 / 100 + 8);
+}
+
+static size_t clean_lds_bytes(int rw, int hcap)
+{
+    return sizeof(uint32_t) * ((size_t)rw + ((size_t)rw + 1) / 2 + (size_t)clean_groups_lds(rw, hcap) / 2) + 64 + (size_t)hcap * 9 + 8;
+}
+
+// The kernel waits for memory and barriers more than it computes, so residency matters: take the largest number
+// of workgroups per CU (32 waves at most) whose share of the 160 KB still stages ~90 % of the expected records.
 static int clean_hcap(int range_words_cap, int want)
 {
-    const size_t fixed = clean_fixed_bytes(range_words_cap, false) + 512;
     int best = 0;
-    for (int per_cu = 2048 / CLEAN_THREADS; per_cu >= 1; --per_cu) {       // 32 waves per CU at most
+    for (int per_cu = 2048 / CLEAN_THREADS; per_cu >= 1; --per_cu) {
         const size_t share = (size_t)(160 * 1024) / per_cu - 512;
-        if (share <= fixed) continue;
-        const int cap = (int)std::min<size_t>(std::min<size_t>((share - fixed) / 9, (size_t)want), 65532) & ~3;
+        int cap = std::min(want, 65532) & ~3;
+        while (cap > 0 && clean_lds_bytes(range_words_cap, cap) + 512 > share) cap -= 4;
         if (cap >= want * 9 / 10 || per_cu == 1) { best = cap; break; }
     }
     return std::max(best, 0);
-}
-
-static size_t clean_lds_bytes(int range_words_cap, int hcap)
-{
-    return clean_fixed_bytes(range_words_cap, false) + (size_t)hcap * 9 + 8;
 }
 
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr)
@@ -558,7 +566,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st,
                            p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
-                           p->range_words_cap, clean_groups_cap(p->range_words_cap), hcap, p->d_overflow, p->d_big_list);
+                           p->range_words_cap, clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(p->n_pairs, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(p->range_words_cap, true), st, p->d_pairs, p->d_nhits, p->d_hits, p->d_hflags,
@@ -815,7 +823,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     if (rc == VAPOR_OK) {
         int hcap = clean_hcap(rw, 4096);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_dp,
-                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), hcap, d_ov, d_big);
+                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_lds(rw, hcap), hcap, d_ov, d_big);
         chk(hipGetLastError(), "clean launch");
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);

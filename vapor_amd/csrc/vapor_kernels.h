@@ -53,7 +53,7 @@ struct DTask {         // 16 B: pairs task_pairs[first .. first + n_reads) of on
 
 constexpr int MAX_READS_PER_TASK = 64;
 #ifndef VAPOR_CLEAN_THREADS
-#define VAPOR_CLEAN_THREADS 512
+#define VAPOR_CLEAN_THREADS 256
 #endif
 constexpr int CLEAN_THREADS = VAPOR_CLEAN_THREADS;
 constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
@@ -1284,13 +1284,19 @@ __device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots
         cluster_axis<true, NARROW, false, false>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
         cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     } else if (c1) {
+#ifndef VAPOR_ABL_NOAXIS1
         cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
+#endif
+#ifndef VAPOR_ABL_NOAXIS2
         cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
+#endif
     } else if (c2) {
         cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
         cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     }
+#ifndef VAPOR_ABL_NODIR
     if (s3) directed_stats<NARROW>(recs, hflags, n, gcnt, sh, pc);
+#endif
     if (tid == 0) {
         st[0] = n_dots; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
         st[5] = sh->c2_kept; st[6] = sh->c2_count10; st[7] = sh->n_diag; st[8] = sh->n_lower; st[9] = sh->c2_kept_diag;
