@@ -158,7 +158,7 @@ def main() -> None:
             traffic = None
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:       # reported at N = 1 only
         from oracle import oracle as orc
         orc.build()
         done = 0
