@@ -334,3 +334,15 @@ def test_async_steps_equal_blocking_run(eng):
     tm = plan.timings()
     assert 0 < tm["join_ms"] < 50 and 0 < tm["clean_ms"] < 50 and tm["total_ms"] >= tm["join_ms"]
     plan.close()
+
+
+def test_randomised_sweep_vs_oracle(eng):
+    """A few seconds of tools/fuzz_parity.py (odd lengths, every k, slices, soft-masked / N / repeat sequences,
+    exact copies, alleles around the tile size): dots, statistics and directed statistics exact."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    msg = mod.run(6.0, 12345, engine=eng)
+    assert msg.startswith("fuzz ok")
