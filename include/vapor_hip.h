@@ -74,6 +74,7 @@ typedef struct vapor_pair {
 #define VAPOR_ST_DIR_N 11       /* kept dots (x,y) = (j+c, i) with abs(x-y)/abs(x) > 0.1 (eu_dis_single_dot SF:710-716) */
 #define VAPOR_ST_DIR_SUM2 12    /* 2 * sum(x - y) over them: eu_dis_dir_calcu = SUM2 / 2 / N, or 0.0001 when N == 0 */
 #define VAPOR_ST_DIR_LISTS 13   /* number of longest sub-bins found (c is a median only when this is 1) */
+#define VAPOR_ST_RECORDS_NEEDED 14 /* 0; on VAPOR_E_OVERFLOW the run records the pair produced (its slot was smaller) */
 #define VAPOR_ST_STATUS 15     /* 0, or VAPOR_E_KEYERROR / VAPOR_E_ARG / VAPOR_E_OVERFLOW for this pair */
 
 /* per-hit flag bits returned by vapor_plan_fetch_hits */
@@ -86,7 +87,9 @@ int vapor_abi_version(void);
 const char* vapor_last_error(void);
 int vapor_init(int device_ordinal, vapor_ctx** ctx);
 int vapor_destroy(vapor_ctx* ctx);
-/* tuning knobs: "reads_per_task" (reads sharing one allele hash table per workgroup) */
+/* tuning knobs: "reads_per_task" (at most this many pairs per join workgroup, <= 64), "join_tasks" (number of
+ * join workgroups a launch is cut into; default = number of CUs), "max_pair_cap" (largest record slot a pair may
+ * grow to on an overflow rerun; beyond it the pair keeps VAPOR_E_OVERFLOW) */
 int vapor_set_param(vapor_ctx* ctx, const char* name, int64_t value);
 
 /* ---- sequences: ASCII in, packed bit planes resident in HBM ------------------------------ */
