@@ -346,3 +346,25 @@ def test_randomised_sweep_vs_oracle(eng):
     spec.loader.exec_module(mod)
     msg = mod.run(6.0, 12345, engine=eng)
     assert msg.startswith("fuzz ok")
+
+
+def test_async_steps_report_overflow(eng):
+    """A pair that cannot get a big enough record slot (max_pair_cap) makes vapor_plan_sync fail loudly instead of
+    handing back records computed from a truncated dot list."""
+    from vapor_amd import _lib as L
+    from vapor_amd import workload as wl
+    w = wl.make_workload("tiny", seed=6, **wl.WORKLOADS["tiny"])
+    eng.set_param("max_pair_cap", 16)
+    try:
+        ss = eng.seqset(w.seqs)
+        plan = eng.plan(ss, w.pairs)
+        plan.set_reads(wl.read_table(w), w.n_loci)
+        st = plan.run()
+        assert (st[:, 15] == -2).any()                 # slots capped at 16 records: overflow stays
+        plan.run_loci()
+        plan.run_loci_async()
+        with pytest.raises(L.VaporHipError):
+            plan.sync()
+        plan.close()
+    finally:
+        eng.set_param("max_pair_cap", 1 << 28)

@@ -91,6 +91,7 @@ struct vapor_plan {
     // vapor_plan_run_loci_async: one set of four events per step in flight, summed by vapor_plan_sync
     std::vector<std::array<hipEvent_t, 4>> ring;
     int ring_n = 0;
+    bool overflow_final = false;               // some pair overflows even at max_pair_cap: do not retry again
     double acc_ms[4] = {0, 0, 0, 0};           // join, clean, finish, total of the steps already folded in
     int64_t acc_n = 0;
     double* h_loci = nullptr;                  // pinned copy of the per-locus records of the last async step
@@ -915,10 +916,14 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     if (read_scores && p->n_reads)
         HIPCHK(hipMemcpyAsync(read_scores, p->d_read_scores, sizeof(double) * (size_t)p->n_reads, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (light && *p->h_overflow != 0) {
-        // some pair outgrew its hit slot on this run: redo through the full path, which resizes
+    if (light && *p->h_overflow != 0 && !p->overflow_final) {
+        // some pair outgrew its record slot on this run: redo through the full path, which resizes.  Pairs that
+        // still overflow after that (their slot would exceed max_pair_cap) keep VAPOR_E_OVERFLOW in their
+        // statistics and are scored as reads without a usable plot; nothing is retried for them again.
         rc = vapor_plan_run(p, p->last_stats.data());
         if (rc != VAPOR_OK) return rc;
+        for (int64_t i = 0; i < p->n_pairs; ++i)
+            if (p->last_stats[16 * (size_t)i + 15] == VAPOR_E_OVERFLOW) { p->overflow_final = true; break; }
         return vapor_plan_run_loci(p, d_loci_out, loci_out, read_scores);
     }
     float f = 0, a = 0, b = 0, t = 0;
