@@ -36,7 +36,9 @@ def main() -> None:
     ap.add_argument("--reads-per-task", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="plans in flight (steps alternate between them)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="plans in flight, steps alternate between them (0 = two when a join launch is one workgroup per "
+                         "CU, else one)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,7 +80,11 @@ def main() -> None:
         pass
     lanes = []
     upload_s = 0.0
-    for li in range(max(1, args.streams)):
+    # A batch whose join is a single wave of workgroups (one per CU) leaves CUs idle at its tail, which a second lane
+    # fills; a join of many waves of workgroups keeps the chip busy by itself, and a second lane would only stretch
+    # every kernel's event interval.
+    n_lanes = args.streams if args.streams > 0 else (2 if len(w.pairs) <= 64 * 256 else 1)
+    for li in range(n_lanes):
         ln = Lane()
         ln.stream = work_stream if li == 0 else torch.cuda.Stream()
         ln.eng = Engine(local)
