@@ -103,6 +103,9 @@ int vapor_set_param(vapor_ctx* ctx, const char* name, int64_t value);
 int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* blob, const int64_t* off,
                         const int32_t* len, const uint8_t* flags, int32_t* seq_info,
                         vapor_seqset** set);
+/* the same from one pointer per sequence (no concatenated copy on the caller's side): seq[s] points at len[s] bytes */
+int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len,
+                             const uint8_t* flags, int32_t* seq_info, vapor_seqset** out);
 int vapor_seqset_destroy(vapor_seqset* set);
 
 /* ---- plans: a batch of dot plots resident on the device ---------------------------------- */

@@ -31,7 +31,7 @@ MAX_SEQ_LEN = 65535
 
 EXPORTS = [
     "vapor_abi_version", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
-    "vapor_seqset_create", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
+    "vapor_seqset_create", "vapor_seqset_create_ptrs", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_record_counts", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
     "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync",
@@ -67,6 +67,7 @@ def load() -> ctypes.CDLL:
     L.vapor_destroy.argtypes = [vp]
     L.vapor_set_param.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.vapor_seqset_create.argtypes = [vp, ctypes.c_int32, u8p, i64p, i32p, u8p, i32p, ctypes.POINTER(vp)]
+    L.vapor_seqset_create_ptrs.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), i32p, u8p, i32p, ctypes.POINTER(vp)]
     L.vapor_seqset_destroy.argtypes = [vp]
     L.vapor_plan_create.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.POINTER(vp)]
     L.vapor_plan_destroy.argtypes = [vp]

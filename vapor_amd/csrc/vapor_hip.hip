@@ -46,6 +46,10 @@ struct vapor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;          // the stream vapor_init created (vapor_set_stream may replace `stream`)
+    // staging for vapor_seqset_create*, kept between calls (pinned allocations are slow): ASCII chunks + chunk map
+    uint8_t* h_stage = nullptr;
+    uint8_t* d_stage = nullptr;
+    size_t stage_cap = 0;
     int reads_per_task = MAX_READS_PER_TASK;   // upper bound on pairs per join task
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
@@ -159,6 +163,8 @@ extern "C" int vapor_destroy(vapor_ctx* c)
     if (!c) return VAPOR_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->d_stage) (void)hipFree(c->d_stage);
     delete c;
     return VAPOR_OK;
 }
@@ -197,11 +203,11 @@ extern "C" int vapor_seqset_destroy(vapor_seqset* s)
     return VAPOR_OK;
 }
 
-extern "C" int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* blob, const int64_t* off,
-                                   const int32_t* len, const uint8_t* flags, int32_t* seq_info, vapor_seqset** out)
+// Shared by the two entry points: sequence i starts at src(i).
+template <typename SRC>
+static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int32_t* len, const uint8_t* flags,
+                              int32_t* seq_info, vapor_seqset** out)
 {
-    if (!ctx || !out || n_seqs < 0 || (n_seqs && (!blob || !off || !len)))
-        return fail(VAPOR_E_ARG, "vapor_seqset_create: null argument");
     HIPCHK(hipSetDevice(ctx->device));
     vapor_seqset* s = new (std::nothrow) vapor_seqset();
     if (!s) return fail(VAPOR_E_NOMEM, "out of memory");
@@ -225,61 +231,83 @@ extern "C" int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t
     pl += VP_PAD_CHUNKS + 1;
     s->plane_chunks = pl;
     const size_t n_asc = asc;
-    // pinned staging: ASCII at 32-byte chunks + chunk -> sequence map
-    uint8_t* h_asc = nullptr;
-    uint32_t* h_map = nullptr;
-    uint8_t* d_asc = nullptr;
-    uint32_t* d_map = nullptr;
     int rc = VAPOR_OK;
 #define SS_CHK(expr)                                                                               \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
         if (_e != hipSuccess) { rc = fail(VAPOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); goto done; } \
     } while (0)
-    SS_CHK(hipHostMalloc((void**)&h_asc, std::max<size_t>(n_asc * 32, 32)));
-    SS_CHK(hipHostMalloc((void**)&h_map, std::max<size_t>(n_asc * 4, 4)));
-    for (int32_t i = 0; i < n_seqs; ++i) {
-        const SeqDesc& d = s->h[i];
-        size_t ch = ((size_t)d.len + 31) / 32;
-        uint8_t* dst = h_asc + (size_t)d.asc0 * 32;
-        memcpy(dst, blob + off[i], (size_t)d.len);
-        memset(dst + d.len, 0, ch * 32 - (size_t)d.len);
-        for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
-    }
-    SS_CHK(hipMalloc((void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
-    SS_CHK(hipMalloc((void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
-    SS_CHK(hipMalloc((void**)&s->d_e1, pl * sizeof(uint32_t)));
-    SS_CHK(hipMalloc((void**)&s->d_x4, pl * 4 * sizeof(uint32_t)));
-    SS_CHK(hipMalloc((void**)&d_asc, std::max<size_t>(n_asc * 32, 32)));
-    SS_CHK(hipMalloc((void**)&d_map, std::max<size_t>(n_asc * 4, 4)));
-    SS_CHK(hipMemsetAsync(s->d_p2, 0, pl * 2 * sizeof(uint32_t), ctx->stream));
-    SS_CHK(hipMemsetAsync(s->d_e1, 0, pl * sizeof(uint32_t), ctx->stream));
-    SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
-    SS_CHK(hipMemcpyAsync(s->d_seqs, s->h.data(), sizeof(SeqDesc) * s->h.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (n_asc) {
-        SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 32, hipMemcpyHostToDevice, ctx->stream));
-        SS_CHK(hipMemcpyAsync(d_map, h_map, n_asc * 4, hipMemcpyHostToDevice, ctx->stream));
-        unsigned grid = (unsigned)((n_asc + 255) / 256);
-        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_asc, s->d_seqs, n_seqs, d_map,
-                           (uint32_t)n_asc, s->d_p2, s->d_e1, s->d_x4);
-        SS_CHK(hipGetLastError());
-    }
-    SS_CHK(hipMemcpyAsync(s->h.data(), s->d_seqs, sizeof(SeqDesc) * s->h.size(), hipMemcpyDeviceToHost, ctx->stream));
-    SS_CHK(hipStreamSynchronize(ctx->stream));
-    if (seq_info)
-        for (int32_t i = 0; i < n_seqs; ++i) {
-            seq_info[2 * i] = s->h[i].n_exc;
-            seq_info[2 * i + 1] = s->h[i].n_invalid;
+    {
+        // staging (ASCII at 32-byte chunks, then the chunk -> sequence map), kept in the context and grown on demand
+        const size_t need = std::max<size_t>(n_asc * 36, 64);
+        if (need > ctx->stage_cap) {
+            SS_CHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+            ctx->h_stage = nullptr; ctx->d_stage = nullptr; ctx->stage_cap = 0;
+            const size_t cap = need + need / 4;
+            SS_CHK(hipHostMalloc((void**)&ctx->h_stage, cap));
+            SS_CHK(hipMalloc((void**)&ctx->d_stage, cap));
+            ctx->stage_cap = cap;
         }
+        uint8_t* h_asc = ctx->h_stage;
+        uint32_t* h_map = reinterpret_cast<uint32_t*>(ctx->h_stage + n_asc * 32);
+        uint8_t* d_asc = ctx->d_stage;
+        uint32_t* d_map = reinterpret_cast<uint32_t*>(ctx->d_stage + n_asc * 32);
+        for (int32_t i = 0; i < n_seqs; ++i) {
+            const SeqDesc& d = s->h[i];
+            size_t ch = ((size_t)d.len + 31) / 32;
+            uint8_t* dst = h_asc + (size_t)d.asc0 * 32;
+            if (d.len) memcpy(dst, src(i), (size_t)d.len);
+            memset(dst + d.len, 0, ch * 32 - (size_t)d.len);
+            for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
+        }
+        SS_CHK(hipMalloc((void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
+        SS_CHK(hipMalloc((void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
+        SS_CHK(hipMalloc((void**)&s->d_e1, pl * sizeof(uint32_t)));
+        SS_CHK(hipMalloc((void**)&s->d_x4, pl * 4 * sizeof(uint32_t)));
+        SS_CHK(hipMemsetAsync(s->d_p2, 0, pl * 2 * sizeof(uint32_t), ctx->stream));
+        SS_CHK(hipMemsetAsync(s->d_e1, 0, pl * sizeof(uint32_t), ctx->stream));
+        SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
+        SS_CHK(hipMemcpyAsync(s->d_seqs, s->h.data(), sizeof(SeqDesc) * s->h.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (n_asc) {
+            SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 36, hipMemcpyHostToDevice, ctx->stream));
+            unsigned grid = (unsigned)((n_asc + 255) / 256);
+            hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_asc, s->d_seqs, n_seqs, d_map,
+                               (uint32_t)n_asc, s->d_p2, s->d_e1, s->d_x4);
+            SS_CHK(hipGetLastError());
+        }
+        SS_CHK(hipMemcpyAsync(s->h.data(), s->d_seqs, sizeof(SeqDesc) * s->h.size(), hipMemcpyDeviceToHost, ctx->stream));
+        SS_CHK(hipStreamSynchronize(ctx->stream));
+        if (seq_info)
+            for (int32_t i = 0; i < n_seqs; ++i) {
+                seq_info[2 * i] = s->h[i].n_exc;
+                seq_info[2 * i + 1] = s->h[i].n_invalid;
+            }
+    }
 done:
-    if (h_asc) (void)hipHostFree(h_asc);
-    if (h_map) (void)hipHostFree(h_map);
-    if (d_asc) (void)hipFree(d_asc);
-    if (d_map) (void)hipFree(d_map);
     if (rc != VAPOR_OK) { vapor_seqset_destroy(s); return rc; }
     *out = s;
     return VAPOR_OK;
 #undef SS_CHK
+}
+
+extern "C" int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* blob, const int64_t* off,
+                                   const int32_t* len, const uint8_t* flags, int32_t* seq_info, vapor_seqset** out)
+{
+    if (!ctx || !out || n_seqs < 0 || (n_seqs && (!blob || !off || !len)))
+        return fail(VAPOR_E_ARG, "vapor_seqset_create: null argument");
+    return seqset_create_impl(ctx, n_seqs, [&](int32_t i) { return blob + off[i]; }, len, flags, seq_info, out);
+}
+
+extern "C" int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len,
+                                        const uint8_t* flags, int32_t* seq_info, vapor_seqset** out)
+{
+    if (!ctx || !out || n_seqs < 0 || (n_seqs && (!seq || !len)))
+        return fail(VAPOR_E_ARG, "vapor_seqset_create_ptrs: null argument");
+    for (int32_t i = 0; i < n_seqs; ++i)
+        if (len[i] > 0 && !seq[i]) return fail(VAPOR_E_ARG, "vapor_seqset_create_ptrs: null sequence");
+    return seqset_create_impl(ctx, n_seqs, [&](int32_t i) { return seq[i]; }, len, flags, seq_info, out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -12,6 +12,11 @@ import numpy as np
 from . import _lib as L
 
 
+_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
+_utf8.restype = ctypes.c_void_p
+_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
+
+
 def _as_bytes(s) -> bytes:
     return s if isinstance(s, (bytes, bytearray)) else s.encode("latin-1", "replace")
 
@@ -22,21 +27,38 @@ class SeqSet:
 
     def __init__(self, engine: "Engine", seqs: Sequence, upper: Optional[Sequence[bool]] = None):
         self.engine = engine
-        bs = [_as_bytes(s) for s in seqs]
-        self.n = len(bs)
-        self.lens = np.array([len(b) for b in bs], dtype=np.int32)
-        off = np.zeros(self.n + 1, dtype=np.int64)
-        np.cumsum(self.lens, out=off[1:])
-        blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
-        flags = np.zeros(max(self.n, 1), dtype=np.uint8)
+        self.n = len(seqs)
+        n1 = max(self.n, 1)
+        # One pointer per sequence, no concatenated copy: an ASCII str is handed over as it lies in memory (CPython
+        # keeps it one byte per character; PyUnicode_AsUTF8AndSize returns that buffer), anything else as the
+        # bytes it is or encodes to (characters outside Latin-1 become '?', which matches nothing anyway).
+        keep = []
+        ptrs = (ctypes.c_void_p * n1)()
+        self.lens = np.zeros(self.n, dtype=np.int32)
+        size = ctypes.c_ssize_t()
+        for t, sq in enumerate(seqs):
+            if isinstance(sq, str):
+                p = _utf8(sq, ctypes.byref(size))
+                if p and size.value == len(sq):
+                    ptrs[t] = p
+                    self.lens[t] = len(sq)
+                    continue
+                sq = sq.encode("latin-1", "replace")
+            elif not isinstance(sq, bytes):
+                sq = bytes(sq)
+            keep.append(sq)
+            ptrs[t] = ctypes.cast(ctypes.c_char_p(sq), ctypes.c_void_p).value
+            self.lens[t] = len(sq)
+        flags = np.zeros(n1, dtype=np.uint8)
         if upper is not None:
             flags[:self.n] = np.asarray(upper, dtype=bool).astype(np.uint8) * L.SEQ_UPPER
-        info = np.zeros(2 * max(self.n, 1), dtype=np.int32)
+        info = np.zeros(2 * n1, dtype=np.int32)
         h = ctypes.c_void_p()
         lib = L.load()
-        L.check(lib.vapor_seqset_create(engine._ctx, self.n, L.ptr(blob, ctypes.c_uint8), L.ptr(off, ctypes.c_int64),
-                                        L.ptr(self.lens if self.n else np.zeros(1, np.int32), ctypes.c_int32),
-                                        L.ptr(flags, ctypes.c_uint8), L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+        L.check(lib.vapor_seqset_create_ptrs(engine._ctx, self.n, ptrs,
+                                             L.ptr(self.lens if self.n else np.zeros(1, np.int32), ctypes.c_int32),
+                                             L.ptr(flags, ctypes.c_uint8), L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+        del keep
         self._h = h
         self.n_exc = info[0::2][:self.n].copy()
         self.n_invalid = info[1::2][:self.n].copy()
