@@ -20,6 +20,15 @@ from typing import List, Sequence
 import numpy as np
 
 
+def _one_thread():
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=1, user_api="openmp")
+    except Exception:                      # threadpoolctl missing: run as is
+        import contextlib
+        return contextlib.nullcontext()
+
+
 def _log10(x):
     """calcu_log10, SF:155-159."""
     return 0 if x == 0 else np.log10(x)
@@ -62,7 +71,10 @@ def _split_once(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     ks = list(range(1, min([5, len(xs) + 1])))
     # the reference fits every k twice (SF:860-861: once for the BIC, once more only to test whether a
     # cluster came out empty); one fit serves both here - the draws are unseeded either way
-    fits = [cluster.KMeans(n_clusters=k, init="k-means++", random_state=rs).fit(pts) for k in ks]
+    # a few hundred 2-D points: one OpenMP thread (the team start-up of sklearn's Lloyd loop costs several times the
+    # fit itself at this size; the arithmetic is the same)
+    with _one_thread():
+        fits = [cluster.KMeans(n_clusters=k, init="k-means++", random_state=rs).fit(pts) for k in ks]
     preds = [f.labels_ for f in fits]
     bic, bic_k = [], []
     for k in ks:
