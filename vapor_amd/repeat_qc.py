@@ -20,11 +20,18 @@ from typing import List, Sequence
 import numpy as np
 
 
+_TPC = None
+
+
 def _one_thread():
+    """Context limiting OpenMP to one thread; the library scan behind it is done once (it takes longer than a fit)."""
+    global _TPC
     try:
-        from threadpoolctl import threadpool_limits
-        return threadpool_limits(limits=1, user_api="openmp")
-    except Exception:                      # threadpoolctl missing: run as is
+        if _TPC is None:
+            from threadpoolctl import ThreadpoolController
+            _TPC = ThreadpoolController()
+        return _TPC.limit(limits=1, user_api="openmp")
+    except Exception:                      # threadpoolctl missing or too old: run as is
         import contextlib
         return contextlib.nullcontext()
 
