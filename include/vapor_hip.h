@@ -197,6 +197,13 @@ int vapor_selfplot_qc(vapor_ctx* ctx, vapor_seqset* set, int32_t n, const int32_
 int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* hits_ji, const int64_t* off,
                      const uint32_t* flags, int64_t* stats, uint8_t* hit_flags);
 
+/*
+ * Host helper of the read extraction (cigar2alignstart_by_pos, SF:309-337; no device involved): walks the CIGAR of
+ * an alignment starting at align_start until the reference cursor passes start-1; out[0] = offset into the read,
+ * out[1] = miss_bp.  VAPOR_E_ARG if the CIGAR holds no operation (IndexError in the reference).
+ */
+int vapor_cigar2alignstart(const char* cigar, int64_t align_start, int64_t start, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -439,3 +439,28 @@ def test_bed_cli_from_files_without_samtools(fake, case, tmp_path):
     finally:
         seqio.set_backend(None)
     assert got == exp and len(exp.splitlines()) == len(case["vapor_text"].splitlines())
+
+
+def test_native_cigar_walk_equals_the_python_statement():
+    """vapor_cigar2alignstart (host helper in the C ABI) against the Python restatement of SF:309-337: the survey's
+    known answers and random CIGARs with every operation, junk characters, empty strings and long walks."""
+    import random
+    assert seqio.cigar2alignstart_by_pos("100S500M20I300M", 1000, 1200, 2200) == [300, 0]
+    assert seqio.cigar2alignstart_by_pos("50M300D500M", 1000, 1200, 2200) == [50, 150]
+    with pytest.raises(IndexError):
+        seqio.cigar2alignstart_by_pos("", 5, 9, 20)
+    rnd = random.Random(11)
+    for _ in range(3000):
+        nops = rnd.choice([0, 1, 3, 30, 400, 2500])
+        cig = "".join("%d%s" % (rnd.randint(1, rnd.choice([3, 40, 900])), rnd.choice("MMMMIDS=XNHPQ ")) for _ in range(nops))
+        a = rnd.randint(1, 5000)
+        st = a + rnd.randint(-50, rnd.choice([10, 500, 20000]))
+        try:
+            exp = seqio._cigar2alignstart_py(cig, a, st, st + 100)
+        except IndexError:
+            exp = "IndexError"
+        try:
+            got = seqio.cigar2alignstart_by_pos(cig, a, st, st + 100)
+        except IndexError:
+            got = "IndexError"
+        assert got == exp, (cig[:60], a, st)

@@ -966,6 +966,37 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
 
 
 // ------------------------------------------------------------------------------------------
+// Host helper of the read extraction: cigar2alignstart_by_pos, SF:309-337.  Walks the CIGAR until the
+// reference cursor passes start-1; out[0] = offset into the read, out[1] = miss_bp.  S/I/M/= advance the read,
+// M/=/D the reference, N/H/P/X nothing (as in the reference).  VAPOR_E_ARG when the CIGAR holds no operation
+// (the reference raises IndexError there).
+extern "C" int vapor_cigar2alignstart(const char* cigar, int64_t align_start, int64_t start, int64_t* out)
+{
+    if (!cigar || !out) return fail(VAPOR_E_ARG, "vapor_cigar2alignstart: null argument");
+    int64_t q = 0, r = align_start, n = 0;
+    bool have_n = false;
+    char last = 0;
+    for (const char* c = cigar; *c; ++c) {
+        const char ch = *c;
+        if (ch >= '0' && ch <= '9') { n = n * 10 + (ch - '0'); have_n = true; continue; }
+        const bool op = ch == 'M' || ch == 'I' || ch == 'D' || ch == 'N' || ch == 'S' || ch == 'H' || ch == 'P' || ch == '=' || ch == 'X';
+        if (op && have_n) {
+            if (ch == 'S' || ch == 'I') q += n;
+            else if (ch == 'M' || ch == '=') { q += n; r += n; }
+            else if (ch == 'D') r += n;
+            last = ch;
+            if (r > start - 1) break;
+        }
+        n = 0; have_n = false;             // any other character ends the number, as the regular expression would
+    }
+    if (!last) return fail(VAPOR_E_ARG, "vapor_cigar2alignstart: no CIGAR operation");
+    const int64_t over = r - start;
+    if (last == 'M' || last == '=') { out[0] = q - over; out[1] = 0; }
+    else { out[0] = q; out[1] = over; }
+    return VAPOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // The same run without a host round trip per step: enqueue only, vapor_plan_sync() waits and reports.
 constexpr int ASYNC_RING = 64;
 
