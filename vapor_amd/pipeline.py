@@ -74,7 +74,7 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
     out: List[Optional[object]] = [None] * n
     work = []                     # (slot, seq2)
     for t, s in enumerate(seqs):
-        s2 = "".join([c for c in s if not c == "X"])
+        s2 = s.replace("X", "")              # ''.join([i for i in seq2 if not i == 'X']), SF:2031
         if s2.count("N") + s2.count("n") > 100:
             out[t] = ["Error", "Error"]
         else:

@@ -74,7 +74,7 @@ def _split_once(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     from sklearn import cluster
     seed = os.environ.get("VAPOR_QC_SEED")
     rs = int(seed) if seed else None
-    pts = np.array([[xs[t], ys[t]] for t in range(len(xs))])
+    pts = np.column_stack((np.asarray(xs), np.asarray(ys)))        # = np.array([[x, y] ...]) of SF:858
     ks = list(range(1, min([5, len(xs) + 1])))
     # the reference fits every k twice (SF:860-861: once for the BIC, once more only to test whether a
     # cluster came out empty); one fit serves both here - the draws are unseeded either way
@@ -100,7 +100,7 @@ def _split_once(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     else:
         cent, _ = kmeans(white, picked)
     idx, _ = vq(white, cent)
-    return [[[int(v) for v in pts[idx == c, 0]], [int(v) for v in pts[idx == c, 1]]] for c in range(picked)]
+    return [[pts[idx == c, 0].tolist(), pts[idx == c, 1].tolist()] for c in range(picked)]
 
 
 def x_means(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
