@@ -83,6 +83,9 @@ WORKLOADS = {
     # configs[2]: 1000 mixed DEL/DUP/INV/INS loci, 15 kb reads at 40x
     "cfg3": dict(n_loci=1000, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), read_len=15000, allele_len=20000,
                  reads_per_locus=40),
+    # the largest shape BASELINE names (configs[4]: 30 kb reads, 40 kb windows, 60x), a single-GPU slice of it
+    "cfg5s": dict(n_loci=200, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), read_len=30000, allele_len=40000,
+                  reads_per_locus=60),
     "tiny": dict(n_loci=8, svtypes=("DEL", "TANDUP", "INV", "INS"), read_len=1500, allele_len=3000, reads_per_locus=6),
 }
 
