@@ -264,7 +264,7 @@ constexpr size_t join_lds_bytes()
     return sizeof(uint32_t) * ((1 << C::NB_LOG2) / 2 + 2) + sizeof(uint32_t) * ((1 << C::FILT_LOG2) / 32) +
            sizeof(uint32_t) * tile_words<C, BPS>() +
            sizeof(uint32_t) * etile_words<C, BPS>() + sizeof(unsigned long long) * MAX_READS_PER_TASK +
-           sizeof(uint32_t) * (C::THREADS / 64) * C::QCAP + sizeof(uint32_t) * (C::THREADS / 64) * rbuf_words<BPS>() +
+           sizeof(uint32_t) * (C::THREADS / 64) * (C::QCAP + 4) + sizeof(uint32_t) * (C::THREADS / 64) * rbuf_words<BPS>() +
            sizeof(uint32_t) * (2 * (C::THREADS / 64) + 4 + MAX_READS_PER_TASK + 2) + sizeof(uint16_t) * tile_pos<C, BPS>();
 }
 
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
     uint32_t* etile = tile + tile_words<C, BPS>();
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + etile_words<C, BPS>());
     uint32_t* queue = reinterpret_cast<uint32_t*>(cnt + MAX_READS_PER_TASK);   // JOIN_WAVES * JQCAP
-    uint32_t* rbufs = queue + JOIN_WAVES * JQCAP;                              // JOIN_WAVES * rbuf_words
+    uint32_t* rbufs = queue + JOIN_WAVES * (JQCAP + 4);                        // JOIN_WAVES * rbuf_words
     uint32_t* wtot = rbufs + JOIN_WAVES * rbuf_words<BPS>();                   // 2 * JOIN_WAVES + 4
     int* cstart = reinterpret_cast<int*>(wtot + 2 * JOIN_WAVES + 4);              // MAX_READS_PER_TASK + 2: strip prefix of the group's reads
     uint16_t* entries = reinterpret_cast<uint16_t*>(cstart + MAX_READS_PER_TASK + 2);  // TA
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
     const DTask task = tasks[blockIdx.x];          // first = index into task_pairs, n_reads = pairs in the range
     const uint32_t* plane = (BPS == 2) ? p2 : x4;
     constexpr int WPC = (BPS == 2) ? VP_P2_WORDS_PER_CHUNK : VP_X4_WORDS_PER_CHUNK;
-    uint32_t* myq = queue + wave * JQCAP;
+    uint32_t* myq = queue + wave * (JQCAP + 4);    // JQCAP slots + a dump slot for lanes that have nothing to store
     uint32_t* rbuf = rbufs + wave * rbuf_words<BPS>();
 
     if (tid < MAX_READS_PER_TASK) cnt[tid] = 0ULL;
@@ -782,13 +782,15 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                             {
                                 // buckets hold one or two entries almost always: two predicated stores, a loop
                                 // only for the rest
+                                // three unconditional stores (a lane without that candidate writes the dump slot:
+                                // no execution-mask juggling, no branch), a uniform loop only for buckets of four
+                                // entries and more
                                 const uint32_t pos = (uint32_t)qlen + incl[x] - c;
                                 const uint32_t item = (il << 16) | s0;
-                                if (c > 0u) myq[pos] = item;
-                                if (c > 1u) myq[pos + 1] = item + 1u;
-                                // larger buckets level by level, uniformly (a per-lane loop here compiles to a
-                                // long divergent sequence that nearly every step would enter for one lane)
-                                for (uint32_t u = 2; __ballot(c > u); ++u)
+                                myq[c > 0u ? pos : (uint32_t)JQCAP] = item;
+                                myq[c > 1u ? pos + 1u : (uint32_t)JQCAP] = item + 1u;
+                                myq[c > 2u ? pos + 2u : (uint32_t)JQCAP] = item + 2u;
+                                for (uint32_t u = 3; __ballot(c > u); ++u)
                                     if (c > u) myq[pos + u] = item + u;
                             }
                             qlen += (int)tot;
