@@ -261,7 +261,7 @@ template <int BPS> __host__ __device__ constexpr int rbuf_words() { return ((JCH
 template <typename C, int BPS>
 constexpr size_t join_lds_bytes()
 {
-    return sizeof(uint32_t) * ((1 << C::NB_LOG2) / 2 + 2) + sizeof(uint32_t) * ((1 << C::FILT_LOG2) / 32) +
+    return sizeof(uint32_t) * ((1 << C::NB_LOG2) / 2 + 2 + 1) + sizeof(uint32_t) * ((1 << C::FILT_LOG2) / 32) +
            sizeof(uint32_t) * tile_words<C, BPS>() +
            sizeof(uint32_t) * etile_words<C, BPS>() + sizeof(unsigned long long) * MAX_READS_PER_TASK +
            sizeof(uint32_t) * (C::THREADS / 64) * (C::QCAP + 4) + sizeof(uint32_t) * (C::THREADS / 64) * rbuf_words<BPS>() +
@@ -524,7 +524,9 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
     uint32_t* filt = start32 + (JNB / 2 + 2);                                // 2^FILT_LOG2 bits
     uint32_t* tile = filt + (1 << C::FILT_LOG2) / 32;
     uint32_t* etile = tile + tile_words<C, BPS>();
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(etile + etile_words<C, BPS>());
+    // (the 64-bit counters need 8-byte alignment whatever the sizes before them add up to)
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(
+        lds + (((JNB / 2 + 2) + (1 << C::FILT_LOG2) / 32 + tile_words<C, BPS>() + etile_words<C, BPS>() + 1) & ~1));
     uint32_t* queue = reinterpret_cast<uint32_t*>(cnt + MAX_READS_PER_TASK);   // JOIN_WAVES * JQCAP
     uint32_t* rbufs = queue + JOIN_WAVES * (JQCAP + 4);                        // JOIN_WAVES * rbuf_words
     uint32_t* wtot = rbufs + JOIN_WAVES * rbuf_words<BPS>();                   // 2 * JOIN_WAVES + 4
