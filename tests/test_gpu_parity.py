@@ -294,11 +294,13 @@ def test_run_records_expand_to_the_oracle_dots(eng, oracle):
     nearly = synth.mutate(np.random.default_rng(5), allele[300:5600], 0.001, 0.002, 0.002)[0]
     inv = allele[500:2000] + synth.revcomp(allele[2000:3500]) + allele[3500:5000]
     with_n = exact[:2000] + "N" + exact[2001:]
-    big = synth.random_dna(rng, 36000)                                  # 24 576-position tiles: two of them
+    big = synth.random_dna(rng, 36000)                                  # more than one table holds: two tiles
     long_read = big[30000:35500]
-    seqs = [allele, exact, nearly, inv, with_n, big, long_read]
+    huge = synth.random_dna(rng, 47000)                                 # a longer one, read across the tile edge below
+    huge_read = synth.mutate(np.random.default_rng(8), huge[22000:27500], 0.002, 0.004, 0.004)[0]   # across the tile edge
+    seqs = [allele, exact, nearly, inv, with_n, big, long_read, huge, huge_read]
     rows = [(1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (3, 0, 0, 10, 7), (1, 0, 913, 10, 3), (4, 0, 0, 10, 7),
-            (6, 5, 0, 10, 7), (1, 0, 0, 20, 7), (2, 0, 0, 40, 3), (6, 5, 31000, 30, 1)]
+            (6, 5, 0, 10, 7), (1, 0, 0, 20, 7), (2, 0, 0, 40, 3), (6, 5, 31000, 30, 1), (8, 7, 0, 10, 7), (8, 7, 21000, 20, 3)]
     ss = eng.seqset(seqs)
     plan = eng.plan(ss, eng.make_pairs(rows))
     st = plan.run().copy()

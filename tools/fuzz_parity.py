@@ -35,8 +35,8 @@ def run(budget: float = 60.0, seed: int = 1, engine=None) -> str:
     while time.time() < t_end:
         seqs, rows = [], []
         for _ in range(int(rng.integers(4, 14))):
-            la = int(rng.choice([rng.integers(12, 200), rng.integers(200, 3000), rng.integers(3000, 9000), rng.integers(24000, 26000)],
-                                p=[0.25, 0.45, 0.25, 0.05]))
+            la = int(rng.choice([rng.integers(12, 200), rng.integers(200, 3000), rng.integers(3000, 9000), rng.integers(24000, 26000),
+                                 rng.integers(40500, 41500)], p=[0.25, 0.45, 0.24, 0.04, 0.02]))
             allele = synth.random_dna(rng, la)
             a_idx = len(seqs)
             seqs.append(spoil(allele, rng) if rng.random() < 0.4 else allele)
