@@ -739,11 +739,177 @@ def gen_melt(m):
                               "fasta": fa, "vcf": "\n".join(lines) + "\n", "status": r if "error" in r else "ok",
                               "cases": [{"name": "melt", "vapor_text": text}]})
 
+# ---------------------------------------------------------------------------
+COMPLEX_SPECS = [
+    # DUP_INV on one contig, copy right of the block (a b a^), left of it (b^ a b), inside it (a a^)
+    dict(type="DUP_INV", a=200, gap=1400), dict(type="DUP_INV", a=260, gap=1900), dict(type="DUP_INV", a=180, gap=-1300),
+    dict(type="DUP_INV", a=520, inside=120, alt_fraction=0.0),
+    # far copy (>= 10 kb): the junction-only branch (within_10Perc_m1b); copy on another contig: abs_dis_m1b
+    dict(type="DUP_INV", a=320, gap=10400), dict(type="DUP_INV", a=280, xchrom=1000), dict(type="DUP_INV", a=240, gap=1500, n_reads=3),
+    # DISDUP from a VCF reaches a scorer only where the whole-region branch is not taken (SF:1801 compares str with
+    # int there and raises): far copy, copy on another contig (near and far coordinates), too few spanning reads
+    dict(type="DISDUP", a=300, gap=11000), dict(type="DISDUP", a=260, xchrom=900), dict(type="DISDUP", a=260, xchrom=15000),
+    dict(type="DISDUP", a=220, gap=1500),
+    # DEL_INV: adjacent blocks in both orders, >= 10 kb (vapor_long_del_inv), blocks >= 100 bp apart (TypeError)
+    dict(type="DEL_INV", a=300, b=420), dict(type="DEL_INV", a=350, b=300, order="inv,del"),
+    dict(type="DEL_INV", a=700, b=9600), dict(type="DEL_INV", a=300, b=400, apart=150), dict(type="DEL_INV", a=240, b=260, n_reads=3),
+    # Other=: letter structures through vapor_CANNOT_CLASSIFY_VapoR
+    dict(type="OTHER", a=420, b=520, other=("ab/ab", "b/b^")), dict(type="OTHER", a=380, b=460, other=("ab/ab", "a/ab")),
+    dict(type="OTHER", a=300, b=2400, other=("ab/ab", "aba/ab")), dict(type="OTHER", a=400, b=500, other=("ab/ab", "ba^/ab")),
+]
+
+
+def run_vcf_complex(m, cli, world, tmp, ref_path, num_reads_cff=3):
+    """The complex-type branches of `vapor vcf` (vapor_vali/vapor:425-463) with figures disabled."""
+    vcf = os.path.join(tmp, "in.vcf")
+    text = synth.complex_vcf_text(world)
+    open(vcf, "w").write(text)
+    out_path = os.path.join(tmp, "figs") + "/"
+    vcf_list, rec_hash = cli["vcf_list_readin"](vcf)
+    rec_new = m.vcf_rec_hash_modify(rec_hash)
+    m.write_output_initiate(vcf + ".vapor")
+    rows = []
+    for x in list(vcf_list.keys()):
+        for y in vcf_list[x]:
+            y0 = jsonable(y)
+            if x == "DISDUP":
+                key = ":".join([str(i) for i in y + ["DISDUP"]])
+                sc = call(m.vapor_simple_disdup_Vapor, num_reads_cff, 1, "x.bam", ref_path, y, out_path + "f.png")
+            elif x == "DEL_INV":
+                key = ":".join(["_".join([str(i) for i in j]) for j in y] + ["DEL_INV"])
+                sc = call(m.vapor_del_inv_Vapor, num_reads_cff, 1, "x.bam", ref_path, y, out_path + "f.png")
+            elif x == "DUP_INV":
+                key = ":".join([str(i) for i in y + ["DUP_INV"]])
+                sc = call(m.vapor_dup_inv_VapoR, num_reads_cff, 1, "x.bam", ref_path, y, out_path + "f.png")
+            elif x == "Other":
+                key = ":".join([str(i) for i in y + ["CANNOT_CLASSIFY"]])
+                sc = call(m.vapor_CANNOT_CLASSIFY_VapoR, num_reads_cff, 1, "x.bam", ref_path, y, out_path + "f.png")
+            else:
+                raise AssertionError(x)
+            rec = {"type": x, "item": y0, "key": key, "scores": sc}
+            if "ok" in sc:
+                m.write_output_main(vcf + ".vapor", m.result_organize_ins([key, sc["ok"]]))
+            rows.append(rec)
+    table = open(vcf + ".vapor").read()
+    final = call(m.vcf_vapor_modify, vcf, rec_new)
+    return {"vcf": text, "per_record": rows, "table": table,
+            "final": open(vcf + ".vapor").read() if "ok" in final else None, "final_status": final if "error" in final else "ok"}
+
+
+def _count_xmeans(m):
+    """Counts entries into the reference's unseeded clustering (SF:1165-1167); the complex worlds must never get there."""
+    calls = [0]
+    orig = m.X_means_cluster_reformat
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    m.X_means_cluster_reformat = counted
+    return calls, orig
+
+
+def gen_complex(m):
+    """BASELINE.json configs[3]'s complex types (DISDUP, DUP_INV, DEL_INV, Other=) through the reference's VCF
+    loop, on worlds whose windows stay out of the X-means band, so that the vectors are reproducible."""
+    cli = load_cli(m)
+    m.make_event_figure_1 = lambda *a, **k: None
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_cx_")
+    os.makedirs(os.path.join(tmp, "figs"), exist_ok=True)
+    calls, orig = _count_xmeans(m)
+    cases = []
+    for name, seed, specs in (("vcf_cx_a", 181, COMPLEX_SPECS), ("vcf_cx_b", 182, COMPLEX_SPECS[:3] + COMPLEX_SPECS[11:13] + COMPLEX_SPECS[16:18])):
+        w = synth.make_complex_world(seed, specs)
+        ref_path = os.path.join(tmp, name + ".fa")
+        with open(ref_path + ".fai", "w") as fo:
+            for k, v in w.contigs.items():
+                fo.write("%s\t%d\t0\t60\t61\n" % (k, len(v)))
+        m.os = ShimOS(w)
+        r = run_vcf_complex(m, cli, w, tmp, ref_path)
+        m.os = os
+        r.update({"name": name, "world": world_to_json(w)})
+        cases.append(r)
+        print("  %s: %s final=%s" % (name, [(p["type"], len(p["scores"]["ok"]) if "ok" in p["scores"] else p["scores"]["error"])
+                                            for p in r["per_record"]], r["final_status"]))
+    # driver-level: DISDUP with integer coordinates (the whole-region branch, directed_dis scorer), which the VCF
+    # parser never produces (it hands the insert point over as a string)
+    drv = []
+    w = synth.make_complex_world(183, [dict(type="DISDUP", a=220, gap=1500), dict(type="DISDUP", a=260, gap=-1700),
+                                       dict(type="DISDUP", a=300, inside=150, alt_fraction=0.0),
+                                       dict(type="DISDUP", a=200, gap=1400, n_reads=3)])
+    m.os = ShimOS(w)
+    for l in w.loci:
+        info = [l.chrom, l.start, l.end, l.chrom, int(l.extra["insert_point"])]
+        sc = call(m.vapor_simple_disdup_Vapor, 3, 1, "x.bam", "ref.fa", list(info), os.path.join(tmp, "f.png"))
+        drv.append({"sv_info": info, "scores": sc})
+        print("  disdup driver %s: %s" % (info, sc if "error" in sc else [round(v, 3) for v in sc["ok"]]))
+    m.os = os
+    m.X_means_cluster_reformat = orig
+    assert calls[0] == 0, "a complex world entered the unseeded X-means branch (%d calls): change its block sizes" % calls[0]
+    dump("locus_complex.json.gz", {"source": "vapor vcf loop vapor_vali/vapor:425-463 + drivers SF:1490-1699, 1786-1854 (figures off); "
+                                             "xmeans_calls == 0 asserted when generated",
+                                   "cases": cases, "disdup_driver": {"world": world_to_json(w), "cases": drv}})
+
+
+def gen_deep(m):
+    """BASELINE.json configs[4]'s concordance leg at a size the reference finishes: loci of 60 reads, every read
+    scored by the reference's scorers directly (the drivers keep 20 reads, SF:1091-1102), then the drivers' per-read
+    rule, result_organize_ins and gt_estimate_log_likelihood."""
+    rng = np.random.default_rng(505)
+    cases = []
+    for li, (t, n_reads, alt_frac) in enumerate((("DEL", 60, 0.5), ("TANDUP", 60, 0.5), ("INV", 60, 1.0), ("INS", 60, 0.0),
+                                                 ("DEL", 64, 0.15), ("INV", 33, 0.5))):
+        L = 2400
+        ref = synth.random_dna(rng, L)
+        span = int(rng.integers(250, 600))
+        s = int(rng.integers(700, 900))
+        if t == "DEL":
+            alt = ref[:s] + ref[s + span:]
+        elif t == "TANDUP":
+            span = 160
+            alt = ref[:s + span] + ref[s:s + span] + ref[s + span:]
+        elif t == "INV":
+            alt = ref[:s] + synth.revcomp(ref[s:s + span]) + ref[s + span:]
+        else:
+            alt = ref[:s] + synth.random_dna(rng, span) + ref[s:]
+        reads = []
+        for ri in range(n_reads):
+            hap = alt if rng.random() < alt_frac else ref
+            rd, _c = synth.mutate(rng, hap[:min(len(ref), len(alt))])
+            reads.append([rd[:min(len(ref), len(alt)) - 5], 0, "d%d_%d" % (li, ri)])
+        k = m.window_size_refine(ref)[0]
+        scores = []
+        per_read = []
+        for x in reads:
+            if t == "DEL":
+                a = m.calcu_vapor_single_read_score_abs_dis_m1b(ref, alt, x, k)
+                b = m.calcu_vapor_single_read_score_within_10Perc_m1b(ref, alt, x, k)
+                per_read.append([a, b])
+                if not 0 in a and not 0 in b:
+                    scores.append(min([1 - float(a[1]) / float(a[0]), 1 - float(b[1]) / float(b[0])]))
+                elif not 0 in a:
+                    scores.append(1 - float(a[1]) / float(a[0]))
+                elif not 0 in b:
+                    scores.append(1 - float(b[1]) / float(b[0]))
+            else:
+                fn = m.calcu_vapor_single_read_score_directed_dis_m1b_redefine_diagnal if t == "TANDUP" else m.calcu_vapor_single_read_score_abs_dis_m1b
+                a = fn(ref, alt, x, k)
+                per_read.append([a])
+                if not 0 in a:
+                    scores.append(1 - float(a[1]) / float(a[0]))
+        org = m.result_organize_ins(["k%d" % li, scores])
+        gt = m.gt_estimate_log_likelihood(org) if org[1] != "NA" else None
+        cases.append({"name": "%s_%d" % (t, n_reads), "svtype": t, "ref": ref, "alt": alt, "k": k, "reads": reads,
+                      "per_read": per_read, "scores": scores, "organize": org, "gt": gt})
+        print("  deep %s: %d reads, %d scored, %s" % (t, n_reads, len(scores), gt))
+    dump("deep_loci.json.gz", {"source": "scorers SF:182-294 on every read, drivers' per-read rule SF:1718-1726, 1909-1915, "
+                                         "result_organize_ins SF:1219-1231, gt_estimate_log_likelihood SF:2054-2077",
+                               "cases": cases})
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt", "complex", "deep"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)

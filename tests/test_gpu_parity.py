@@ -370,3 +370,19 @@ def test_async_steps_report_overflow(eng):
         plan.close()
     finally:
         eng.set_param("max_pair_cap", 1 << 28)
+
+
+def test_queue_edge(eng, oracle):
+    """Candidate totals of 127, 129 and 129 on consecutive filled positions of one strip (tests/queue_case.py): the
+    queue's fast path must not take a total it cannot always hold.  Dot for dot against the oracle."""
+    import queue_case
+    read, allele, _km = queue_case.build()
+    assert queue_case.candidate_totals(read, allele)[:9] == [127, 0, 0, 0, 129, 0, 0, 0, 129]
+    seqs = [read, allele]
+    ss = eng.seqset(seqs)
+    st, hits = eng.dotplots(ss, eng.make_pairs([(0, 1, 0, 10, 7)]))
+    exp, h, _k1, _k2 = oracle.pair_stats(10, read, allele, want_hits=True)
+    assert st[0, 15] == 0 and st[0, :10].tolist() == exp[:10].tolist()
+    eh = np.asarray(h, dtype=np.int32).reshape(-1, 2)
+    assert hits[0].tolist() == eh[np.lexsort((eh[:, 1], eh[:, 0]))].tolist()
+    assert st[0, 0] >= 127 + 129 + 129

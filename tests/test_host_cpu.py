@@ -464,3 +464,12 @@ def test_native_cigar_walk_equals_the_python_statement():
         except IndexError:
             got = "IndexError"
         assert got == exp, (cig[:60], a, st)
+
+
+def test_queue_edge_case_design():
+    """The crafted pair of tests/queue_case.py really asks the join's queue for 127, 129, 129 candidates (model of
+    the device hash on the CPU; the GPU test compares the kernel's dots with the oracle)."""
+    import queue_case
+    read, allele, km = queue_case.build()
+    assert queue_case.candidate_totals(read, allele)[:9] == [127, 0, 0, 0, 129, 0, 0, 0, 129]
+    assert allele.count(km["P"]) == 2 and allele.count(km["Q"]) == 3 and allele.count(km["R"]) == 3

@@ -58,6 +58,7 @@ struct vapor_ctx {
 
 struct vapor_seqset {
     vapor_ctx* ctx = nullptr;
+    int device = 0;                // kept here: the set may be destroyed after its context
     int32_t n = 0;
     std::vector<SeqDesc> h;        // host copy (with device-computed counts)
     SeqDesc* d_seqs = nullptr;
@@ -71,6 +72,7 @@ struct Launch {
 
 struct vapor_plan {
     vapor_ctx* ctx = nullptr;
+    int device = 0;                // kept here: the plan may be destroyed after its context
     vapor_seqset* set = nullptr;
     int64_t n_pairs = 0;
     std::vector<DPair> hp;
@@ -123,8 +125,8 @@ extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 template <int BPS, int K>
 static hipError_t set_join_attr()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinBig, BPS, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<JoinBig, BPS>());
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinCfg, BPS, K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<JoinCfg, BPS>());
 }
 
 extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
@@ -141,7 +143,8 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
-            c->join_tasks = prop.multiProcessorCount;   // a join workgroup fills a CU's LDS: one task per CU per launch
+            // a join workgroup fills a CU's LDS (or, in the two-per-CU experiment geometry, half of it)
+            c->join_tasks = prop.multiProcessorCount * (JoinCfg::THREADS <= 768 ? 2 : 1);
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VAPOR_E_HIP, hipGetErrorString(e)); }
@@ -194,7 +197,7 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
 extern "C" int vapor_seqset_destroy(vapor_seqset* s)
 {
     if (!s) return VAPOR_OK;
-    (void)hipSetDevice(s->ctx->device);
+    (void)hipSetDevice(s->device);
     (void)hipFree(s->d_seqs);
     (void)hipFree(s->d_p2);
     (void)hipFree(s->d_e1);
@@ -212,6 +215,7 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
     vapor_seqset* s = new (std::nothrow) vapor_seqset();
     if (!s) return fail(VAPOR_E_NOMEM, "out of memory");
     s->ctx = ctx;
+    s->device = ctx->device;
     s->n = n_seqs;
     s->h.resize((size_t)std::max(n_seqs, 1));
     size_t asc = 0, pl = 0;
@@ -330,7 +334,7 @@ static void plan_free_device(vapor_plan* p)
 extern "C" int vapor_plan_destroy(vapor_plan* p)
 {
     if (!p) return VAPOR_OK;
-    (void)hipSetDevice(p->ctx->device);
+    (void)hipSetDevice(p->device);
     plan_free_device(p);
     if (p->h_stats) (void)hipHostFree(p->h_stats);
     if (p->h_overflow) (void)hipHostFree(p->h_overflow);
@@ -348,6 +352,8 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
     delete p;
     return VAPOR_OK;
 }
+
+static_assert((2 * VAPOR_MAX_SEQ_LEN + 2 + 31) / 32 <= CLEAN_RANGE_WORDS_MAX, "cluster_axis sizes its per-thread word list for this");
 
 static bool k_supported(int k) { return k == 10 || k == 20 || k == 30 || k == 40; }
 
@@ -379,6 +385,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     vapor_plan* p = new (std::nothrow) vapor_plan();
     if (!p) return fail(VAPOR_E_NOMEM, "out of memory");
     p->ctx = ctx;
+    p->device = ctx->device;
     p->set = set;
     p->n_pairs = n_pairs;
     p->hp.resize((size_t)std::max<int64_t>(n_pairs, 1));
@@ -426,7 +433,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     });
     p->task_pairs = order;
     auto tiles_of = [&](int32_t seq2, int k, int bps) {
-        const int ta = bps == 2 ? tile_pos<JoinBig, 2>() : tile_pos<JoinBig, 4>();
+        const int ta = bps == 2 ? tile_pos<JoinCfg, 2>() : tile_pos<JoinCfg, 4>();
         return std::max(1, (set->h[seq2].len - k + 1 + ta - 1) / ta);
     };
     for (size_t q = 0; q < order.size();) {
@@ -519,7 +526,7 @@ template <int BPS, int K>
 static void launch_join(vapor_plan* p, const Launch& L, bool first)
 {
     const vapor_seqset* s = p->set;
-    hipLaunchKernelGGL((join_kernel<JoinBig, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinBig::THREADS), (join_lds_bytes<JoinBig, BPS>()),
+    hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), (join_lds_bytes<JoinCfg, BPS>()),
                        p->ctx->stream, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
                        p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }
@@ -827,7 +834,8 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         d.cap = (uint32_t)(off[t + 1] - off[t]);
         d.hit_off = poff[t];
         nh[t] = (unsigned long long)(off[t + 1] - off[t]) * 0x100000001ull;   // records | dots << 32
-        rw = std::max(rw, (mi + mj + 4 + 31) / 32);
+        // the largest values, i + j = 131070 and i - j + len2 = 131071, still fall into word 4095
+        rw = std::min(std::max(rw, (mi + mj + 4 + 31) / 32), CLEAN_RANGE_WORDS_MAX);
     }
     DPair* d_dp = nullptr; unsigned long long* d_nh = nullptr; unsigned int* d_ov = nullptr; int32_t* d_big = nullptr;
     unsigned long long* d_hits = nullptr; uint8_t* d_fl = nullptr; long long* d_st = nullptr;

@@ -57,6 +57,8 @@ constexpr int MAX_READS_PER_TASK = 64;
 #endif
 constexpr int CLEAN_THREADS = VAPOR_CLEAN_THREADS;
 constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
+// words of the clean kernels' value bitmap: values i + j and i - j + len2 stay below 2 * 65536 (positions are 16 bit)
+constexpr int CLEAN_RANGE_WORDS_MAX = 4096;
 
 // per-hit working flags inside clean_kernel (upper nibble) and the public ones (lower)
 #define HF_C1 1u
@@ -247,11 +249,23 @@ __device__ __forceinline__ bool any_exc(P plane, uint32_t pos)
 // A task is a contiguous range of the batch's pairs sorted by allele (cost-balanced on the host);
 // the table is rebuilt only when the allele changes inside the range.
 constexpr int JCHUNK = 1024;                      // read positions per wave pass (16 per lane)
+// The queue's fast path takes a position whose candidates over the wave number at most QCAP - this (see the fill loop).
+// 128 is the value; tests/test_gpu_parity.py::test_queue_edge was checked once against a build with 127 (it fails there).
+#ifndef VAPOR_JQ_FAST_SLACK
+#define VAPOR_JQ_FAST_SLACK 128
+#endif
 
 // Geometry of the join workgroup: it owns a whole CU's LDS (16 waves, one table of up to 24576 positions
 // in 32768 buckets).  Smaller tables would not raise residency: at ~117 VGPRs four waves per SIMD is the
 // register limit as well.
-struct JoinBig { static constexpr int THREADS = 1024, TA2 = 24576, TA4 = 16384, NB_LOG2 = 15, FILT_LOG2 = 17, QCAP = 256; };
+struct JoinBig { static constexpr int THREADS = 1024, WPS = 4, TA2 = 24576, TA4 = 16384, NB_LOG2 = 15, FILT_LOG2 = 17, QCAP = 256; };
+// Experiment geometry (tools/ab.py -DVAPOR_JOIN_CFG=JoinHalf): two workgroups per CU, six waves per SIMD, half a
+// table each - a 20 kb allele then takes two tiles and every read is probed twice.
+struct JoinHalf { static constexpr int THREADS = 768, WPS = 6, TA2 = 10240, TA4 = 8192, NB_LOG2 = 14, FILT_LOG2 = 16, QCAP = 224; };
+#ifndef VAPOR_JOIN_CFG
+#define VAPOR_JOIN_CFG JoinBig
+#endif
+using JoinCfg = VAPOR_JOIN_CFG;
 
 template <typename C, int BPS> __host__ __device__ constexpr int tile_pos() { return BPS == 2 ? C::TA2 : C::TA4; }
 template <typename C, int BPS> __host__ __device__ constexpr int tile_words() { return ((tile_pos<C, BPS>() + 64) * BPS) / 32 + 8; }
@@ -504,7 +518,7 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
 }
 
 template <typename C, int BPS, int K>
-__global__ __launch_bounds__(C::THREADS) void join_kernel(
+__global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
     const int32_t* __restrict__ task_pairs, unsigned long long* __restrict__ hits, unsigned long long* __restrict__ n_hits,
@@ -590,11 +604,12 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
             __syncthreads();
             // ---- build 2/3: inclusive prefix -> end of every bucket ---------------------------
             {
-                constexpr int WPT = (JNB / 2) / JOIN_THREADS;   // words per thread (16)
+                constexpr int WPT = (JNB / 2 + JOIN_THREADS - 1) / JOIN_THREADS;   // words per thread (16)
+                constexpr bool WHOLE = (JNB / 2) % JOIN_THREADS == 0;
                 uint32_t local = 0;
 #pragma unroll
                 for (int x = 0; x < WPT; ++x) {
-                    uint32_t w = start32[tid * WPT + x];
+                    uint32_t w = (WHOLE || tid * WPT + x < JNB / 2) ? start32[tid * WPT + x] : 0u;
                     local += (w & 0xFFFFu) + (w >> 16);
                 }
                 uint32_t incl = wave_incl_scan_u32(local);
@@ -604,6 +619,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                 for (int q = 0; q < wave; ++q) run += wtot[q];
 #pragma unroll
                 for (int x = 0; x < WPT; ++x) {
+                    if (!WHOLE && tid * WPT + x >= JNB / 2) break;
                     uint32_t w = start32[tid * WPT + x];
                     uint32_t lo = run + (w & 0xFFFFu);
                     uint32_t hi = lo + (w >> 16);
@@ -760,8 +776,10 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                             pc.count(7, tot);                  // candidates
                             if (tot == 0) continue;
                             const uint32_t il = (uint32_t)(16 * lane + g * 4 + x);
-                            if (tot > (uint32_t)(JQCAP - 127)) {
-                                // more candidates than the queue can always take (long repeats): level by level
+                            if (tot > (uint32_t)(JQCAP - VAPOR_JQ_FAST_SLACK)) {
+                                // more candidates than the queue can always take (long repeats): level by level.
+                                // (tot <= JQCAP - 128 keeps the invariant of the fast path: qlen <= 127 on entry,
+                                // at most 255 after the stores, at most 127 again after the one verification)
                                 for (uint32_t u = 0;; ++u) {
                                     const bool act = c > u;
                                     const unsigned long long m = __ballot(act);
@@ -780,7 +798,7 @@ __global__ __launch_bounds__(C::THREADS) void join_kernel(
                                 }
                                 continue;
                             }
-                            // qlen <= 127 here, so qlen + tot <= JQCAP
+                            // qlen <= 127 here, so qlen + tot <= JQCAP - 1
                             {
                                 // buckets hold one or two entries almost always: two predicated stores, a loop
                                 // only for the rest
@@ -953,7 +971,7 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
     const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
     const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
     uint32_t local = 0;
-    constexpr int PER_MAX = (4096 + CLEAN_THREADS - 1) / CLEAN_THREADS;   // range_words_cap <= 4096
+    constexpr int PER_MAX = (CLEAN_RANGE_WORDS_MAX + CLEAN_THREADS - 1) / CLEAN_THREADS;   // range_words <= the cap
     uint32_t stv[PER_MAX];
 #pragma unroll
     for (int q = 0; q < PER_MAX; ++q) {

@@ -352,3 +352,163 @@ def make_world_from_bed(rows: Sequence[Sequence], seed: int, contig_len: int = 1
                                             r0 + a + 1, cigar, read, b - a))
         w.loci.append(Locus(chrom, svtype, s, e, "sv%d" % (li + 1)))
     return w
+
+
+# ---------------------------------------------------------------------------
+# complex SV types of the VCF path (BASELINE.json configs[3]): DISDUP, DUP_INV, DEL_INV, Other=
+# ---------------------------------------------------------------------------
+
+def _add_reads(rng, w: SynthWorld, chrom: str, hap_ref: str, hap_alt: str, anchor: int, read_len: int, n_reads: int,
+               alt_fraction: float, lead: int, errors, tag: str) -> None:
+    """`n_reads` reads that start 1..`lead` bases left of the 1-based window start `anchor`."""
+    recs = w.reads.setdefault(chrom, [])
+    for ri in range(n_reads):
+        from_alt = rng.random() < alt_fraction
+        hap = hap_alt if from_alt else hap_ref
+        a = max(anchor - 1 - int(rng.integers(1, lead + 1)), 0)
+        b = min(a + read_len, len(hap))
+        read, cigar = mutate(rng, hap[a:b], *errors)
+        recs.append(SamRecord("%s_%d%s" % (tag, ri, "a" if from_alt else "r"), chrom, a + 1, cigar, read, b - a))
+
+
+def make_complex_world(seed: int, specs: Sequence[dict], n_reads: int = 8, alt_fraction: float = 0.5, lead: int = 250,
+                       errors: Tuple[float, float, float] = (0.01, 0.08, 0.04), chrom_prefix: str = "x") -> SynthWorld:
+    """One private contig (two for an inter-contig duplication) per spec.  Spec keys:
+      type   DUP_INV | DISDUP | DEL_INV | OTHER
+      a      length of the duplicated / first block
+      gap    DUP_INV / DISDUP: distance from the block's end to the insert point (negative: the insert point lies
+             that far left of the block's start); `inside`: insert point this far inside the block
+      b      DEL_INV: length of the second block; OTHER: length of block b
+      order  DEL_INV: "del,inv" or "inv,del"; `apart`: bases between the two blocks (the reference wants < 100)
+      other  OTHER: (ref structure, alt structure), e.g. ("ab/ab", "b/b^")
+      xchrom DISDUP / DUP_INV: insert point on a contig of its own, at this coordinate
+      n_reads / alt_fraction override the defaults.
+    Duplicated blocks are kept short against the distance to their copy so that the self dot plot of the alt
+    window stays below the 10 % lower-triangle share at which the reference starts its unseeded X-means
+    (qual_check_repetitive_region, SF:1165)."""
+    rng = np.random.default_rng(seed)
+    w = SynthWorld()
+    for li, sp in enumerate(specs):
+        t = sp["type"]
+        chrom = "%s%d" % (chrom_prefix, li + 1)
+        a = int(sp["a"])
+        nr = int(sp.get("n_reads", n_reads))
+        af = float(sp.get("alt_fraction", alt_fraction))
+        left = 500 + lead + 80
+        tag = "q%d" % (li + 1)
+        if t in ("DUP_INV", "DISDUP"):
+            s, e = left, left + a
+            flank = min(500, a)
+            rcb = t == "DUP_INV"
+            if "xchrom" in sp:
+                # the copy lands on another contig
+                p = int(sp["xchrom"])
+                ref = random_dna(rng, e + 3000)
+                xc = chrom + "i"
+                xref = random_dna(rng, p + a + 4000)
+                blk = ref[s:e]
+                xalt = xref[:p] + (revcomp(blk) if rcb else blk) + xref[p:]
+                w.contigs[chrom] = ref
+                w.contigs[xc] = xref
+                w.reads.setdefault(chrom, [])
+                _add_reads(rng, w, xc, xref, xalt, p - flank, 2 * flank + a + lead + 600, nr, af, lead, errors, tag)
+                w.loci.append(Locus(chrom, t, s, e, "cx%d" % (li + 1), None, {"insert_point": p, "insert_chrom": xc}))
+                continue
+            gap = int(sp.get("gap", 1200))
+            if sp.get("inside"):
+                p = s + int(sp["inside"])
+            elif gap >= 0:
+                p = e + gap
+            else:
+                left = left - gap
+                s, e = left, left + a
+                p = s + gap
+            hi = max(e, p)
+            ref = random_dna(rng, hi + 2 * a + 3000 + lead)
+            blk = ref[s:e]
+            alt = ref[:p] + (revcomp(blk) if rcb else blk) + ref[p:]
+            w.contigs[chrom] = ref
+            far = hi - min(s, p) >= 10000
+            if far:
+                anchor, rl = p - flank, 2 * flank + a + lead + 600
+            else:
+                anchor, rl = min(s, p) - flank, (hi - min(s, p)) + a + 2 * flank + lead + 500
+            _add_reads(rng, w, chrom, ref, alt, anchor, rl, nr, af, lead, errors, tag)
+            w.loci.append(Locus(chrom, t, s, e, "cx%d" % (li + 1), None, {"insert_point": p, "insert_chrom": chrom}))
+        elif t == "DEL_INV":
+            b = int(sp["b"])
+            apart = int(sp.get("apart", 0))
+            s = left
+            m1 = s + a                    # end of the first block
+            m0 = m1 + apart               # start of the second
+            e = m0 + b
+            ref = random_dna(rng, e + a + b + 3000 + lead)
+            first, second = sp.get("order", "del,inv").split(",")
+            blocks = [(s, m1, first), (m0, e, second)]
+            def piece(x0, x1, kind):
+                return revcomp(ref[x0:x1]) if kind == "inv" else ""
+
+            alt = ref[:s] + piece(*blocks[0]) + ref[m1:m0] + piece(*blocks[1])
+            alt += ref[e:]
+            w.contigs[chrom] = ref
+            flank = min(500, e - s)
+            if e - s >= 10000:
+                anchor, rl = s - flank, 2 * flank + lead + 700
+            else:
+                anchor, rl = s - flank, (e - s) + 2 * flank + lead + 500
+            _add_reads(rng, w, chrom, ref, alt, anchor, rl, nr, af, lead, errors, tag)
+            w.loci.append(Locus(chrom, t, s, e, "cx%d" % (li + 1), None,
+                                {"blocks": [[x0, x1, kind] for (x0, x1, kind) in blocks]}))
+        elif t == "OTHER":
+            b = int(sp["b"])
+            s = left
+            m = s + a
+            e = m + b
+            ref = random_dna(rng, e + a + b + 3000 + lead)
+            ref_s, alt_s = sp["other"]
+            blk = {"a": ref[s:m], "b": ref[m:e]}
+            alleles = [x for x in alt_s.split("/") if x not in ref_s.split("/")] or [ref_s.split("/")[0]]
+            haps = []
+            for al in alleles:
+                mid, prev = "", None
+                for ch in al:
+                    if ch == "^":
+                        mid = mid[:len(mid) - len(blk[prev])] + revcomp(blk[prev])
+                    else:
+                        mid += blk[ch]
+                        prev = ch
+                haps.append(ref[:s] + mid + ref[e:])
+            w.contigs[chrom] = ref
+            flank = min(500, e - s)
+            rl = 2 * (e - s) + 2 * flank + lead + 500
+            recs = w.reads.setdefault(chrom, [])
+            for ri in range(nr):
+                from_alt = rng.random() < af
+                hap = haps[ri % len(haps)] if from_alt else ref
+                a0 = max(s - flank - 1 - int(rng.integers(1, lead + 1)), 0)
+                b0 = min(a0 + rl, len(hap))
+                read, cigar = mutate(rng, hap[a0:b0], *errors)
+                recs.append(SamRecord("%s_%d%s" % (tag, ri, "a" if from_alt else "r"), chrom, a0 + 1, cigar, read, b0 - a0))
+            w.loci.append(Locus(chrom, t, s, e, "cx%d" % (li + 1), None, {"other": [ref_s, alt_s], "bps": [s, m, e]}))
+        else:
+            raise ValueError(t)
+    return w
+
+
+def complex_vcf_text(world: SynthWorld, header: bool = False) -> str:
+    """VCF records for make_complex_world's loci with the INFO keys vapor_vali/vapor:87-125, 176-202 read:
+    insert_point=chrom:pos (DISDUP, DUP_INV), del=/inv= (DEL_INV), Other=ref_alt_chrom:bp:bp:bp."""
+    out = ["##fileformat=VCFv4.1", "##source=vapor_amd.synth",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE"] if header else []
+    for l in world.loci:
+        if l.svtype in ("DISDUP", "DUP_INV"):
+            info = "SVTYPE=%s;END=%d;insert_point=%s:%d" % (l.svtype, l.end, l.extra["insert_chrom"], l.extra["insert_point"])
+        elif l.svtype == "DEL_INV":
+            info = "SVTYPE=DEL_INV;END=%d;" % l.end + ";".join("%s=%s:%d-%d" % (k, l.chrom, x0, x1) for x0, x1, k in l.extra["blocks"])
+        elif l.svtype == "OTHER":
+            r, a = l.extra["other"]
+            info = "SVTYPE=CPLX;END=%d;Other=%s_%s_%s:%s" % (l.end, r, a, l.chrom, ":".join(str(x) for x in l.extra["bps"]))
+        else:
+            raise ValueError(l.svtype)
+        out.append("\t".join([l.chrom, str(l.start), l.svid, "N", "<%s>" % l.svtype, ".", "PASS", info, "GT", "0/1"]))
+    return "\n".join(out) + "\n"
