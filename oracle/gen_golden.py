@@ -598,6 +598,8 @@ def run_vcf(m, cli, world, tmp, header, num_reads_cff=3):
 
 
 def gen_vcf(m):
+    # the complex types (DISDUP, DUP_INV, DEL_INV, Other=) have worlds of their own, built to stay out of the
+    # reference's unseeded X-means branch: gen_complex
     cli = load_cli(m)
     m.make_event_figure_1 = lambda *a, **k: None
     tmp = tempfile.mkdtemp(prefix="vapor_golden_vcf_")
@@ -605,7 +607,6 @@ def gen_vcf(m):
     cases = []
     specs = [
         ("vcf_simple", dict(seed=81, n_loci=8, svtypes=("DEL", "INV", "INS", "TANDUP"), span_range=(120, 1200), read_len=4200, n_reads=8)),
-        ("vcf_complex", dict(seed=82, n_loci=9, svtypes=("DISDUP", "DUP_INV", "DEL_INV"), span_range=(200, 900), read_len=5200, n_reads=8)),
         ("vcf_tiny_span", dict(seed=83, n_loci=4, svtypes=("DEL", "INV"), span_range=(20, 60), read_len=1600, n_reads=6)),
     ]
     for name, kw in specs:

@@ -386,3 +386,27 @@ def test_queue_edge(eng, oracle):
     eh = np.asarray(h, dtype=np.int32).reshape(-1, 2)
     assert hits[0].tolist() == eh[np.lexsort((eh[:, 1], eh[:, 0]))].tolist()
     assert st[0, 0] >= 127 + 129 + 129
+
+
+def test_deep_loci_device_finish_vs_reference(eng):
+    """BASELINE configs[4]'s concordance leg: loci of 33-64 reads through join -> clean -> finish_kernel; per-read
+    scores, VaPoR_QS, VaPoR_GS, VaPoR_GT and VaPoR_GQ against what the reference's scorers, result_organize_ins
+    (SF:1219-1231) and gt_estimate_log_likelihood (SF:2054-2077) returned for the same reads."""
+    import deep_cases as dc
+    seqs, rows, table, n_loci = dc.build()
+    ss = eng.seqset(seqs)
+    plan = eng.plan(ss, eng.make_pairs(rows))
+    plan.set_reads(table, n_loci)
+    for _ in range(2):
+        loci = plan.run_loci(want_scores=True).copy()
+        sc = plan.read_scores[:len(table)].copy()
+        for li, c in enumerate(dc.DEEP):
+            scores, qs, gs, gt, gq = dc.expected(c)
+            got = sc[table["locus"] == li]
+            got = got[~np.isnan(got)]
+            assert got.tolist() == scores, c["name"]                   # float for float (tolerance 1e-6 not needed)
+            assert loci[li, 0] == qs and loci[li, 1] == gs, c["name"]  # np.mean's own summation order
+            assert int(loci[li, 2]) == gt and loci[li, 3] == gq, c["name"]
+            assert int(loci[li, 4]) == len(scores)
+    plan.close()
+    ss.close()

@@ -165,18 +165,11 @@ def test_vcf_records_and_table(fake, case, tmp_path):
             else:
                 gen = fns[x](3, 1, "x.bam", "ref.fa", y, "f.png")
             if "error" in p["scores"]:
-                if p["scores"]["error"] == "AttributeError":
-                    continue        # the reference died in the unseeded X-means branch (scipy.std)
                 with pytest.raises(Exception) as ei:
                     pipeline.run_sync(gen)
                 assert type(ei.value).__name__ == p["scores"]["error"]
             else:
-                try:
-                    got = pipeline.run_sync(gen)
-                except Exception:
-                    if x == "DUP_INV":
-                        continue    # X-means branch taken on this run only (unseeded in both worlds)
-                    raise
+                got = pipeline.run_sync(gen)
                 assert [float(v) for v in got] == [float(v) for v in p["scores"]["ok"]], (x, y)
     if not clean:
         return
@@ -473,3 +466,34 @@ def test_queue_edge_case_design():
     read, allele, km = queue_case.build()
     assert queue_case.candidate_totals(read, allele)[:9] == [127, 0, 0, 0, 129, 0, 0, 0, 129]
     assert allele.count(km["P"]) == 2 and allele.count(km["Q"]) == 3 and allele.count(km["R"]) == 3
+
+
+def test_deep_loci_host_finish_vs_reference(oracle):
+    """The 33-64-read loci of tests/golden/deep_loci.json.gz: oracle statistics -> host finish (vapor_amd.finish)
+    == the reference's per-read scores, result_organize_ins and gt_estimate_log_likelihood."""
+    import deep_cases as dc
+    from vapor_amd import finish
+    seqs, rows, table, _n = dc.build()
+    fe = FakeEngine(oracle)
+    st = fe.score(fe.seqset(seqs), fe.make_pairs(rows))
+    fin = {0: None, 1: finish.score_abs_dis_m1b, 3: finish.score_directed_dis_m1b_redefine_diagnal}
+    for li, c in enumerate(dc.DEEP):
+        scores, qs, gs, gt, gq = dc.expected(c)
+        got = []
+        for r in np.flatnonzero(table["locus"] == li):
+            a, b, lr, la = st[2 * r], st[2 * r + 1], int(table["len_ref"][r]), int(table["len_alt"][r])
+            if table["kind"][r] == 0:
+                x, y = finish.score_abs_dis_m1b(a, b, lr, la), finish.score_within_10Perc_m1b(a, b, lr, la)
+                if 0 not in x and 0 not in y:
+                    got.append(min([1 - float(x[1]) / float(x[0]), 1 - float(y[1]) / float(y[0])]))
+                elif 0 not in x:
+                    got.append(1 - float(x[1]) / float(x[0]))
+                elif 0 not in y:
+                    got.append(1 - float(y[1]) / float(y[0]))
+            else:
+                x = fin[int(table["kind"][r])](a, b, lr, la)
+                if 0 not in x:
+                    got.append(1 - float(x[1]) / float(x[0]))
+        assert got == scores, c["name"]
+        s_qs, s_gs, idx, s_gq = finish.locus_summary(got)
+        assert (float(s_qs), float(s_gs), idx, float(s_gq)) == (qs, gs, gt, gq), c["name"]
