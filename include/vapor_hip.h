@@ -164,15 +164,23 @@ int vapor_plan_set_reads(vapor_plan* plan, int64_t n_reads, const vapor_read* re
  * before it is synchronised; loci_out / read_scores: host copies (may be NULL; a skipped read is NaN). */
 int vapor_plan_run_loci(vapor_plan* plan, void* d_loci_out, double* loci_out, double* read_scores);
 /*
- * The same run without a host round trip per step.  vapor_set_stream makes the library enqueue on the caller's
- * HIP stream (NULL: back to its own), so that a framework's collectives and these kernels order themselves.
- * vapor_plan_run_loci_async only enqueues join -> clean -> finish (with 64 steps in flight it waits for them first; the plan must
- * have run once through vapor_plan_run_loci, which sizes the record slots); vapor_plan_sync waits, makes
- * vapor_plan_timings report the averages over those steps, copies the last step's records to loci_out (may be
- * NULL) and returns VAPOR_E_OVERFLOW if a pair outgrew its slot in one of them.
+ * The same run without a host round trip per step.  vapor_plan_run_loci_async only enqueues join -> clean -> finish
+ * (with 64 steps in flight it waits for them first; the plan must have run once through vapor_plan_run_loci, which
+ * sizes the record slots); vapor_plan_sync waits, makes vapor_plan_timings report the averages over those steps,
+ * copies the last step's records to loci_out (may be NULL) and returns VAPOR_E_OVERFLOW if a pair outgrew its slot
+ * in one of them.
+ * Streams: every plan keeps to one of two streams the context owns, dealt out in turn, so the steps of two plans in
+ * flight overlap on the device (a caller that works through a sequence of batches gets this by keeping two plans
+ * alive: the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage).  vapor_plan_then makes a
+ * stream of the caller's wait, on the device, for the plan's most recently enqueued step (e.g. before a
+ * collective that reads d_loci_out); vapor_plan_after makes the plan's next step wait for what the caller has
+ * enqueued on its stream so far (before d_loci_out is overwritten).  vapor_set_stream makes the library enqueue
+ * everything on the caller's HIP stream instead (NULL: back to its own streams).
  */
 int vapor_set_stream(vapor_ctx* ctx, void* hip_stream);
 int vapor_plan_run_loci_async(vapor_plan* plan, void* d_loci_out);
+int vapor_plan_then(vapor_plan* plan, void* hip_stream);
+int vapor_plan_after(vapor_plan* plan, void* hip_stream);
 int vapor_plan_sync(vapor_plan* plan, double* loci_out);
 
 /* ---- one-shot conveniences over the above -------------------------------------------------- */

@@ -34,7 +34,7 @@ EXPORTS = [
     "vapor_seqset_create", "vapor_seqset_create_ptrs", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_record_counts", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
-    "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync",
+    "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync", "vapor_plan_then", "vapor_plan_after",
     "vapor_cigar2alignstart",
 ]
 
@@ -78,6 +78,8 @@ def load() -> ctypes.CDLL:
     L.vapor_set_stream.argtypes = [vp, vp]
     L.vapor_plan_run_loci_async.argtypes = [vp, vp]
     L.vapor_plan_sync.argtypes = [vp, f64p]
+    L.vapor_plan_then.argtypes = [vp, vp]
+    L.vapor_plan_after.argtypes = [vp, vp]
     L.vapor_cigar2alignstart.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i64p]
     L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
     L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]

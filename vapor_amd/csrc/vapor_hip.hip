@@ -46,6 +46,13 @@ struct vapor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;          // the stream vapor_init created (vapor_set_stream may replace `stream`)
+    // vapor_plan_run_loci_async: every plan keeps to one of two library-owned streams ("lanes"), dealt out in turn, so
+    // that the steps of two plans in flight overlap (the join owns every CU's LDS while it runs; the clean and finish
+    // kernels of the other plan fill the CUs it has not reached or has already left).  A caller's stream
+    // (vapor_set_stream) replaces both.
+    hipStream_t lane[2] = {nullptr, nullptr};
+    unsigned lane_rr = 0;
+    bool user_stream = false;
     // staging for vapor_seqset_create*, kept between calls (pinned allocations are slow): ASCII chunks + chunk map
     uint8_t* h_stage = nullptr;
     uint8_t* d_stage = nullptr;
@@ -102,6 +109,10 @@ struct vapor_plan {
     int64_t acc_n = 0;
     double* h_loci = nullptr;                  // pinned copy of the per-locus records of the last async step
     hipEvent_t ev_t0 = nullptr;
+    hipStream_t lane = nullptr;                // the stream this plan's asynchronous steps are enqueued on
+    hipEvent_t ev_last = nullptr;              // end of the most recently enqueued asynchronous step
+    hipEvent_t ev_after = nullptr;             // vapor_plan_after: the next step waits for it
+    bool have_last = false, have_after = false;
     double t_join = 0, t_clean = 0, t_total = 0;
     int n_retried = 0;
     bool ran = false;
@@ -166,6 +177,8 @@ extern "C" int vapor_destroy(vapor_ctx* c)
     if (!c) return VAPOR_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    for (hipStream_t l : c->lane)
+        if (l) (void)hipStreamDestroy(l);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_stage) (void)hipFree(c->d_stage);
     delete c;
@@ -349,6 +362,8 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
     for (auto& e : p->ev_f)
         if (e) (void)hipEventDestroy(e);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
+    if (p->ev_last) (void)hipEventDestroy(p->ev_last);
+    if (p->ev_after) (void)hipEventDestroy(p->ev_after);
     delete p;
     return VAPOR_OK;
 }
@@ -523,11 +538,11 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
 }
 
 template <int BPS, int K>
-static void launch_join(vapor_plan* p, const Launch& L, bool first)
+static void launch_join(vapor_plan* p, const Launch& L, bool first, hipStream_t st)
 {
     const vapor_seqset* s = p->set;
     hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), (join_lds_bytes<JoinCfg, BPS>()),
-                       p->ctx->stream, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
+                       st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
                        p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }
 
@@ -571,10 +586,12 @@ static int clean_hcap(int range_words_cap, int want)
     return std::max(best, 0);
 }
 
-static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr)
+static int async_fold(vapor_plan* p);
+
+static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr)
 {
     vapor_ctx* c = p->ctx;
-    hipStream_t st = c->stream;
+    hipStream_t st = on ? on : c->stream;
     hipEvent_t* ev = evs ? evs : p->ev;
     // no memsets in the steady state: the pair counts are stored whole by the join, the clean kernels' two
     // counters are cleared by the first join launch
@@ -583,15 +600,15 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
     bool first = true;
     for (const Launch& L : p->launches) {
         if (L.bps == 2) {
-            if (L.k == 10) launch_join<2, 10>(p, L, first);
-            else if (L.k == 20) launch_join<2, 20>(p, L, first);
-            else if (L.k == 30) launch_join<2, 30>(p, L, first);
-            else launch_join<2, 40>(p, L, first);
+            if (L.k == 10) launch_join<2, 10>(p, L, first, st);
+            else if (L.k == 20) launch_join<2, 20>(p, L, first, st);
+            else if (L.k == 30) launch_join<2, 30>(p, L, first, st);
+            else launch_join<2, 40>(p, L, first, st);
         } else {
-            if (L.k == 10) launch_join<4, 10>(p, L, first);
-            else if (L.k == 20) launch_join<4, 20>(p, L, first);
-            else if (L.k == 30) launch_join<4, 30>(p, L, first);
-            else launch_join<4, 40>(p, L, first);
+            if (L.k == 10) launch_join<4, 10>(p, L, first, st);
+            else if (L.k == 20) launch_join<4, 20>(p, L, first, st);
+            else if (L.k == 30) launch_join<4, 30>(p, L, first, st);
+            else launch_join<4, 40>(p, L, first, st);
         }
         first = false;
         HIPCHK(hipGetLastError());
@@ -627,6 +644,10 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 {
     if (!p || (p->n_pairs && !stats)) return fail(VAPOR_E_ARG, "vapor_plan_run: null argument");
     HIPCHK(hipSetDevice(p->ctx->device));
+    if (p->ring_n > 0) {                        // asynchronous steps in flight share the workspace: let them finish
+        int rc0 = async_fold(p);
+        if (rc0 != VAPOR_OK) return rc0;
+    }
     p->n_retried = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         int rc = plan_run_once(p);
@@ -921,6 +942,10 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     if (!p) return fail(VAPOR_E_ARG, "vapor_plan_run_loci: null plan");
     if (!p->d_reads) return fail(VAPOR_E_ARG, "vapor_plan_run_loci: call vapor_plan_set_reads first");
     HIPCHK(hipSetDevice(p->ctx->device));
+    if (p->ring_n > 0) {
+        int rc0 = async_fold(p);
+        if (rc0 != VAPOR_OK) return rc0;
+    }
     hipStream_t st = p->ctx->stream;
     bool host_status = false;
     for (int64_t i = 0; i < p->n_pairs; ++i)
@@ -1012,13 +1037,31 @@ extern "C" int vapor_set_stream(vapor_ctx* c, void* hip_stream)
 {
     if (!c) return fail(VAPOR_E_ARG, "vapor_set_stream: null context");
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->user_stream = hip_stream != nullptr;
+    return VAPOR_OK;
+}
+
+// the stream a plan's asynchronous steps go to: the caller's if one is set, else the plan's lane (dealt out on first use)
+static int plan_lane(vapor_plan* p, hipStream_t* out)
+{
+    vapor_ctx* c = p->ctx;
+    if (c->user_stream) { *out = c->stream; return VAPOR_OK; }
+    if (!p->lane) {
+        const unsigned l = c->lane_rr++ & 1u;
+        if (!c->lane[l]) HIPCHK(hipStreamCreateWithFlags(&c->lane[l], hipStreamNonBlocking));
+        p->lane = c->lane[l];
+    }
+    *out = p->lane;
     return VAPOR_OK;
 }
 
 // waits for the steps in flight and adds their event times to the accumulators
 static int async_fold(vapor_plan* p)
 {
-    HIPCHK(hipStreamSynchronize(p->ctx->stream));
+    hipStream_t st = nullptr;
+    int rc = plan_lane(p, &st);
+    if (rc != VAPOR_OK) return rc;
+    HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < p->ring_n; ++i) {
         float x = 0;
         hipEvent_t* ev = p->ring[(size_t)i].data();
@@ -1044,15 +1087,22 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
         int rc0 = async_fold(p);
         if (rc0 != VAPOR_OK) return rc0;
     }
-    hipStream_t st = p->ctx->stream;
+    hipStream_t st = nullptr;
+    int rc = plan_lane(p, &st);
+    if (rc != VAPOR_OK) return rc;
     if (p->ring.empty()) {
         p->ring.resize(ASYNC_RING);
         for (auto& r : p->ring)
             for (auto& e : r) { e = nullptr; HIPCHK(hipEventCreate(&e)); }
         HIPCHK(hipHostMalloc((void**)&p->h_loci, sizeof(double) * 8 * (size_t)std::max<int64_t>(p->n_loci, 1)));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_last, hipEventDisableTiming));
+    }
+    if (p->have_after) {                        // vapor_plan_after: what the caller enqueued elsewhere comes first
+        HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
+        p->have_after = false;
     }
     hipEvent_t* ev = p->ring[(size_t)p->ring_n].data();
-    int rc = plan_run_once(p, false, ev);
+    rc = plan_run_once(p, false, ev, st);
     if (rc != VAPOR_OK) return rc;
     double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
     if (p->n_loci > 0) {
@@ -1062,7 +1112,32 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
         HIPCHK(hipMemcpyAsync(p->h_loci, d_out, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipEventRecord(ev[3], st));
+    HIPCHK(hipEventRecord(p->ev_last, st));
+    p->have_last = true;
     ++p->ring_n;
+    return VAPOR_OK;
+}
+
+// Ordering against a stream of the caller's without a host round trip (e.g. a framework's collective on its own
+// stream): vapor_plan_then makes `hip_stream` wait for the plan's most recently enqueued step (so the caller can read
+// d_loci_out there), vapor_plan_after makes the plan's NEXT step wait for everything enqueued on `hip_stream` so far
+// (so that step does not overwrite d_loci_out under the caller's feet).
+extern "C" int vapor_plan_then(vapor_plan* p, void* hip_stream)
+{
+    if (!p) return fail(VAPOR_E_ARG, "vapor_plan_then: null plan");
+    if (!p->have_last) return VAPOR_OK;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), p->ev_last, 0));
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_plan_after(vapor_plan* p, void* hip_stream)
+{
+    if (!p) return fail(VAPOR_E_ARG, "vapor_plan_after: null plan");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    if (!p->ev_after) HIPCHK(hipEventCreateWithFlags(&p->ev_after, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(p->ev_after, static_cast<hipStream_t>(hip_stream)));
+    p->have_after = true;
     return VAPOR_OK;
 }
 

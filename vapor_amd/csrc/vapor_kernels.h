@@ -740,8 +740,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             // inside every position's own branch and serialise the four lookups.  The filter bit
                             // says whether any allele k-mer shares these 17 hash bits: without it two in three
                             // candidates are mere bucket mates of nothing.
+                            // (bitwise, not `&&`: with a short-circuit the compiler sinks the filter read into the branch on
+                            // `valid` and waits for it there, one LDS round trip per position instead of one per four)
                             const uint32_t s0 = start16[h], s1v = start16[h + 1], fw = filt[fb >> 5];
-                            sc[t4] = (s0 | ((s1v - s0) << 16)) & ((valid && ((fw >> (fb & 31u)) & 1u)) ? 0xFFFFFFFFu : 0u);
+                            const uint32_t take = (uint32_t)valid & (fw >> (fb & 31u)) & 1u;
+                            sc[t4] = (s0 | ((s1v - s0) << 16)) & (0u - take);
 #ifdef VAPOR_ABL_NOCAND
                             sc[t4] &= 0xFFFFu;
 #endif

@@ -128,6 +128,14 @@ class Plan:
         """Enqueue join -> clean -> finish without waiting (after one run_loci(), which sizes the slots)."""
         L.check(L.load().vapor_plan_run_loci_async(self._h, ctypes.c_void_p(device_out) if device_out else None))
 
+    def then(self, hip_stream: int) -> None:
+        """Make `hip_stream` (a caller's stream) wait on the device for this plan's most recently enqueued step."""
+        L.check(L.load().vapor_plan_then(self._h, ctypes.c_void_p(hip_stream)))
+
+    def after(self, hip_stream: int) -> None:
+        """Make this plan's next step wait for what has been enqueued on `hip_stream` so far."""
+        L.check(L.load().vapor_plan_after(self._h, ctypes.c_void_p(hip_stream)))
+
     def sync(self, want_host: bool = True):
         """Wait for the enqueued steps; timings() then holds their averages.  Returns the last step's records."""
         L.check(L.load().vapor_plan_sync(self._h, L.ptr(self.loci, ctypes.c_double) if want_host else None))
