@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """bench.py - throughput of the recurrence-plot scoring hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic loci whose packed
-sequences and pair descriptors are already resident in HBM:
-    join kernel(s) -> clean kernel -> finish kernel (float64: per-read scores, VaPoR_QS / VaPoR_GS /
-    VaPoR_GT / VaPoR_GQ per locus) -> per-locus records to the host (N = 1) or RCCL all-gather (N > 1).
+One PASS = the hot path over one batch of synthetic loci (BASELINE.json configs[1], "cfg2": 100 DEL/TANDUP loci x 20
+reads of 10 kb x ref and alt windows of 20 kb) whose packed sequences and pair descriptors are already resident in HBM:
+    join kernel(s) -> clean kernel -> finish kernel (float64: per-read scores, VaPoR_QS / VaPoR_GS / VaPoR_GT /
+    VaPoR_GQ per locus) -> per-locus records to the host (N = 1) or RCCL all-gather (N > 1).
+One STEP = `passes_per_step` passes back to back; the number is sized by a probe before the timed region so that the
+K timed steps last about a second or more (a single pass takes 0.3 ms; K is the driver's).  Two plans over the same
+batch are kept in flight and alternate (the library runs each plan on one of its two streams), so the clean and finish
+kernels of one pass fill the CUs the next pass's join has not reached or has already left.
 Weak scaling: every rank processes its own batch of the same shape.
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is measured live with HIP
-events on the library's own stream (vapor_plan_timings); `cpu_baseline` times the CPU oracle
-(oracle/, a restatement: kind "port") on a bounded sample of the same pairs, 1 thread.
+Prints ONE JSON line on rank 0.  `value` is the resident-kernel rate (inputs in HBM, window size fixed at 10);
+`inclusive` next to it is the rate when every batch also pays upload + packing, planning and the self dot plots of
+window_size_refine (SF:2030-2046), `sub` repeats the resident measurement on BASELINE configs[2] ("cfg3").
+`roofline` is measured live with HIP events on the library's streams (vapor_plan_timings); `cpu_baseline` times the
+CPU oracle (oracle/, a restatement: kind "port") on a bounded sample of the same pairs, 1 thread.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -27,18 +34,80 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def _load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+class Resident:
+    """A batch resident in HBM with `n_plans` plans over it; pass i runs on plan i % n_plans."""
+
+    def __init__(self, eng, w, wl, n_plans, torch, dist, world, coll_stream):
+        self.w, self.torch, self.dist, self.world, self.coll = w, torch, dist, world, coll_stream
+        t0 = time.perf_counter()
+        self.ss = eng.seqset(w.seqs)
+        self.upload_s = time.perf_counter() - t0
+        self.plans, self.rec = [], []
+        for _ in range(n_plans):
+            p = eng.plan(self.ss, w.pairs)
+            p.set_reads(wl.read_table(w), w.n_loci)
+            self.plans.append(p)
+            self.rec.append(torch.empty((w.n_loci, 8), dtype=torch.float64, device="cuda"))
+        self.gathered = None
+        self.i = 0
+        # one blocking run per plan sizes the record slots (reruns pairs that overflow their first guess); its
+        # kernel times are those of the kernels running alone
+        for p, r in zip(self.plans, self.rec):
+            p.run_loci(device_out=r.data_ptr(), want_host=False)
+        self.alone = self.plans[0].timings()
+
+    def one_pass(self):
+        k = self.i % len(self.plans)
+        self.i += 1
+        p, r = self.plans[k], self.rec[k]
+        p.run_loci_async(device_out=r.data_ptr())       # join -> clean -> finish enqueued, no host round trip
+        if self.dist is not None:
+            # the collective runs on torch's stream: it waits (on the device) for this pass, and the plan's next
+            # pass waits for the collective before it overwrites the records
+            p.then(self.coll.cuda_stream)
+            with self.torch.cuda.stream(self.coll):
+                out = self.torch.empty((self.world * r.shape[0], r.shape[1]), dtype=r.dtype, device=r.device)
+                self.dist.all_gather_into_tensor(out, r)
+                self.gathered = out
+            p.after(self.coll.cuda_stream)
+
+    def drain(self, want_host=False):
+        """Waits for every plan; returns (passes folded per plan, timings per plan, last records of plan 0)."""
+        out = []
+        for p in self.plans:
+            rec = p.sync(want_host=want_host)
+            out.append((p.timings(), rec.copy() if want_host else None))
+        return out
+
+    def close(self):
+        for p in self.plans:
+            p.close()
+        self.ss.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2")
-    ap.add_argument("--reads-per-task", type=int, default=0)
+    ap.add_argument("--passes-per-step", type=int, default=0, help="0: sized by a probe so that the timed region lasts >= --min-seconds")
+    ap.add_argument("--min-seconds", type=float, default=1.2)
+    ap.add_argument("--plans", type=int, default=0, help="plans in flight (0 = two when a join launch is one workgroup per CU, else one)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="plans in flight, steps alternate between them (0 = two when a join launch is one workgroup per "
-                         "CU, else one)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inclusive rate and the cfg3 sub-record")
+    ap.add_argument("--sub", default="cfg3", help="workload of the sub-record ('' = none)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -60,100 +129,71 @@ def main() -> None:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    # one explicit stream for everything timed: the library's kernels and the all-gather are enqueued on it in
-    # program order (the legacy default stream cannot be handed to the library)
-    work_stream = torch.cuda.Stream()
-    torch.cuda.set_stream(work_stream)
+    coll = torch.cuda.Stream()          # the collectives' stream; the library's kernels run on its own two streams
 
     from vapor_amd import workload as wl
     from vapor_amd.engine import Engine
 
+    eng = Engine(local)
     spec = wl.WORKLOADS[args.workload]
     w = wl.make_workload(args.workload, seed=1000 + rank, **spec)
-
-    # `--streams` lanes, each with its own context, packed sequences, plan and HIP stream; step i runs on lane
-    # i % streams.  The join owns every CU's LDS while it runs, so inside one stream the clean kernel only starts
-    # when the slowest join workgroup is done; with two lanes the clean and finish kernels of one step fill the CUs
-    # the next step's join has not reached yet or has already left.  Every step is still one complete pass of the
-    # hot path over the batch, and all K steps finish inside the timed region.
-    class Lane:
-        pass
-    lanes = []
-    upload_s = 0.0
-    # A batch whose join is a single wave of workgroups (one per CU) leaves CUs idle at its tail, which a second lane
-    # fills; a join of many waves of workgroups keeps the chip busy by itself, and a second lane would only stretch
-    # every kernel's event interval.
-    n_lanes = args.streams if args.streams > 0 else (2 if len(w.pairs) <= 64 * 256 else 1)
-    for li in range(n_lanes):
-        ln = Lane()
-        ln.stream = work_stream if li == 0 else torch.cuda.Stream()
-        ln.eng = Engine(local)
-        if args.reads_per_task:
-            ln.eng.set_param("reads_per_task", args.reads_per_task)
-        t0 = time.perf_counter()
-        ln.ss = ln.eng.seqset(w.seqs)
-        if li == 0:
-            upload_s = time.perf_counter() - t0
-        ln.plan = ln.eng.plan(ln.ss, w.pairs)
-        ln.plan.set_reads(wl.read_table(w), w.n_loci)
-        ln.rec_dev = torch.empty((w.n_loci, 8), dtype=torch.float64, device="cuda")
-        # the library enqueues on the lane's stream, so its kernels and the all-gather order themselves
-        ln.eng.set_stream(ln.stream.cuda_stream)
-        lanes.append(ln)
-    plan = lanes[0].plan
+    # A batch whose join is a single wave of workgroups (one per CU) leaves CUs idle at its tail, which the other plan's
+    # pass fills; a join of many waves of workgroups keeps the chip busy by itself.
+    n_plans = args.plans if args.plans > 0 else (2 if len(w.pairs) <= 64 * 256 else 1)
+    res = Resident(eng, w, wl, n_plans, torch, dist, world, coll)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = [None]
+    # probe: how many passes make a step long enough
+    for _ in range(2 * n_plans):
+        res.one_pass()
+    res.drain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_probe = 40
+    for _ in range(n_probe):
+        res.one_pass()
+    torch.cuda.synchronize()
+    t_pass = (time.perf_counter() - t0) / n_probe
+    res.drain()
+    inner = args.passes_per_step if args.passes_per_step > 0 else max(1, math.ceil(args.min_seconds / (max(args.steps, 1) * t_pass)))
+    if dist is not None:
+        t = torch.tensor([inner], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # every rank runs the same number of passes
+        inner = int(t.item())
 
-    def gather(ln):
-        if dist is not None:
-            out = torch.empty((world * ln.rec_dev.shape[0], ln.rec_dev.shape[1]), dtype=ln.rec_dev.dtype, device=ln.rec_dev.device)
-            dist.all_gather_into_tensor(out, ln.rec_dev)
-            gathered[0] = out
+    def step():
+        for _ in range(inner):
+            res.one_pass()
 
-    def step(i):
-        # join -> clean -> finish enqueued without a host round trip: records to rec_dev and (pinned, async) to the host
-        ln = lanes[i % len(lanes)]
-        with torch.cuda.stream(ln.stream):
-            ln.plan.run_loci_async(device_out=ln.rec_dev.data_ptr())
-            gather(ln)
-
-    # one blocking run per lane sizes the record slots (reruns pairs that overflow their first guess); its kernel
-    # times are those of the kernels running alone
-    for ln in lanes:
-        with torch.cuda.stream(ln.stream):
-            ln.plan.run_loci(device_out=ln.rec_dev.data_ptr(), want_host=False)
-    alone = plan.timings()
-    for i in range(args.warmup):
-        step(i)
-    for ln in lanes:
-        ln.plan.sync(want_host=False)
+    for _ in range(args.warmup):
+        step()
+    res.drain()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
-    join_ms = clean_ms = dev_ms = fin_ms = 0.0
-    for li, ln in enumerate(lanes):
-        rec = ln.plan.sync()            # waits (nothing left), averages the lane's per-step HIP events
-        n_l = len(range(li, args.steps, len(lanes)))
-        tm = ln.plan.timings()
-        join_ms += tm["join_ms"] * n_l; clean_ms += tm["clean_ms"] * n_l
-        dev_ms += tm["total_ms"] * n_l; fin_ms += tm["finish_ms"] * n_l
-        if dist is None and li == (args.steps - 1) % len(lanes):
-            gathered[0] = rec.copy()
+    tm = res.drain(want_host=True)
+    n_passes = args.steps * inner
+    # every plan ran n_passes / n_plans passes (+-1); its timings are averages over them
+    wts = [len(range(k, n_passes, n_plans)) for k in range(n_plans)]
+    avg = {key: sum(t[0][key] * wt for t, wt in zip(tm, wts)) / max(sum(wts), 1) for key in ("join_ms", "clean_ms", "total_ms", "finish_ms")}
+    last_rec = tm[(n_passes - 1) % n_plans][1]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if res.gathered is not None:
+            last_rec = res.gathered.cpu().numpy()
 
     # untimed: per-pair statistics once, for the algorithmic byte count and the oracle cross-check; and the
     # host-side finish on the same statistics must agree with what the device produced
+    plan = res.plans[0]
     st = plan.run().copy()
     host_rec = wl.finish_workload(w, st)
     dev_rec = plan.run_loci().copy()
@@ -161,53 +201,36 @@ def main() -> None:
     assert np.array_equal(np.isnan(dev_rec[:, 0]), ~ok) and np.array_equal(dev_rec[ok, 2], host_rec[ok, 2]) \
         and np.allclose(dev_rec[ok, :2], host_rec[ok, :2], rtol=0, atol=1e-9), "device / host finish mismatch"
     alg_bytes, cells = plan.algorithmic()
+    n_rec = int(plan.record_counts().sum())
     n_pairs = len(w.pairs)
-    steps = max(args.steps, 1)
-    join_avg, clean_avg = join_ms / steps, clean_ms / steps
     launches = plan.timings()["join_launches"]
-    ms_per_step = elapsed / steps * 1e3
-    loci_s = w.n_loci * world * steps / elapsed
-    cells_s = cells * world * steps / elapsed
-    # the dominant kernel is the one that takes longest when it runs alone (with two lanes the other kernels' event
-    # intervals include waiting for CUs the join holds); its duration is the live average over the timed steps
-    dom = "join_kernel" if alone["join_ms"] >= alone["clean_ms"] else "clean_kernel"
-    dom_ms = join_avg if dom == "join_kernel" else clean_avg
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+    loci_s = w.n_loci * world * n_passes / elapsed
+    cells_s = cells * world * n_passes / elapsed
+    # the dominant kernel is the one that takes longest when it runs alone (with two plans in flight the other kernels'
+    # event intervals include waiting for CUs the join holds); its duration is the live average over the timed passes
+    dom = "join_kernel" if res.alone["join_ms"] >= res.alone["clean_ms"] else "clean_kernel"
+    dom_ms = avg["join_ms"] if dom == "join_kernel" else avg["clean_ms"]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # counter passes of this same workload and build, committed under profiles/ (byte and instruction counts depend on
+    # the batch and the code, not on the run): fabric-side bytes per launch and what the counters say binds
+    traffic = util = None
+    tj = _load_json("r02_%s_traffic.json" % args.workload) or _load_json("r01_%s_traffic.json" % args.workload)
+    if tj and dom in tj:
+        traffic = int(tj[dom]["bytes"])
+    uj = _load_json("r02_%s_util.json" % args.workload)
+    if uj and dom in uj:
+        util = uj[dom]
 
-    # HBM-side bytes of the dominant kernel per launch, from the committed PMC passes of this same workload
-    # (the byte counts depend on the batch only, not on the run)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % args.workload)
-    if os.path.exists(tpath):
-        try:
-            traffic = int(json.load(open(tpath))[dom]["bytes"])
-        except Exception:
-            traffic = None
-
+    extras = {}
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:       # reported at N = 1 only
-        from oracle import oracle as orc
-        orc.build()
-        done = 0
-        c_cells = 0
-        t0 = time.perf_counter()
-        while done < n_pairs and time.perf_counter() - t0 < args.cpu_seconds:
-            p = w.pairs[done]
-            exp = orc.pair_stats(int(p["k"]), w.seqs[p["seq1"]], w.seqs[p["seq2"]][int(p["off2"]):])
-            if not int(p["flags"]) & 1:
-                exp[3] = exp[4] = 0
-            if not int(p["flags"]) & 2:
-                exp[5] = exp[6] = exp[9] = 0
-            assert exp[:10].tolist() == st[done, :10].tolist(), "GPU/oracle mismatch on pair %d" % done
-            c_cells += len(w.seqs[p["seq1"]]) * (len(w.seqs[p["seq2"]]) - int(p["off2"]))
-            done += 1
-        ct = time.perf_counter() - t0
-        pairs_per_locus = n_pairs / w.n_loci
-        cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "kind": "port",
-               "sample": "first %d of %d (read, allele) dot plots of the same batch (fill + C1/C2 clean + counts, "
-                         "oracle/vapor_oracle.c, gcc -O2, 1 thread, %.1f s); each checked equal to the GPU record"
-                         % (done, n_pairs, ct),
-               "cells_per_s": round(c_cells / ct, 1)}
+    if rank == 0 and world == 1:
+        if not args.no_extras:
+            extras["inclusive"] = inclusive_rate(eng, w, wl)
+            if args.sub and args.sub != args.workload:
+                extras["sub"] = sub_record(eng, wl, args.sub, torch)
+        if not args.no_cpu:
+            cpu = cpu_baseline(w, st, n_pairs, args.cpu_seconds)
 
     if rank == 0:
         out = {
@@ -223,26 +246,137 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d loci/GPU x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s"
+            "config": {"workload": "%s: %d loci/GPU x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s; resident in HBM"
                                    % (args.workload, w.n_loci, spec["reads_per_locus"], spec["read_len"],
                                       spec["allele_len"], "/".join(sorted(set(w.svtypes)))),
-                       "pairs_per_step_per_gpu": n_pairs, "parallelism": "loci sharded over %d GPU(s)" % world},
+                       "pairs_per_pass_per_gpu": n_pairs, "passes_per_step": inner, "plans_in_flight": n_plans,
+                       "parallelism": "loci sharded over %d GPU(s)" % world},
+            "timed_region_s": round(elapsed, 4),
+            "ms_per_pass": round(elapsed / n_passes * 1e3, 5),
             "cells_per_s": round(cells_s, 1),
-            "hits_per_step": int(st[:, 0].sum()),
-            "loci_with_scores": int(np.isfinite(gathered[0].reshape(-1, 8)[:, 0].cpu().numpy() if hasattr(gathered[0], "cpu")
-                                                else gathered[0][:, 0]).sum()),
-            "kernel_ms": {"join": round(join_avg, 4), "clean": round(clean_avg, 4), "finish": round(fin_ms / steps, 4),
-                          "device_total": round(dev_ms / steps, 4), "join_launches": launches, "streams": len(lanes),
-                          "alone": {"join": round(alone["join_ms"], 4), "clean": round(alone["clean_ms"], 4)}},
-            "upload_pack_s": round(upload_s, 4),
+            "hits_per_pass": int(st[:, 0].sum()),
+            "records_per_pass": n_rec,
+            "loci_with_scores": int(np.isfinite(np.asarray(last_rec).reshape(-1, 8)[:, 0]).sum()),
+            "kernel_ms": {"join": round(avg["join_ms"], 4), "clean": round(avg["clean_ms"], 4), "finish": round(avg["finish_ms"], 4),
+                          "device_total": round(avg["total_ms"], 4), "join_launches": launches,
+                          "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)}},
+            "upload_pack_s": round(res.upload_s, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         # what the kernel really moves and what really limits it
+                         "record_bytes_per_launch": 8 * n_rec,
+                         "traffic_gbs": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic and dom_ms > 0 else None,
+                         "traffic_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and dom_ms > 0 else None,
+                         "binds": util},
             "cpu_baseline": cpu,
         }
+        out.update(extras)
         print(json.dumps(out))
+    res.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def inclusive_rate(eng, w, wl, reps: int = 6):
+    """Everything a fresh batch costs: upload + packing of the ASCII, the self dot plots window_size_refine looks at
+    (k = 10, every ref and alt window), planning, join -> clean -> finish, records back on the host."""
+    from vapor_amd import _lib as L
+    n_alleles = 2 * w.n_loci
+    allele_idx = sorted(set(int(x) for x in w.pairs["seq2"]))
+    selfp = np.zeros(len(allele_idx), dtype=L.PAIR_DTYPE)
+    selfp["seq1"] = selfp["seq2"] = allele_idx
+    selfp["k"] = 10
+    table = wl.read_table(w)
+    times, parts = [], np.zeros(4)
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        ss = eng.seqset(w.seqs)
+        t1 = time.perf_counter()
+        pw = eng.plan(ss, selfp)
+        stw = pw.run()
+        assert int(stw[:, 15].min()) == 0 and int(stw[:, 0].min()) > 0
+        t2 = time.perf_counter()
+        p = eng.plan(ss, w.pairs)
+        p.set_reads(table, w.n_loci)
+        t3 = time.perf_counter()
+        rec = p.run_loci()
+        t4 = time.perf_counter()
+        pw.close(); p.close(); ss.close()
+        if r:                                   # the first repetition warms allocators up
+            times.append(t4 - t0)
+            parts += (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+    t = float(np.median(times))
+    return {"value": round(w.n_loci / t, 2), "unit": "loci/s", "ms_per_batch": round(t * 1e3, 3),
+            "ms": dict(zip(("upload_pack", "window_selfplots", "plan", "join_clean_finish"), [round(x / reps * 1e3, 3) for x in parts])),
+            "includes": "host ASCII -> pinned staging -> H2D -> pack_kernel; %d self dot plots (k = 10) for window_size_refine's "
+                        "integer part; vapor_plan_create + set_reads; one blocking join -> clean -> finish; records to host. "
+                        "Median of %d batches, one at a time" % (len(allele_idx), reps)}
+
+
+def sub_record(eng, wl, name, torch, passes: int = 12):
+    """The resident measurement on another BASELINE shape, same build, same run."""
+    spec = wl.WORKLOADS[name]
+    w = wl.make_workload(name, seed=3000, **spec)
+    ss = eng.seqset(w.seqs)
+    p = eng.plan(ss, w.pairs)
+    p.set_reads(wl.read_table(w), w.n_loci)
+    p.run_loci(want_host=False)
+    for _ in range(2):
+        p.run_loci_async()
+    p.sync(want_host=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        p.run_loci_async()
+    p.sync(want_host=False)
+    dt = time.perf_counter() - t0
+    tm = p.timings()
+    p.run()
+    alg, cells = p.algorithmic()
+    out = {"workload": "%s: %d loci x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s; resident in HBM"
+                       % (name, w.n_loci, spec["reads_per_locus"], spec["read_len"], spec["allele_len"], "/".join(sorted(set(w.svtypes)))),
+           "value": round(w.n_loci * passes / dt, 2), "unit": "loci/s", "passes": passes, "ms_per_pass": round(dt / passes * 1e3, 4),
+           "cells_per_s": round(cells * passes / dt, 1),
+           "kernel_ms": {"join": round(tm["join_ms"], 4), "clean": round(tm["clean_ms"], 4), "finish": round(tm["finish_ms"], 4)},
+           "roofline_frac": round(alg / (tm["join_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    p.close(); ss.close()
+    return out
+
+
+def cpu_baseline(w, st, n_pairs, seconds):
+    from oracle import oracle as orc
+    orc.build()
+    done = 0
+    c_cells = 0
+    t0 = time.perf_counter()
+    while done < n_pairs and time.perf_counter() - t0 < seconds:
+        p = w.pairs[done]
+        exp = orc.pair_stats(int(p["k"]), w.seqs[p["seq1"]], w.seqs[p["seq2"]][int(p["off2"]):])
+        if not int(p["flags"]) & 1:
+            exp[3] = exp[4] = 0
+        if not int(p["flags"]) & 2:
+            exp[5] = exp[6] = exp[9] = 0
+        assert exp[:10].tolist() == st[done, :10].tolist(), "GPU/oracle mismatch on pair %d" % done
+        c_cells += len(w.seqs[p["seq1"]]) * (len(w.seqs[p["seq2"]]) - int(p["off2"]))
+        done += 1
+    ct = time.perf_counter() - t0
+    pairs_per_locus = n_pairs / w.n_loci
+    cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "kind": "port",
+           "sample": "first %d of %d (read, allele) dot plots of the same batch (fill + C1/C2 clean + counts, "
+                     "oracle/vapor_oracle.c, gcc -O2, 1 thread, %.1f s); each checked equal to the GPU record"
+                     % (done, n_pairs, ct),
+           "cells_per_s": round(c_cells / ct, 1)}
+    rj = _load_json("r02_cpu_ratio.json")
+    if rj:
+        # the reference itself cannot travel to the GPU box: its rate relative to this port was measured in the
+        # development container on the same shape (tools/cpu_ratio.py)
+        cpu["reference"] = {"port_over_reference_cython": round(rj["port_over_reference_cython"], 1),
+                            "port_over_reference_python": round(rj["port_over_reference_python"], 1),
+                            "reference_cython_loci_per_s_there": round(rj["reference_cython_loci_per_s"], 4),
+                            "estimated_reference_cython_loci_per_s_here": round(cpu["value"] / rj["port_over_reference_cython"], 4),
+                            "provenance": "profiles/r02_cpu_ratio.json: " + rj["note"] + "; " + rj["shape"]}
+    return cpu
 
 
 if __name__ == "__main__":

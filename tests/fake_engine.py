@@ -7,10 +7,15 @@ import numpy as np
 from vapor_amd import _lib as L
 
 
+_VALID = set("ACGTNRYSWKMBDHVacgtnryswkmbdhv")       # what pack_kernel's sym_code accepts (IUPAC folds to N, SF:908-949)
+
+
 class _SeqSet:
     def __init__(self, seqs, upper):
         self.seqs = [s.upper() if u else s for s, u in zip(seqs, upper)]
         self.n = len(seqs)
+        self.lens = np.array([len(s) for s in self.seqs], dtype=np.int32)
+        self.n_invalid = np.array([sum(1 for ch in set(s) if ch not in _VALID) for s in self.seqs], dtype=np.int32)
 
     def close(self):
         pass
@@ -54,6 +59,30 @@ class _Plan:
             self.stats[t] = row
             self._hits[t] = h
         return self.stats[:self.n]
+
+    def set_reads(self, reads, n_loci):
+        self.reads, self.n_loci = reads, n_loci
+        self.read_scores = np.zeros(max(len(reads), 1), dtype=np.float64)
+
+    def run_loci(self, device_out=0, want_host=True, want_scores=False):
+        """The per-read reduction finish_kernel does on the device, with the host functions of vapor_amd.finish
+        (which restate SF:182-294 and are themselves checked against the reference's vectors)."""
+        from vapor_amd import finish
+        st = self.run()
+        fn = {1: finish.score_abs_dis_m1b, 2: finish.score_within_10Perc_m1b, 3: finish.score_directed_dis_m1b_redefine_diagnal}
+
+        def ratio(ab):
+            return None if 0 in ab else 1 - float(ab[1]) / float(ab[0])
+        for t, r in enumerate(self.reads):
+            lr, la = int(r["len_ref"]), int(r["len_alt"])
+            if int(r["kind"]) == 0:
+                s1 = ratio(finish.score_abs_dis_m1b(st[r["ref_a"]], st[r["alt_a"]], lr, la))
+                s2 = ratio(finish.score_within_10Perc_m1b(st[r["ref_b"]], st[r["alt_b"]], lr, la))
+                v = min([s1, s2]) if s1 is not None and s2 is not None else s1 if s1 is not None else s2
+            else:
+                v = ratio(fn[int(r["kind"])](st[r["ref_a"]], st[r["alt_a"]], lr, la))
+            self.read_scores[t] = np.nan if v is None else v
+        return None
 
     def fetch_hits(self, idx, want_flags=True):
         idx = list(idx)

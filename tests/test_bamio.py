@@ -1,0 +1,203 @@
+"""vapor_amd.bamio (the default BAM backend) against bytes and rules it did not produce itself:
+  * its BGZF blocks decoded by Python's gzip module (an independent inflater and member parser);
+  * reg2bin / reg2bins against a brute-force walk of the UCSC bin hierarchy the SAM specification (5.3) defines;
+  * records parsed from a BAM + BAI that THIS FILE encodes from the specification's field tables (BAM 4.2, BAI 5.2),
+    one BGZF block per record at another compression level, with aux fields, an unmapped read, several references
+    and a read of more than 65535 CIGAR operations stored the CG:B,I way (4.2.2);
+  * the linear-index rule: a region query never starts before the window's recorded offset and finds every overlap.
+CPU only; no third-party BAM exists in this environment."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from vapor_amd import bamio, seqio, synth
+
+
+def test_bgzf_blocks_are_gzip_members(tmp_path):
+    rng = np.random.default_rng(3)
+    refs = [("c1", 30000)]
+    recs = [("r%d" % i, 0, int(rng.integers(0, 25000)), "%dM" % n, synth.random_dna(rng, n))
+            for i, n in enumerate(rng.integers(50, 2000, 40))]
+    path = str(tmp_path / "a.bam")
+    bamio.write_bam(path, refs, recs, block_size=3000)
+    raw = gzip.open(path, "rb").read()                      # every BGZF block is a complete gzip member
+    cur = bamio.BgzfReader(path).read_from(0)
+    assert cur.read(len(raw) + 10) == raw
+    assert raw[:4] == b"BAM\x01"
+
+
+def _bins_brute(beg, end):
+    """All bins of the 6-level hierarchy (512 Mb down to 16 kb) whose interval overlaps [beg, end), and the
+    smallest one that contains it."""
+    out, smallest = [], 0
+    first = 0
+    for level in range(6):
+        size = 1 << (29 - 3 * level)
+        n = 1 << (3 * level)
+        for k in range(beg // size, min((end - 1) // size, n - 1) + 1):
+            out.append(first + k)
+        if beg // size == (end - 1) // size:
+            smallest = first + beg // size
+        first += n
+    return sorted(out), smallest
+
+
+def test_reg2bin_and_reg2bins_against_the_hierarchy():
+    rng = np.random.default_rng(8)
+    assert bamio.reg2bin(0, 1) == 4681 and bamio.reg2bin(16384, 16385) == 4682 and bamio.reg2bin(0, 16385) == 585
+    assert bamio.reg2bin(0, 1 << 29) == 0 and bamio.reg2bin((1 << 26) - 1, (1 << 26) + 1) == 0
+    for _ in range(3000):
+        beg = int(rng.integers(0, (1 << 29) - 2))
+        end = beg + int(rng.choice([1, 2, 100, 16384, 20000, 1 << 17, 1 << 20, 1 << 24]))
+        end = min(end, 1 << 29)
+        bins, smallest = _bins_brute(beg, end)
+        assert sorted(bamio.reg2bins(beg, end)) == bins
+        assert bamio.reg2bin(beg, end) == smallest
+
+
+# ---- a second encoder, straight from the specification's tables -------------------------------------------------
+_NT16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_OPS = "MIDNSHP=X"
+
+
+def _member(data, level):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = c.compress(data) + c.flush()
+    total = 18 + len(body) + 8
+    return (struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, 6) + b"BC" + struct.pack("<HH", 2, total - 1) + body
+            + struct.pack("<II", zlib.crc32(data), len(data)))
+
+
+def _encode_bam(path, refs, reads):
+    """reads: (qname, tid, pos0, [(len, op)...], seq, aux bytes); tid -1 = unmapped.  One BGZF block per record."""
+    text = b"@HD\tVN:1.6\tSO:coordinate\n"
+    head = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for name, ln in refs:
+        head += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln)
+    out = bytearray(_member(head, 1))
+    index = [dict() for _ in refs]
+    linear = [dict() for _ in refs]
+    for qname, tid, pos, ops, seq, aux in reads:
+        rlen = sum(n for n, o in ops if o in "MDN=X") or 1
+        cig = [(n << 4) | _OPS.index(o) for n, o in ops]
+        if len(cig) > 65535:
+            aux = aux + b"CGBI" + struct.pack("<i", len(cig)) + b"".join(struct.pack("<I", c) for c in cig)
+            cig = [(len(seq) << 4) | 4, (rlen << 4) | 3]
+        sq = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            sq[i // 2] |= _NT16[ch] << (0 if i & 1 else 4)
+        b = bamio.reg2bin(pos, pos + rlen) if tid >= 0 else 4680
+        rec = struct.pack("<iiBBHHHiiii", tid, pos, len(qname) + 1, 30, b, len(cig), 4 if tid < 0 else 0, len(seq), -1, -1, 0)
+        rec += qname.encode() + b"\0" + b"".join(struct.pack("<I", c) for c in cig) + bytes(sq) + b"\x20" * len(seq) + aux
+        v0 = len(out) << 16
+        out += _member(struct.pack("<i", len(rec)) + rec, 9)
+        v1 = len(out) << 16
+        if tid >= 0:
+            index[tid].setdefault(b, []).append((v0, v1))
+            for wdw in range(pos >> 14, ((pos + rlen - 1) >> 14) + 1):
+                linear[tid].setdefault(wdw, v0)
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    open(path, "wb").write(bytes(out))
+    bai = b"BAI\x01" + struct.pack("<i", len(refs))
+    for t in range(len(refs)):
+        bai += struct.pack("<i", len(index[t]))
+        for b, ch in index[t].items():
+            bai += struct.pack("<Ii", b, len(ch)) + b"".join(struct.pack("<QQ", *c) for c in ch)
+        n = (max(linear[t]) + 1) if linear[t] else 0
+        lin, last = [], 0
+        for wdw in range(n):
+            last = linear[t].get(wdw, last)
+            lin.append(last)
+        bai += struct.pack("<i", n) + b"".join(struct.pack("<Q", v) for v in lin)
+    open(path + ".bai", "wb").write(bai)
+
+
+def _cigar_text(ops):
+    return "".join("%d%s" % (n, o) for n, o in ops)
+
+
+def test_records_from_an_independent_encoder(tmp_path):
+    rng = np.random.default_rng(5)
+    refs = [("chrA", 200000), ("chrB", 90000), ("chrC", 5000)]
+    reads = []
+    for i in range(60):
+        tid = int(rng.integers(0, 2))
+        pos = int(rng.integers(0, 80000))
+        ops, seq_len = [], 0
+        for _ in range(int(rng.integers(1, 40))):
+            o = "MIDS=X"[int(rng.integers(0, 6))]
+            n = int(rng.integers(1, 300))
+            ops.append((n, o))
+            seq_len += n if o in "MIS=X" else 0
+        seq = "".join("ACGTN"[j] for j in rng.integers(0, 5, max(seq_len, 1)))
+        if seq_len == 0:
+            ops.append((1, "M"))
+        aux = b"NMC\x05" + b"RGZgrp1\0" + b"XBBs" + struct.pack("<ihh", 2, -3, 7) if i % 3 == 0 else b""
+        reads.append(("q%d" % i, tid, pos, ops, seq, aux))
+    # a read with 70000 CIGAR operations (alternating 1M 1I): the CG:B,I convention
+    n_ops = 70000
+    long_ops = [(1, "M") if j % 2 == 0 else (1, "I") for j in range(n_ops)]
+    reads.append(("qlong", 0, 1000, long_ops, "ACGT" * (n_ops // 4), b"NMC\x01"))
+    reads.append(("qun", -1, -1, [], "ACGT", b""))
+    reads.sort(key=lambda r: (r[1] if r[1] >= 0 else 1 << 30, r[2]))
+    path = str(tmp_path / "ind.bam")
+    _encode_bam(path, refs, reads)
+    raw = gzip.open(path, "rb").read()
+    assert raw[:4] == b"BAM\x01"
+    bam = bamio.BamFile(path)
+    assert bam.refs == refs
+    for chrom, a, b in (("chrA", 1, 200000), ("chrA", 1001, 1200), ("chrA", 30000, 52000), ("chrB", 500, 70000),
+                        ("chrB", 16384, 16385), ("chrC", 1, 5000), ("chrA", 36000, 36001)):
+        tid = [n for n, _ in refs].index(chrom)
+        exp = []
+        for q, t, pos, ops, seq, _aux in reads:
+            if t != tid:
+                continue
+            rlen = sum(n for n, o in ops if o in "MDN=X") or 1
+            if pos < b and pos + rlen > a - 1:
+                exp.append((q, pos + 1, _cigar_text(ops), seq))
+        got = [r[:4] for r in bam.fetch_records(chrom, a, b)]
+        assert got == exp, (chrom, a, b)
+    rec = [r for r in bam.fetch_records("chrA", 1001, 1100) if r[0] == "qlong"][0]
+    assert rec[2] == "1M1I" * (n_ops // 2) and len(rec[3]) == n_ops
+    # and the trimming code on top of the default backend sees the long read with its real CIGAR
+    seqio.set_backend(seqio.InProcessBam())
+    try:
+        got = seqio.get_backend().records(path, "chrA", 1001, 1100)
+        assert any(q == "qlong" and c.startswith("1M1I1M1I") for q, _p, c, _s in got)
+    finally:
+        seqio.set_backend(None)
+
+
+def test_own_writer_round_trips_a_long_cigar(tmp_path):
+    n_ops = 66000
+    cigar = "1M1D" * (n_ops // 2)
+    seq = "ACGT" * (n_ops // 8)
+    path = str(tmp_path / "w.bam")
+    bamio.write_bam(path, [("c", 100000)], [("long", 0, 10, cigar, seq), ("short", 0, 20, "50M", "A" * 50)])
+    got = bamio.BamFile(path).fetch_records("c", 1, 100)
+    assert [(q, p, c == (cigar if q == "long" else "50M")) for q, p, c, _s, _f in got] == [("long", 11, True), ("short", 21, True)]
+
+
+def test_linear_index_bounds_every_query(tmp_path):
+    """Reads long enough to sit in coarse bins plus many short ones: every region query returns exactly the
+    overlapping reads although it starts at the linear index' offset for its 16 kb window."""
+    rng = np.random.default_rng(12)
+    refs = [("c", 400000)]
+    recs = []
+    for i in range(300):
+        n = int(rng.choice([80, 500, 20000, 70000], p=[0.5, 0.3, 0.15, 0.05]))
+        pos = int(rng.integers(0, 400000 - n))
+        recs.append(("r%d" % i, 0, pos, "%dM" % n, "A" * min(n, 200) + "C" * max(0, n - 200)))
+    path = str(tmp_path / "l.bam")
+    bamio.write_bam(path, refs, recs, block_size=2048)
+    bam = bamio.BamFile(path)
+    order = sorted(recs, key=lambda r: (r[1], r[2]))
+    for _ in range(60):
+        a = int(rng.integers(1, 399000))
+        b = a + int(rng.choice([1, 50, 3000, 40000]))
+        exp = [r[0] for r in order if r[2] < b and r[2] + int(r[3][:-1]) > a - 1]
+        assert [r[0] for r in bam.fetch_records("c", a, b)] == exp, (a, b)

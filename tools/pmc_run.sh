@@ -4,5 +4,5 @@
 R=$GRAFT_REPO_ROOT
 TAG=$1; CTR=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --streams 1 "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extras --plans 1 --passes-per-step 1 "$@" > $R/gpurun_out/pmc_$TAG.log 2>&1
 echo "pmc $TAG rc=$?"

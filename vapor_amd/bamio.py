@@ -2,12 +2,15 @@
 
 The reference starts one samtools process per locus and BAM (SF:340); once scoring runs on the GPU
 that popen is the wall-clock floor.  This module reads BGZF/BAM and the .bai index directly and returns
-the four fields the reference uses from every SAM line (QNAME, POS, CIGAR, SEQ; SF:342-352) as text
-lines in SAM column order, so `seqio.chop_pacbio_read_by_pos` is unchanged.
+the four fields the reference uses from every SAM line (QNAME, POS, CIGAR, SEQ; SF:342-352), as records
+(`fetch_records`) or as text lines in SAM column order (`fetch_lines`).
 
-Opt-in (`seqio.set_backend(seqio.InProcessBam())` or VAPOR_BAM_BACKEND=inprocess): it follows the
-SAM/BAM specification (v1 BAM, BAI bins and linear index) and is checked against this repository's own
-BAM writer (tests), but it has not been run on third-party BAM files in this environment.
+This is the default BAM backend (`seqio.get_backend`; VAPOR_BAM_BACKEND=samtools selects the samtools binary
+instead).  It follows the SAM/BAM specification (v1 BAM incl. the CG:B,I long-CIGAR convention, BAI bins and
+linear index).  Checks (tests/test_bamio.py): its BGZF blocks against Python's gzip module, reg2bin / reg2bins
+against a brute-force walk of the bin hierarchy, records against a second, independent BAM encoder written from
+the specification in the test, and against this module's own writer.  No third-party BAM file exists in this
+environment (the reference bundles none), so it has not been run on one.
 """
 from __future__ import annotations
 
@@ -192,7 +195,29 @@ class BamFile:
         self.index = BaiIndex(bai)
 
     @staticmethod
-    def _parse(rec: bytes):
+    def _aux_cigar(rec: bytes, p: int):
+        """The real CIGAR of a record that carries more than 65535 operations: the CG:B,I tag (SAM spec 4.2.2)."""
+        n = len(rec)
+        size = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+        while p + 3 <= n:
+            tag, typ = rec[p:p + 2], chr(rec[p + 2])
+            p += 3
+            if typ in size:
+                p += size[typ]
+            elif typ in "ZH":
+                p = rec.index(b"\x00", p) + 1
+            elif typ == "B":
+                sub, cnt = chr(rec[p]), struct.unpack_from("<i", rec, p + 1)[0]
+                p += 5
+                if tag == b"CG" and sub == "I":
+                    return struct.unpack_from("<%dI" % cnt, rec, p)
+                p += cnt * size[sub]
+            else:
+                break
+        return None
+
+    @classmethod
+    def _parse(cls, rec: bytes):
         ref_id, pos, l_name, _mapq, _bin, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHi", rec, 0)
         p = 32
         name = rec[p:p + l_name - 1].decode()
@@ -201,16 +226,20 @@ class BamFile:
         p += 4 * n_cig
         nb = (l_seq + 1) // 2
         sq = rec[p:p + nb]
+        if n_cig == 2 and (cig[0] & 15) == 4 and (cig[0] >> 4) == l_seq and (cig[1] & 15) == 3:
+            real = cls._aux_cigar(rec, p + nb + l_seq)      # placeholder <l_seq>S<ref len>N: the operations are in CG
+            if real is not None:
+                cig = real
         return ref_id, pos, name, flag, cig, l_seq, sq
 
-    def fetch_lines(self, chrom: str, start: int, end: int) -> List[str]:
-        """SAM-ordered text lines (QNAME FLAG RNAME POS MAPQ CIGAR * 0 0 SEQ *) of the alignments that
-        overlap the 1-based inclusive region, in file order."""
+    def fetch_records(self, chrom: str, start: int, end: int) -> List[Tuple[str, int, str, str, int]]:
+        """(QNAME, 1-based POS, CIGAR, SEQ, FLAG) of the alignments that overlap the 1-based inclusive region, in
+        file order - what `samtools view bam chrom:start-end` lists."""
         tid = self.tid.get(chrom)
         if tid is None:
             return []
         beg, stop = max(start - 1, 0), end               # 0-based half-open
-        out: List[str] = []
+        out = []
         for cs, ce in self.index.chunks(tid, beg, stop):
             cur = self.bgzf.read_from(cs)
             while cur.tell() < ce:
@@ -228,8 +257,13 @@ class BamFile:
                     continue
                 cigar = "".join("%d%s" % (c >> 4, _CIG[c & 15]) for c in cig) or "*"
                 seq = "".join(_SEQ_LUT[b] for b in sq)[:l_seq] or "*"
-                out.append("\t".join([name, str(flag), chrom, str(pos + 1), "0", cigar, "*", "0", "0", seq, "*"]))
+                out.append((name, pos + 1, cigar, seq, flag))
         return out
+
+    def fetch_lines(self, chrom: str, start: int, end: int) -> List[str]:
+        """The same as SAM-ordered text lines (QNAME FLAG RNAME POS MAPQ CIGAR * 0 0 SEQ *)."""
+        return ["\t".join([name, str(flag), chrom, str(pos), "0", cigar, "*", "0", "0", seq, "*"])
+                for name, pos, cigar, seq, flag in self.fetch_records(chrom, start, end)]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -266,8 +300,14 @@ def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, i
         sq = bytearray((len(seq) + 1) // 2)
         for i, ch in enumerate(seq):
             sq[i >> 1] |= enc.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
-        body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname) + 1, 60, reg2bin(pos, end), len(ops), 0, len(seq), -1, -1, 0)
-        body += qname.encode() + b"\x00" + b"".join(struct.pack("<I", (n << 4) | o) for n, o in ops) + bytes(sq) + b"\xff" * len(seq)
+        packed = [(n << 4) | o for n, o in ops]
+        aux = b""
+        if len(packed) > 65535:
+            # SAM spec 4.2.2: the operations go to CG:B,I, the CIGAR field holds <l_seq>S<reference length>N
+            aux = b"CGBI" + struct.pack("<i", len(packed)) + struct.pack("<%dI" % len(packed), *packed)
+            packed = [(len(seq) << 4) | 4, (rlen << 4) | 3]
+        body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname) + 1, 60, reg2bin(pos, end), len(packed), 0, len(seq), -1, -1, 0)
+        body += qname.encode() + b"\x00" + b"".join(struct.pack("<I", c) for c in packed) + bytes(sq) + b"\xff" * len(seq) + aux
         blobs.append(struct.pack("<i", len(body)) + body)
         meta.append((tid, pos, end))
     # lay the stream out in BGZF blocks, remembering the virtual offset of every record

@@ -5,8 +5,11 @@ Each driver is a generator.  It does its host-side string work itself and *yield
 kinds of device work the reference does inline -
 
     Window(seq)                             -> window_size_refine(seq)            (SF:2030-2046)
-    Score(kind, ref_seq, alt_seq, reads, k) -> [calcu_vapor_single_read_score_*(ref, alt, x, k)
-                                                for x in reads]
+    Score(kind, ref_seq, alt_seq, reads, k) -> per read x the drivers' own reduction of
+                                               calcu_vapor_single_read_score_*(ref, alt, x, k): the score
+                                               1 - b/a, or None where the reference skips the read
+                                               (`0 in [a, b]`, e.g. SF:1913); 'del' takes the smaller of the
+                                               abs_dis and within_10Perc scores (SF:1718-1726)
 
 - and receives the results back through send().  Run one generator at a time
 (`pipeline.run_sync`) and it behaves like the reference's function of the same name; run many
@@ -16,7 +19,6 @@ where it raises (cited inline).
 """
 from __future__ import annotations
 
-import math
 from typing import List
 
 from . import seqio
@@ -34,7 +36,7 @@ class Window:
 
 class Score:
     """kind: 's1' abs_dis_m1b, 's2' within_10Perc_m1b, 's3' directed_dis_m1b_redefine_diagnal,
-    'del' = s1 and s2 for the same reads (result: (list_s1, list_s2))."""
+    'del' = s1 and s2 for the same reads.  Result: one score (float) or None per read."""
     __slots__ = ("kind", "ref_seq", "alt_seq", "reads", "k")
 
     def __init__(self, kind, ref_seq, alt_seq, reads, k):
@@ -50,24 +52,20 @@ class Figure:
         self.ref_seq, self.alt_seq, self.name = ref_seq, alt_seq, name
 
 
-def _ratio(ab) -> float:
-    return 1 - float(ab[1]) / float(ab[0])
-
-
-def _collect(results, reads, scores: List[float], nan_guard: bool = False, keep=None):
-    """The per-read loop every driver repeats (e.g. SF:1909-1915): a read counts when neither
-    scorer output is 0; returns the read with the best score so far (ties: the later read)."""
+def _collect(results, reads, scores: List[float], keep=None):
+    """The per-read loop every driver repeats (e.g. SF:1909-1915): a read counts when neither scorer output is 0
+    (the executor hands such a read over as None, the others as 1 - b/a; the scorers never produce NaN, so
+    vapor_dup_inv_VapoR's extra isnan test, SF:1629, changes nothing); returns the read with the best score so
+    far (ties: the later read)."""
     best = ""
     it = iter(results)
     for x in reads:
         if keep is not None and not keep(x):
             continue
-        ab = next(it)
-        if 0 in ab:
+        s = next(it)
+        if s is None:
             continue
-        if nan_guard and (math.isnan(ab[0]) or math.isnan(ab[1])):
-            continue
-        scores.append(_ratio(ab))
+        scores.append(s)
         if scores[-1] == max(scores):
             best = x
     return best
@@ -94,19 +92,8 @@ def vapor_simple_del(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_nam
             k = yield from _window(ref_seq)
             if not k == "Error":
                 alt_seq = ref_seq[:flank] + ref_seq[-flank:]
-                r1, r2 = yield Score("del", ref_seq, alt_seq, reads, k)
-                best = ""
-                for x, a, b in zip(reads, r1, r2):
-                    if not 0 in a and not 0 in b:
-                        scores.append(min([_ratio(a), _ratio(b)]))
-                    elif not 0 in a:
-                        scores.append(_ratio(a))
-                    elif not 0 in b:
-                        scores.append(_ratio(b))
-                    else:
-                        continue
-                    if scores[-1] == max(scores):
-                        best = x
+                res = yield Score("del", ref_seq, alt_seq, reads, k)     # min of the two scorers' scores, SF:1718-1726
+                best = _collect(res, reads, scores)
                 yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
     else:
         reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
@@ -314,7 +301,7 @@ def vapor_dup_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
                     k = yield from _window(alt_seq)
                     if not k == "Error":
                         res = yield Score("s3", ref_seq, alt_seq, reads, k)
-                        best = _collect(res, reads, scores, nan_guard=True)
+                        best = _collect(res, reads, scores)
                         yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
         if not ran:
             short = max(bp) - min(bp) < default_max_sv_test
@@ -331,7 +318,7 @@ def vapor_dup_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
                     k = yield from _window(alt_seq)
                     if not k == "Error":
                         res = yield Score("s1" if short else "s2", ref_seq, alt_seq, reads, k)
-                        best = _collect(res, reads, scores, nan_guard=True)
+                        best = _collect(res, reads, scores)
                         yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
     return scores
 

@@ -12,7 +12,7 @@ from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib as L
-from . import finish, repeat_qc
+from . import repeat_qc
 from .drivers import Figure, Score, Window
 
 _engine = None
@@ -142,70 +142,138 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
 # scorer requests
 # ------------------------------------------------------------------------------------------
 _FLAGS = {"s1": L.PF_C1, "s2": L.PF_C2, "s3": L.PF_C1 | L.PF_DIR}
-_FINISH = {"s1": finish.score_abs_dis_m1b, "s2": finish.score_within_10Perc_m1b,
-           "s3": finish.score_directed_dis_m1b_redefine_diagnal}
+_KIND = {"del": 0, "s1": 1, "s2": 2, "s3": 3}
 
 
 def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
-    """Evaluates every Score request; result per request: list of [a, b] per read ('del':
-    (list_s1, list_s2)), or the exception the reference would raise."""
-    tab = _SeqTable()
-    rows = []
-    layout = []            # per request: list of (kind, first_row) blocks, rows = 2 per read
-    for r in reqs:
-        blocks = []
-        kinds = ["s1", "s2"] if r.kind == "del" else [r.kind]
-        merged = False
-        if r.kind == "del" and r.ref_seq.upper() == r.ref_seq and r.alt_seq.upper() == r.alt_seq:
-            merged = True                       # upper-casing changes nothing: one fill serves both
-        done_first = None
-        for kind in kinds:
-            if merged and done_first is not None:
-                blocks.append((kind, done_first))
-                continue
-            up = kind == "s1"
-            ri = tab.add(r.ref_seq, up and not merged)
-            ai = tab.add(r.alt_seq, up and not merged)
-            fl = (L.PF_C1 | L.PF_C2) if merged else _FLAGS[kind]
-            first = len(rows)
-            for x in r.reads:
-                q = tab.add(x[0])
-                rows.append((q, ri, int(x[1]), int(r.k), fl))
-                rows.append((q, ai, int(x[1]), int(r.k), fl))
-            blocks.append((kind, first))
-            done_first = first
-        layout.append(blocks)
-    if not rows:
-        return [([], []) if r.kind == "del" else [] for r in reqs]
-    ss = engine.seqset(tab.seqs, tab.upper)
-    plan = engine.plan(ss, engine.make_pairs(rows))
-    st = plan.run().copy()
-    plan.close()
-    ss.close()
-    out: List[object] = []
-    for r, blocks in zip(reqs, layout):
-        lr, la = len(r.ref_seq), len(r.alt_seq)
-        res = []
-        err = None
-        for kind, first in blocks:
-            lst = []
-            for t in range(len(r.reads)):
-                a, b = st[first + 2 * t], st[first + 2 * t + 1]
-                try:
-                    _raise_for_status(a)
-                    _raise_for_status(b)
-                    lst.append(_FINISH[kind](a, b, lr, la))
-                except Exception as e:      # noqa: BLE001
-                    err = e
-                    break
-            if err is not None:
-                break
-            res.append(lst)
-        if err is not None:
-            out.append(err)
+    """Evaluates every Score request on the device, per-read reduction included (finish_kernel): per request a list
+    with one score (float) or None per read, or the exception the reference would raise (KeyError for a read with a
+    base outside invert_base's alphabet, SF:1421).
+
+    One sequence set and one plan for all requests: request t is "locus" t of the plan, its reads are the plan's
+    reads in order.  The arrays are put together with numpy per request, not per read."""
+    seqs: List[str] = []
+    upper: List[bool] = []
+    seq1, seq2, off2, kk, flg = [], [], [], [], []           # pair columns, one array per request block
+    ra, aa, rb, ab, kind, locus, lref, lalt = [], [], [], [], [], [], [], []
+    first_read, n_pairs = [], 0
+    read_seq_first = []                                      # per request: index of its first read sequence
+    n_reads_tot = 0
+    for t, r in enumerate(reqs):
+        n = len(r.reads)
+        first_read.append(n_reads_tot)
+        if n == 0:
+            read_seq_first.append(len(seqs))
+            continue
+        # allele sequences of this request: as given, and (abs_dis_m1b, SF:183-184) upper-cased where that differs
+        ri = len(seqs)
+        seqs += [r.ref_seq, r.alt_seq]
+        upper += [False, False]
+        if r.kind in ("del", "s1") and not (_is_upper(r.ref_seq) and _is_upper(r.alt_seq)):
+            ui = len(seqs)
+            seqs += [r.ref_seq, r.alt_seq]
+            upper += [True, True]
         else:
-            out.append(tuple(res) if r.kind == "del" else res[0])
+            ui = ri
+        q0 = len(seqs)
+        read_seq_first.append(q0)
+        seqs += [x[0] for x in r.reads]
+        upper += [False] * n
+        q = np.arange(q0, q0 + n, dtype=np.int32)
+        miss = np.fromiter((int(x[1]) for x in r.reads), dtype=np.int32, count=n)
+
+        def block(allele0, fl):
+            nonlocal n_pairs
+            base = n_pairs
+            seq1.append(np.repeat(q, 2))
+            seq2.append(np.tile(np.array([allele0, allele0 + 1], dtype=np.int32), n))
+            off2.append(np.repeat(miss, 2))
+            kk.append(np.full(2 * n, int(r.k), dtype=np.int32))
+            flg.append(np.full(2 * n, fl, dtype=np.uint32))
+            n_pairs += 2 * n
+            return base + 2 * np.arange(n, dtype=np.int32)
+
+        if r.kind == "del":
+            if ui == ri:
+                pa = pb = block(ri, L.PF_C1 | L.PF_C2)       # upper-casing changes nothing: one fill serves both scorers
+            else:
+                pa = block(ui, L.PF_C1)
+                pb = block(ri, L.PF_C2)
+        else:
+            pa = pb = block(ui if r.kind == "s1" else ri, _FLAGS[r.kind])
+        ra.append(pa); aa.append(pa + 1); rb.append(pb); ab.append(pb + 1)
+        kind.append(np.full(n, _KIND[r.kind], dtype=np.int32))
+        locus.append(np.full(n, t, dtype=np.int32))
+        lref.append(np.full(n, len(r.ref_seq), dtype=np.int32))
+        lalt.append(np.full(n, len(r.alt_seq), dtype=np.int32))
+        n_reads_tot += n
+    if n_reads_tot == 0:
+        return [[] for _ in reqs]
+    pairs = np.zeros(n_pairs, dtype=L.PAIR_DTYPE)
+    for name, col in (("seq1", seq1), ("seq2", seq2), ("off2", off2), ("k", kk), ("flags", flg)):
+        pairs[name] = np.concatenate(col)
+    table = np.zeros(n_reads_tot, dtype=L.READ_DTYPE)
+    for name, col in (("ref_a", ra), ("alt_a", aa), ("ref_b", rb), ("alt_b", ab), ("kind", kind), ("locus", locus),
+                      ("len_ref", lref), ("len_alt", lalt)):
+        table[name] = np.concatenate(col)
+    ss = engine.seqset(seqs, upper)
+    try:
+        plan = engine.plan(ss, pairs)
+        try:
+            plan.set_reads(table, len(reqs))
+            plan.run_loci(want_host=False, want_scores=True)
+            sc = plan.read_scores[:n_reads_tot]
+        finally:
+            plan.close()
+        # pairs the library rejects, as the reference would have raised: a read k-mer with a base outside
+        # invert_base's alphabet (SF:1421), a sequence beyond the device's 16-bit positions
+        bad_inv = np.asarray(ss.n_invalid) > 0
+        lens = np.asarray(ss.lens)
+    finally:
+        ss.close()
+    out: List[object] = []
+    for t, r in enumerate(reqs):
+        n = len(r.reads)
+        if n == 0:
+            out.append([])
+            continue
+        q0 = read_seq_first[t]
+        if k_unsupported(r.k) or max(len(r.ref_seq), len(r.alt_seq)) > L.MAX_SEQ_LEN or int(lens[q0:q0 + n].max()) > L.MAX_SEQ_LEN:
+            out.append(ValueError("sequence longer than %d bases or unsupported window size" % L.MAX_SEQ_LEN))
+            continue
+        inv = bad_inv[q0:q0 + n] & (lens[q0:q0 + n] - int(r.k) + 1 > 0)
+        if inv.any():
+            out.append(KeyError("invert_base"))              # what SF:1421 raises on a base outside ATCGN/atcgn
+            continue
+        v = sc[first_read[t]:first_read[t] + n]
+        out.append([None if x != x else x for x in v.tolist()])
     return out
+
+
+def scorer_outputs(engine, kind: str, ref_seq: str, alt_seq: str, x, k):
+    """[a, b] of calcu_vapor_single_read_score_{abs_dis_m1b, within_10Perc_m1b, directed_dis_m1b_redefine_diagnal}
+    (kind 's1', 's2', 's3'; SF:182-203, 277-294, 241-257) for one read: the two dot plots' statistics from the
+    device, the scorer's own gates and ratios on the host in float64 (vapor_amd.finish)."""
+    from . import finish
+    up = kind == "s1"
+    ss = engine.seqset([x[0], ref_seq, alt_seq], [False, up, up])
+    try:
+        st = engine.score(ss, engine.make_pairs([(0, 1, int(x[1]), int(k), _FLAGS[kind]), (0, 2, int(x[1]), int(k), _FLAGS[kind])]))
+    finally:
+        ss.close()
+    _raise_for_status(st[0])
+    _raise_for_status(st[1])
+    fn = {"s1": finish.score_abs_dis_m1b, "s2": finish.score_within_10Perc_m1b,
+          "s3": finish.score_directed_dis_m1b_redefine_diagnal}[kind]
+    return fn(st[0], st[1], len(ref_seq), len(alt_seq))
+
+
+def _is_upper(s: str) -> bool:
+    return s.isupper() or s.upper() == s
+
+
+def k_unsupported(k) -> bool:
+    return int(k) not in (10, 20, 30, 40)
 
 
 # ------------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ class FaiFasta:
         return raw.replace(b"\n", b"").replace(b"\r", b"").decode("ascii")
 
     def lines(self, region: str) -> List[str]:
+        """`samtools faidx` text: header line, then the sequence in lines of 60."""
         chrom, _, span = region.rpartition(":")
         if not chrom:
             chrom, a, b = region, 1, self.index.get(region, (0,))[0]
@@ -106,28 +107,41 @@ class SamtoolsHybrid(SamtoolsCLI):
 
 
 class InProcessBam(SamtoolsHybrid):
-    """BAM and BAI read in-process as well (vapor_amd.bamio): no samtools process at all per locus.
-    samtools itself is then not needed."""
+    """BAM and BAI read in-process as well (vapor_amd.bamio): no process per locus at all, and the records reach
+    the trimming code as fields, not as text to be split again.  The default backend."""
 
     def __init__(self) -> None:        # noqa: D401 - does not require the samtools binary
         self.exe = None
         self._fa = {}
         self._bam = {}
 
-    def view_lines(self, bam: str, region: str) -> Iterable[str]:
+    def _open(self, bam: str):
         from . import bamio
         b = self._bam.get(bam)
         if b is None:
             b = self._bam[bam] = bamio.BamFile(bam)
+        return b
+
+    def view_lines(self, bam: str, region: str) -> Iterable[str]:
         chrom, _, span = region.rpartition(":")
         a, _, e = span.partition("-")
-        return b.fetch_lines(chrom, int(a), int(e))
+        return self._open(bam).fetch_lines(chrom, int(a), int(e))
 
-    def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
+    def records(self, bam: str, chrom: str, start: int, end: int):
+        """(QNAME, POS, CIGAR, SEQ) per alignment overlapping chrom:start-end."""
+        return [r[:4] for r in self._open(bam).fetch_records(chrom, int(start), int(end))]
+
+    def _fasta(self, ref: str) -> FaiFasta:
         fa = self._fa.get(ref)
         if fa is None:
             fa = self._fa[ref] = FaiFasta(ref)
-        return fa.lines(region)
+        return fa
+
+    def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
+        return self._fasta(ref).lines(region)
+
+    def fetch_seq(self, ref: str, chrom: str, start: int, end: int) -> str:
+        return self._fasta(ref).fetch(chrom, start, end)
 
 
 class MemorySamtools:
@@ -158,6 +172,12 @@ class MemorySamtools:
         chrom, a, b = self._region(region)
         return [r.line() for r in self.world.overlapping(chrom, a, b)]
 
+    def records(self, bam: str, chrom: str, start: int, end: int):
+        return [(r.qname, r.pos, r.cigar, r.seq) for r in self.world.overlapping(chrom, int(start), int(end))]
+
+    def fetch_seq(self, ref: str, chrom: str, start: int, end: int) -> str:
+        return self.world.fetch(chrom, start, end) if chrom in self.world.contigs else ""
+
     def isfile(self, path: str) -> bool:
         return True
 
@@ -173,13 +193,13 @@ def set_backend(b) -> None:
 def get_backend():
     global _backend
     if _backend is None:
-        # samtools for the BAM when it is installed (or asked for); otherwise the in-process reader, which
-        # raises on a missing .bai/.fai instead of returning nothing
-        want = os.environ.get("VAPOR_BAM_BACKEND", "")
-        if want == "inprocess" or (want != "samtools" and shutil.which("samtools") is None):
-            _backend = InProcessBam()
-        else:
-            _backend = SamtoolsHybrid()
+        # In-process readers (.fai, BGZF/BAM + .bai) unless samtools is asked for: no process per locus, which is the
+        # wall-clock floor once scoring runs on the GPU.  They raise on a missing .bai/.fai instead of returning nothing.
+        want = os.environ.get("VAPOR_BAM_BACKEND", "inprocess")
+        _backend = SamtoolsHybrid() if want == "samtools" else InProcessBam()
+        import sys
+        print("vapor_amd.seqio: %s backend for BAM regions (VAPOR_BAM_BACKEND=%s)"
+              % ("samtools" if want == "samtools" else "in-process BGZF/BAI", want), file=sys.stderr)
     return _backend
 
 
@@ -202,15 +222,19 @@ def reverse(seq: str) -> str:
 def ref_seq_readin(ref, chrom, start, end, reverse_flag="FALSE") -> str:
     """SF:1203-1217: `samtools faidx ref chrom:start-end`, header dropped, the first
     whitespace-separated token of every following line joined, stopping at a blank line."""
-    lines = iter(get_backend().faidx_lines(ref, "%s:%d-%d" % (chrom, int(start), int(end))))
-    next(lines, None)
-    parts: List[str] = []
-    for ln in lines:
-        tok = ln.strip().split()
-        if not tok:
-            break
-        parts.append(tok[0])
-    seq = "".join(parts)
+    be = get_backend()
+    if hasattr(be, "fetch_seq"):
+        seq = be.fetch_seq(ref, chrom, int(start), int(end))     # the same bases without the 60-column text in between
+    else:
+        lines = iter(be.faidx_lines(ref, "%s:%d-%d" % (chrom, int(start), int(end))))
+        next(lines, None)
+        parts: List[str] = []
+        for ln in lines:
+            tok = ln.strip().split()
+            if not tok:
+                break
+            parts.append(tok[0])
+        seq = "".join(parts)
     if reverse_flag == "FALSE":
         return seq
     return reverse(complementary(seq))
@@ -271,17 +295,24 @@ def cigar2alignstart_by_pos(cigar: str, align_start: int, start: int, end: int):
 def chop_pacbio_read_by_pos(bam_in_new, chrom, start, end, flank_length):
     """SF:339-354."""
     out = []
-    for line in get_backend().view_lines(bam_in_new, "%s:%d-%d" % (chrom, start, end)):
-        f = line.strip().split()
-        if not f or f[0] == "@":
-            continue
-        if int(f[3]) < start + 1:
-            q0, miss_bp = cigar2alignstart_by_pos(f[5], int(f[3]), start, end)
+    be = get_backend()
+    if hasattr(be, "records"):
+        recs = be.records(bam_in_new, chrom, start, end)
+    else:
+        recs = []
+        for line in be.view_lines(bam_in_new, "%s:%d-%d" % (chrom, start, end)):
+            f = line.strip().split()
+            if not f or f[0] == "@":
+                continue
+            recs.append((f[0], f[3], f[5], f[9]))
+    for qname, pos, cigar, seq in recs:
+        if int(pos) < start + 1:
+            q0, miss_bp = cigar2alignstart_by_pos(cigar, int(pos), start, end)
             if not miss_bp > flank_length / 2:
-                tail = f[9][q0:]
+                tail = seq[q0:]
                 want = end - start - miss_bp
                 if len(tail) > want:
-                    out.append([tail[:want], miss_bp, f[0]])
+                    out.append([tail[:want], miss_bp, qname])
     return out
 
 

@@ -74,10 +74,7 @@ def clean_dotdata_diagnal_and_anti_diagnal(ref_dotdata):
 
 
 def _one_score(kind, ref_seq, alt_seq, x, window_size):
-    r = pipeline.score_requests(pipeline.get_engine(), [drivers.Score(kind, ref_seq, alt_seq, [x], window_size)])[0]
-    if isinstance(r, BaseException):
-        raise r
-    return r[0]
+    return pipeline.scorer_outputs(pipeline.get_engine(), kind, ref_seq, alt_seq, x, window_size)
 
 
 def calcu_vapor_single_read_score_abs_dis_m1b(ref_seq, alt_seq, x, window_size):

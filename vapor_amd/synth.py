@@ -39,12 +39,14 @@ def _rle_cigar(ops: np.ndarray) -> str:
     change = np.flatnonzero(ops[1:] != ops[:-1]) + 1
     starts = np.concatenate(([0], change))
     ends = np.concatenate((change, [ops.size]))
-    return "".join("%d%s" % (e - s, chr(ops[s])) for s, e in zip(starts, ends))
+    # "<run length><op>" for every run, formatted by numpy rather than one str.__mod__ per run
+    return "".join(np.char.add((ends - starts).astype("U"), ops[starts].view("S1").astype("U")).tolist())
 
 
 def mutate(rng: np.random.Generator, seg: str, sub: float = 0.01, ins: float = 0.08,
-           dele: float = 0.04) -> Tuple[str, str]:
-    """Apply CLR-like errors to `seg`; returns (read, cigar relative to seg).
+           dele: float = 0.04, cigar: bool = True) -> Tuple[str, str]:
+    """Apply CLR-like errors to `seg`; returns (read, cigar relative to seg; "" when `cigar` is off - the random
+    stream is the same either way).
 
     The first base is always kept as a match so that POS is the first aligned base."""
     n = len(seg)
@@ -73,6 +75,8 @@ def mutate(rng: np.random.Generator, seg: str, sub: float = 0.01, ins: float = 0
     ins_pos = off[:-1] + keep.astype(np.int64)
     out[ins_pos[is_ins]] = ins_b[is_ins]
     # cigar ops: per position M or D, then I
+    if not cigar:
+        return out.tobytes().decode("ascii"), ""
     opcnt = 1 + is_ins.astype(np.int64)
     ooff = np.concatenate(([0], np.cumsum(opcnt)))
     ops = np.empty(ooff[-1], dtype=np.uint8)

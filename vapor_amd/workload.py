@@ -61,7 +61,7 @@ def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], rea
             lo = max(0, s + span + 500 - read_len)
             hi = max(lo, min(s - 200, len(hap) - read_len))
             st = int(rng.integers(lo, hi + 1))
-            rd, _c = synth.mutate(rng, hap[st:st + read_len + read_len // 8])
+            rd, _c = synth.mutate(rng, hap[st:st + read_len + read_len // 8], cigar=False)
             seqs.append(rd[:read_len])
             q = len(seqs) - 1
             rows.append((q, ri, 0, k, SCORER_FLAGS[t]))
@@ -70,9 +70,11 @@ def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], rea
             read_kind.append(kind)
             len_ref.append(len(ref))
             len_alt.append(len(alt))
-    pairs = np.zeros(len(rows), dtype=L.PAIR_DTYPE)
-    for i, r in enumerate(rows):
-        pairs[i] = r
+    pairs = np.array(rows, dtype=np.int64).view(np.int64).reshape(-1, 5)
+    pa = np.zeros(len(rows), dtype=L.PAIR_DTYPE)
+    for c, name in enumerate(("seq1", "seq2", "off2", "k", "flags")):
+        pa[name] = pairs[:, c]
+    pairs = pa
     return Workload(name, seqs, pairs, np.asarray(read_locus), np.asarray(read_kind), np.asarray(len_ref),
                     np.asarray(len_alt), n_loci, types)
 
