@@ -906,11 +906,93 @@ def gen_deep(m):
                                          "result_organize_ins SF:1219-1231, gt_estimate_log_likelihood SF:2054-2077",
                                "cases": cases})
 
+class PltRecorder:
+    """Stands in for matplotlib.pyplot inside the reference module: records what make_event_figure_1 /
+    makeDotplot_subfigure (SF:1041-1089) would draw instead of drawing it."""
+
+    def __init__(self):
+        self.figs = []
+        self.cur = None
+
+    def figure(self, n=None):
+        self.cur = {"figure": n, "subplots": [], "saved": None}
+        self.figs.append(self.cur)
+        return self.cur
+
+    def subplot(self, pos):
+        self.cur["subplots"].append({"pos": int(pos)})
+
+    def plot(self, x, y, marker, color=None):
+        sp = self.cur["subplots"][-1]
+        xa, ya = np.asarray(x, dtype=np.int32), np.asarray(y, dtype=np.int32)
+        sp.update({"n": int(len(xa)), "marker": marker, "color": color,
+                   "xy_sha256": hashlib.sha256(np.stack([xa, ya], 1).tobytes()).hexdigest(),
+                   "first": [int(xa[0]), int(ya[0])], "last": [int(xa[-1]), int(ya[-1])]})
+
+    def xticks(self, ticks, labels):
+        self.cur["subplots"][-1].update({"xticks": [float(t) for t in ticks], "xticklabels": list(labels)})
+
+    def title(self, t):
+        self.cur["subplots"][-1]["title"] = t
+
+    def grid(self, flag):
+        self.cur["subplots"][-1]["grid"] = bool(flag)
+
+    def savefig(self, name):
+        self.cur["saved"] = name
+
+    def close(self, fig):
+        pass
+
+
+def gen_figures(m):
+    """make_event_figure_1 (SF:1072-1089) as the drivers call it (vapor_vali/vapor:338 naming): the arguments of
+    every call and what it plots - the four point sets, tick lists, titles and the (clamped) file name."""
+    cli = load_cli(m)
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_fig_")
+    # (no TANDUP: its alt window always has a 1/6 - 1/4 lower-triangle share and sends the reference into its unseeded
+    # X-means, SF:1165, so its figure calls would not be reproducible)
+    w = synth.make_world(seed=171, n_loci=8, svtypes=("DEL", "INV", "INS", "DEL"), span_range=(150, 900), read_len=3000, n_reads=7)
+    xm_calls, xm_orig = _count_xmeans(m)
+    rec = PltRecorder()
+    calls = []
+    orig = m.make_event_figure_1
+
+    def wrapped(plt_li, scores, best, k, ref_seq, alt_seq, name):
+        n0 = len(rec.figs)
+        orig(plt_li, scores, best, k, ref_seq, alt_seq, name)
+        calls.append({"plt_li": plt_li, "scores": [float(s) for s in scores], "best_read": jsonable(best), "k": k,
+                      "ref_seq": ref_seq, "alt_seq": alt_seq, "name": name,
+                      "drawn": rec.figs[n0] if len(rec.figs) > n0 else None})
+    m.plt = rec
+    m.make_event_figure_1 = wrapped
+    m.os = ShimOS(w)
+    per_locus, _text = run_bed(m, cli, w, tmp)
+    m.os = os
+    # direct calls: a file name longer than 150 characters (SF:1080-1081), no best read, an empty plot
+    c0 = [c for c in calls if c["drawn"] is not None][0]
+    long_name = tmp + "/" + "s." + "DEL." + "x" * 170 + ".png"
+    for best, name in ((c0["best_read"], long_name), ("", tmp + "/none.png"), ([], tmp + "/none2.png"),
+                       (["ACGT", 0, "tiny"], tmp + "/empty.png")):
+        wrapped(99, c0["scores"], best, c0["k"], c0["ref_seq"], c0["alt_seq"], name)
+    m.make_event_figure_1 = orig
+    m.X_means_cluster_reformat = xm_orig
+    assert xm_calls[0] == 0
+    import matplotlib.pyplot as real_plt
+    m.plt = real_plt
+    for c in calls:
+        c["name"] = c["name"].replace(tmp, "<tmp>")
+        if c["drawn"] and c["drawn"]["saved"]:
+            c["drawn"]["saved"] = c["drawn"]["saved"].replace(tmp, "<tmp>")
+    print("  figures: %d calls, %d drawn" % (len(calls), sum(1 for c in calls if c["drawn"])))
+    dump("figures.json.gz", {"source": "make_event_figure_1 / makeDotplot_subfigure SF:1041-1089 with matplotlib.pyplot replaced by a recorder",
+                             "world": world_to_json(w), "bed": synth.bed_text(w), "cases": calls})
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt", "complex", "deep"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt", "complex", "deep", "figures"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)

@@ -119,3 +119,13 @@ def test_melt_ins_mode_gpu(tmp_path):
         assert (tmp_path / "S1.melt.sites.vapor").read_text() == d["cases"][0]["vapor_text"]
     finally:
         seqio.set_backend(None)
+
+
+def test_figure_specs_match_what_the_reference_plots_gpu():
+    """The four plotted point sets, tick lists, titles and the clamped file name of every make_event_figure_1 call of
+    the reference (recorded with matplotlib.pyplot replaced inside it), from dot plots the HIP library computes."""
+    import figure_cases
+    from vapor_amd import pipeline
+    pipeline.set_engine(None)
+    figure_cases.check_specs()
+    figure_cases.check_driver_requests()

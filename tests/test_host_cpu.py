@@ -123,9 +123,12 @@ def test_partition_is_balanced_and_complete():
     assert sorted(sum(parts, [])) == list(range(len(costs)))
     loads = [sum(costs[t] for t in p) for p in parts]
     assert max(loads) - min(loads) <= max(costs)
-    rec, extra = dist.pack_records({0: [0.5, -1.25], 2: [], 3: KeyError("x")}, 4)
-    back = dist.unpack_records(np.where(np.isnan(rec[:, :1]), 0, rec), {**extra, 1: None})
-    assert back[0] == [0.5, -1.25] and back[2] == [] and isinstance(back[3], KeyError)
+    flat, extra = dist.pack_records({0: [0.5, -1.25], 2: [], 3: KeyError("x"), 5: list(range(40))}, [0, 2, 3, 5])
+    assert flat.tolist()[:6] == [2.0, 0.5, -1.25, 0.0, -1.0, 40.0] and list(extra) == [3]
+    back = [None] * 6
+    dist.unpack_records(flat, [0, 2, 3, 5], extra, back)
+    assert back[0] == [0.5, -1.25] and back[2] == [] and isinstance(back[3], KeyError) and back[5] == [float(v) for v in range(40)]
+    assert dist.gather_results({0: [1.0], 1: []}, 2) == [[1.0], []]
 
 
 VCF = load_golden("locus_vcf.json.gz")["cases"]
@@ -385,25 +388,7 @@ def test_workflow_sorted_bgzipped_indexed_table(fake, tmp_path):
 
 
 def _world_to_files(world, d):
-    """FASTA + .fai and BAM + .bai of a synthetic world (no samtools involved)."""
-    from vapor_amd import bamio
-    fa = str(d / "ref.fa")
-    names = list(world.contigs)
-    with open(fa, "w") as f, open(fa + ".fai", "w") as fi:
-        off = 0
-        for n in names:
-            seq = world.contigs[n]
-            hdr = ">" + n + "\n"
-            f.write(hdr)
-            off += len(hdr)
-            fi.write("%s\t%d\t%d\t60\t61\n" % (n, len(seq), off))
-            for i in range(0, len(seq), 60):
-                f.write(seq[i:i + 60] + "\n")
-            off += len(seq) + (len(seq) + 59) // 60
-    recs = [(r.qname, names.index(c), r.pos - 1, r.cigar, r.seq) for c, rs in world.reads.items() for r in rs]
-    bam = str(d / "reads.bam")
-    bamio.write_bam(bam, [(n, len(world.contigs[n])) for n in names], recs, block_size=8192)
-    return fa, bam
+    return synth.write_world_files(world, str(d))
 
 
 @pytest.mark.parametrize("case", [c for c in LOCUS if not [p for p in c["per_locus"] if "error" in p["scores"]]][:3],
@@ -497,3 +482,13 @@ def test_deep_loci_host_finish_vs_reference(oracle):
         assert got == scores, c["name"]
         s_qs, s_gs, idx, s_gq = finish.locus_summary(got)
         assert (float(s_qs), float(s_gs), idx, float(s_gq)) == (qs, gs, gt, gq), c["name"]
+
+
+def test_figure_specs_match_what_the_reference_plots(fake):
+    import figure_cases
+    figure_cases.check_specs()
+
+
+def test_figure_requests_of_the_drivers(fake):
+    import figure_cases
+    figure_cases.check_driver_requests()

@@ -300,6 +300,8 @@ def svelter_jobs(sv_hash, num_reads_cff, bam_in, ref, out_path, sample_name) -> 
 def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
     """Score every job (sharded over ranks, batched on each GPU); returns per job the list of read
     scores, in job order, identical on every rank."""
+    import time
+    t0 = time.perf_counter()
     mine = vdist.my_share(len(jobs))
     local: dict = {}
     for a in range(0, len(mine), max(chunk, 1)):
@@ -312,6 +314,10 @@ def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
             if jobs[t].make is None:
                 local[t] = jobs[t].fixed
     allres = vdist.gather_results(local, len(jobs))
+    if os.environ.get("VAPOR_TIMING") and vdist.rank() == 0:
+        dt = time.perf_counter() - t0
+        print("vapor_amd.cli: scored %d loci on %d rank(s) in %.3f s -> %.1f loci/s" % (len(jobs), vdist.world(), dt, len(jobs) / dt),
+              file=sys.stderr)
     for r in allres:
         if isinstance(r, BaseException):
             raise r

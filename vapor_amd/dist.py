@@ -2,10 +2,9 @@
 (SURVEY.md §8e).
 
 Loci are independent, so there is no data-path collective: each rank scores its share and one
-all-gather of fixed-size float64 records (RCCL over xGMI when the ranks own GPUs, gloo on CPU in
-the tests) gives every rank the complete table.  Record layout (RECORD_WIDTH float64):
-    [0] = n scores (or -1: the locus ended in an exception, sent separately as an object)
-    [1 .. 1+n) = the read scores in read order.
+all-gather of the ranks' score vectors (RCCL over xGMI when every rank owns a GPU; gloo on CPU in the tests and
+between ranks that share a GPU) gives every rank the complete table: per locus [n, score_1 .. score_n] in read order (n = -1: the locus
+ended in an exception, which is sent separately as an object), each rank's own loci only.
 """
 from __future__ import annotations
 
@@ -14,9 +13,18 @@ from typing import Dict, List, Sequence
 
 import numpy as np
 
-RECORD_WIDTH = 32      # the reference keeps at most 20 reads per locus (SF:1091)
-
 _pg = None
+
+
+def _device_ordinal() -> int:
+    """LOCAL_RANK folded onto the GPUs present (several ranks may share one GPU)."""
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:       # noqa: BLE001
+        n = 0
+    return lr % n if n > 0 else lr
 
 
 def init_from_env(backend: str = None) -> None:
@@ -29,9 +37,15 @@ def init_from_env(backend: str = None) -> None:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("VAPOR_DIST_BACKEND")
+    if backend is None:
+        # RCCL wants a GPU per rank; ranks that share a GPU (host-side parallelism: the per-locus Python, BAM
+        # decompression) exchange their few kilobytes of scores through gloo
+        n_gpu = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        backend = "nccl" if n_gpu > 0 and local_world <= n_gpu else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(_device_ordinal())
     if not dist.is_initialized():
         dist.init_process_group(backend)
     _pg = backend
@@ -82,53 +96,68 @@ def my_share(n_items: int, costs: Sequence[float] = None) -> List[int]:
     return partition(costs, w)[rank()]
 
 
-def pack_records(local: Dict[int, object], n_items: int):
-    """(records (n_items, RECORD_WIDTH) with NaN rows for other ranks' items, {index: object}
-    for what does not fit a record)."""
-    rec = np.full((n_items, RECORD_WIDTH), np.nan, dtype=np.float64)
+def pack_records(local: Dict[int, object], items: Sequence[int]):
+    """This rank's share as one flat float64 vector - per item, in `items` order, [n, score_1 .. score_n], or [-1]
+    for an item that ended in an exception (or produced no list), which travels separately as an object - and
+    {index: object} for those."""
+    flat: List[float] = []
     extra = {}
-    for t, v in local.items():
-        if isinstance(v, BaseException) or v is None or len(v) > RECORD_WIDTH - 1:
-            rec[t, 0] = -1
+    for t in items:
+        v = local[t]
+        if isinstance(v, BaseException) or v is None:
+            flat.append(-1.0)
             extra[t] = v
         else:
-            rec[t, 0] = len(v)
-            rec[t, 1:1 + len(v)] = v
-    return rec, extra
+            flat.append(float(len(v)))
+            flat.extend(float(x) for x in v)
+    return np.asarray(flat, dtype=np.float64), extra
 
 
-def unpack_records(rec: np.ndarray, extra: Dict[int, object]) -> List[object]:
-    out: List[object] = []
-    for t in range(rec.shape[0]):
-        n = rec[t, 0]
-        if n == -1:
-            out.append(extra[t])
+def unpack_records(flat: np.ndarray, items: Sequence[int], extra: Dict[int, object], out: List[object]) -> None:
+    p = 0
+    for t in items:
+        n = int(flat[p])
+        p += 1
+        if n < 0:
+            out[t] = extra[t]
         else:
-            out.append([float(x) for x in rec[t, 1:1 + int(n)]])
-    return out
+            out[t] = [float(x) for x in flat[p:p + n]]
+            p += n
 
 
-def gather_results(local: Dict[int, object], n_items: int) -> List[object]:
-    """Every rank contributes the items it scored; every rank gets the full list back."""
-    rec, extra = pack_records(local, n_items)
+def gather_results(local: Dict[int, object], n_items: int, costs: Sequence[float] = None) -> List[object]:
+    """Every rank contributes the items it scored (its share of `my_share(n_items, costs)`); every rank gets the
+    full list back.  What travels: one all-gather of (vector length, number of exceptions) per rank, then one
+    all-gather of the ranks' own score vectors padded to the longest - a few hundred bytes per locus, no NaN rows
+    for other ranks' loci, and no pickling unless some locus raised."""
+    out: List[object] = [None] * n_items
     if _pg is None:
-        return unpack_records(rec, extra)
+        items = list(range(n_items))
+        flat, extra = pack_records(local, items)
+        unpack_records(flat, items, extra, out)
+        return out
     import torch
     import torch.distributed as dist
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if _pg == "nccl" else torch.device("cpu")
-    mine = torch.from_numpy(rec).to(dev)
     nw = dist.get_world_size()
-    allr = torch.empty((nw * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=dev)
-    dist.all_gather_into_tensor(allr, mine.contiguous())
-    allr = allr.cpu().numpy().reshape(nw, mine.shape[0], mine.shape[1])
-    # each item was scored by exactly one rank: take the row that is not NaN
-    have = ~np.isnan(allr[:, :, 0])
-    owner = have.argmax(axis=0)
-    assert have.sum(axis=0).min() == 1 and have.sum(axis=0).max() == 1, "every locus must be scored exactly once"
-    merged = allr[owner, np.arange(n_items)]
-    extras = [None] * dist.get_world_size()
-    dist.all_gather_object(extras, extra)
-    all_extra = {}
-    for e in extras:
-        all_extra.update(e)
-    return unpack_records(merged, all_extra)
+    shares = partition([1.0] * n_items if costs is None else costs, nw)
+    flat, extra = pack_records(local, shares[dist.get_rank()])
+    dev = torch.device("cuda", _device_ordinal()) if _pg == "nccl" else torch.device("cpu")
+    head = torch.tensor([len(flat), len(extra)], dtype=torch.int64, device=dev)
+    heads = torch.empty(nw * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads, head)
+    heads = heads.cpu().numpy().reshape(nw, 2)
+    width = max(int(heads[:, 0].max()), 1)
+    mine = torch.zeros(width, dtype=torch.float64, device=dev)
+    mine[:len(flat)] = torch.from_numpy(flat).to(dev)
+    allv = torch.empty(nw * width, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allv, mine)
+    allv = allv.cpu().numpy().reshape(nw, width)
+    all_extra: Dict[int, object] = {}
+    if int(heads[:, 1].sum()) > 0:              # some locus ended in an exception: those objects are pickled
+        extras = [None] * nw
+        dist.all_gather_object(extras, extra)
+        for e in extras:
+            all_extra.update(e)
+    for r in range(nw):
+        unpack_records(allv[r, :int(heads[r, 0])], shares[r], all_extra, out)
+    return out

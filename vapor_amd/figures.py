@@ -1,46 +1,52 @@
 """Recurrence-plot PNGs (make_event_figure_1, SF:1072-1089): ref x ref,
-alt x alt, best read x ref, best read x alt, drawn from dot plots the device computes."""
+alt x alt, best read x ref, best read x alt, drawn from dot plots the device computes.
+
+`figure_spec` decides everything the reference's make_event_figure_1 / makeDotplot_subfigure (SF:1041-1089) decide -
+whether a figure is drawn at all, the four point sets in dotdata's order, the tick positions and labels, the titles,
+the file name with its 150-character clamp - and `make_event_figure_1` hands that to matplotlib.  The parity tests
+compare the specification with what the reference passes to matplotlib (tests/golden/figures.json.gz)."""
 from __future__ import annotations
+
+from typing import List, Optional
 
 import numpy as np
 
+TITLES = ('ref vs. ref', 'alt vs. alt', 'read vs. ref', 'read vs. alt')
+POSITIONS = (221, 222, 223, 224)
 
-def _subplot(plt, hits: np.ndarray, title: str, pos: int) -> None:
-    if len(hits) == 0:
-        return
-    x, y = hits[:, 0], hits[:, 1]
-    mx = int(x.max())
-    digits = len(str(mx))
+
+def x_ticks(max_x: int) -> list:
+    """Tick positions of makeDotplot_subfigure (SF:1051-1062) for the largest x of a plot."""
+    digits = len(str(max_x))
     unit = 10 ** (digits - 1)
-    n = int(float(mx) / float(unit)) + 1
+    n = int(float(max_x) / float(unit)) + 1
     if n < 3:
         ticks = [(i + 1) * unit for i in range(n)]
         half = [ticks[0] / 2]
         for i in range(len(ticks) - 1):
             half.append(half[0] * (2 * (i + 1) + 1))
-        ticks = sorted(ticks + half)
-    elif n < 5:
-        ticks = [(i + 1) * unit for i in range(n)]
-    else:
-        ticks = [(i + 1) * 2 * unit for i in range(int(n / 2 + 1) + 1)]
-    plt.subplot(pos)
-    plt.plot(x, y, '+', color='r')
-    plt.xticks(ticks, [str(i) for i in ticks])
-    plt.title(title)
-    plt.grid(False)
+        return sorted(ticks + half)
+    if n < 5:
+        return [(i + 1) * unit for i in range(n)]
+    return [(i + 1) * 2 * unit for i in range(int(n / 2 + 1) + 1)]
 
 
-def make_event_figure_1(req) -> None:
-    """`req` is a drivers.Figure.  Nothing is drawn without a best read or when any of the four
-    plots is empty, as in the reference."""
+def clamp_name(name: str) -> str:
+    """SF:1080-1081: a file name of more than 150 characters keeps its first 140 and its extension."""
+    base = name.split('/')[-1]
+    if len(base) > 150:
+        return '/'.join(name.split('/')[:-1]) + '/' + base[:140] + '.' + name.split('.')[-1]
+    return name
+
+
+def figure_spec(req, engine=None) -> Optional[dict]:
+    """None when the reference draws nothing (no best read, or one of the four plots is empty); else
+    {"name": file name, "subplots": [{"pos", "title", "hits" (n, 2) int32 [x = j, y = i], "xticks", "xticklabels"}]}."""
     best = req.best_read
     if best == '' or best == []:
-        return
-    import matplotlib
-    matplotlib.use('Agg')
-    import matplotlib.pyplot as plt
+        return None
     from . import pipeline
-    eng = pipeline.get_engine()
+    eng = engine or pipeline.get_engine()
     ss = eng.seqset([req.ref_seq, req.alt_seq, best[0]])
     try:
         k, miss = int(req.k), int(best[1])
@@ -50,13 +56,31 @@ def make_event_figure_1(req) -> None:
     for row in st:
         pipeline._raise_for_status(row)
     if any(len(h) == 0 for h in hits):
+        return None
+    subs: List[dict] = []
+    for h, title, pos in zip(hits, TITLES, POSITIONS):
+        h = np.asarray(h, dtype=np.int32).reshape(-1, 2)
+        h = h[np.lexsort((h[:, 1], h[:, 0]))]            # dotdata's order: by j, then i
+        ticks = x_ticks(int(h[:, 0].max()))
+        subs.append({"pos": pos, "title": title, "hits": h, "xticks": ticks, "xticklabels": [str(i) for i in ticks]})
+    return {"name": clamp_name(req.name), "subplots": subs}
+
+
+def make_event_figure_1(req) -> None:
+    """`req` is a drivers.Figure.  Nothing is drawn without a best read or when any of the four
+    plots is empty, as in the reference."""
+    spec = figure_spec(req)
+    if spec is None:
         return
-    name = req.name
-    base = name.split('/')[-1]
-    if len(base) > 150:
-        name = '/'.join(name.split('/')[:-1]) + '/' + base[:140] + '.' + name.split('.')[-1]
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
     fig = plt.figure()
-    for h, title, pos in zip(hits, ('ref vs. ref', 'alt vs. alt', 'read vs. ref', 'read vs. alt'), (221, 222, 223, 224)):
-        _subplot(plt, h, title, pos)
-    plt.savefig(name)
+    for sp in spec["subplots"]:
+        plt.subplot(sp["pos"])
+        plt.plot(sp["hits"][:, 0], sp["hits"][:, 1], '+', color='r')
+        plt.xticks(sp["xticks"], sp["xticklabels"])
+        plt.title(sp["title"])
+        plt.grid(False)
+    plt.savefig(spec["name"])
     plt.close(fig)

@@ -22,9 +22,9 @@ def get_engine():
     """Process-wide default engine on the current device (LOCAL_RANK or 0)."""
     global _engine
     if _engine is None:
-        import os
+        from .dist import _device_ordinal
         from .engine import Engine
-        _engine = Engine(int(os.environ.get("LOCAL_RANK", "0")))
+        _engine = Engine(_device_ordinal())
     return _engine
 
 
@@ -69,70 +69,76 @@ def _raise_for_status(st_row) -> None:
 
 def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> List[list]:
     """window_size_refine (SF:2030-2046) for every sequence; returns [[w, qc] | ['Error','Error']].
-    Exceptions the reference would raise for one sequence are returned in its slot."""
+    Exceptions the reference would raise for one sequence are returned in its slot.
+
+    All self dot plots of a round (one window size) are one plan; the statistics are read as arrays, and only a
+    plot whose lower-triangle share falls into (0.1, 0.5) (SF:1165) is fetched dot by dot for the clustering."""
     n = len(seqs)
     out: List[Optional[object]] = [None] * n
     work = []                     # (slot, seq2)
     for t, s in enumerate(seqs):
-        s2 = s.replace("X", "")              # ''.join([i for i in seq2 if not i == 'X']), SF:2031
+        s2 = s.replace("X", "") if "X" in s else s   # ''.join([i for i in seq2 if not i == 'X']), SF:2031
         if s2.count("N") + s2.count("n") > 100:
             out[t] = ["Error", "Error"]
         else:
             work.append((t, s2))
     k = 10
     while work:
-        tab = _SeqTable()
-        rows = []
-        for _t, s2 in work:
-            q = tab.add(s2)
-            rows.append((q, q, 0, k, 0))
-        ss = engine.seqset(tab.seqs)
-        plan = engine.plan(ss, engine.make_pairs(rows))
-        st = plan.run()
+        idx_of: Dict[str, int] = {}
+        useqs: List[str] = []
+        which = np.empty(len(work), dtype=np.int64)
+        for w, (_t, s2) in enumerate(work):
+            q = idx_of.get(s2)
+            if q is None:
+                q = idx_of[s2] = len(useqs)
+                useqs.append(s2)
+            which[w] = q
+        pairs = np.zeros(len(useqs), dtype=L.PAIR_DTYPE)
+        pairs["seq1"] = pairs["seq2"] = np.arange(len(useqs))
+        pairs["k"] = k
+        ss = engine.seqset(useqs)
+        plan = engine.plan(ss, pairs)
+        st = plan.run()[which]
+        code = st[:, L.ST_STATUS]
+        nh, nd, nl = st[:, L.ST_N_HITS], st[:, L.ST_N_DIAG], st[:, L.ST_N_LOWER]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            frac = nl.astype(np.float64) / nh.astype(np.float64)
+            diag = nd.astype(np.float64) / nh.astype(np.float64)
+        band = (code == 0) & (nh > 0) & (frac > 0.1) & (frac < 0.5)
+        pts = {}
+        need = np.flatnonzero(band)
+        if len(need):
+            hits, _f, off = plan.fetch_hits(which[need].tolist(), want_flags=False)
+            for q, w in enumerate(need):
+                h = hits[off[q]:off[q + 1]]
+                h = h[h[:, 0] > h[:, 1]]
+                pts[int(w)] = h[np.lexsort((h[:, 1], h[:, 0]))]
+        plan.close()
+        ss.close()
         nxt = []
-        need_pts = []
         for w, (t, s2) in enumerate(work):
-            code = int(st[w, L.ST_STATUS])
-            if code != 0:
+            if code[w] != 0:
                 try:
                     _raise_for_status(st[w])
                 except Exception as e:      # noqa: BLE001
                     out[t] = e
                 continue
-            nh, nd, nl = int(st[w, L.ST_N_HITS]), int(st[w, L.ST_N_DIAG]), int(st[w, L.ST_N_LOWER])
-            if nh == 0:
-                if k == 10:
-                    out[t] = ["Error", "Error"]                      # SF:2035, 2045
-                else:
-                    out[t] = ZeroDivisionError("float division by zero")   # SF:1171 on an empty plot
+            if nh[w] == 0:
+                # SF:2035, 2045 at the first size; later an empty plot divides by zero in SF:1171
+                out[t] = ["Error", "Error"] if k == 10 else ZeroDivisionError("float division by zero")
                 continue
-            frac = float(nl) / float(nh)
-            if frac > 0.1 and frac < 0.5:
-                need_pts.append(w)
-        pts = {}
-        if need_pts:
-            hits, _f, off = plan.fetch_hits(need_pts, want_flags=False)
-            for q, w in enumerate(need_pts):
-                h = hits[off[q]:off[q + 1]]
-                h = h[h[:, 0] > h[:, 1]]
-                h = h[np.lexsort((h[:, 1], h[:, 0]))]
-                pts[w] = h
-        for w, (t, s2) in enumerate(work):
-            if out[t] is not None:
-                continue
-            nh, nd, nl = int(st[w, L.ST_N_HITS]), int(st[w, L.ST_N_DIAG]), int(st[w, L.ST_N_LOWER])
-            try:
-                qc = repeat_qc.qual_check_from_counts(
-                    nh, nd, nl, (lambda w=w: (pts[w][:, 0].tolist(), pts[w][:, 1].tolist())))
-            except Exception as e:          # noqa: BLE001 - e.g. the clustering libraries' own errors
-                out[t] = e
-                continue
+            if band[w]:
+                try:
+                    qc = [float(diag[w]), repeat_qc.cluster_sizes(pts[w][:, 0].tolist(), pts[w][:, 1].tolist())]
+                except Exception as e:          # noqa: BLE001 - e.g. the clustering libraries' own errors
+                    out[t] = e
+                    continue
+            else:
+                qc = [float(diag[w]), [0]]
             if k > 30 or qc[0] > region_QC_Cff or sum(qc[1]) / float(len(s2)) < 0.3:
                 out[t] = [k, qc]
             else:
                 nxt.append((t, s2))
-        plan.close()
-        ss.close()
         work = nxt
         k += 10
     return out  # type: ignore[return-value]

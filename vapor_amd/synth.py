@@ -516,3 +516,28 @@ def complex_vcf_text(world: SynthWorld, header: bool = False) -> str:
             raise ValueError(l.svtype)
         out.append("\t".join([l.chrom, str(l.start), l.svid, "N", "<%s>" % l.svtype, ".", "PASS", info, "GT", "0/1"]))
     return "\n".join(out) + "\n"
+
+
+def write_world_files(world: SynthWorld, directory: str, block_size: int = 8192) -> Tuple[str, str]:
+    """FASTA + .fai and coordinate-sorted BAM + .bai of a synthetic world, written by this package alone
+    (vapor_amd.bamio); returns (fasta path, bam path).  Reads keep their order inside one start position."""
+    import os
+    from . import bamio
+    fa = os.path.join(directory, "ref.fa")
+    names = list(world.contigs)
+    with open(fa, "w") as f, open(fa + ".fai", "w") as fi:
+        off = 0
+        for n in names:
+            seq = world.contigs[n]
+            seq = seq[0:len(seq)] if not isinstance(seq, str) else seq
+            hdr = ">" + n + "\n"
+            f.write(hdr)
+            off += len(hdr)
+            fi.write("%s\t%d\t%d\t60\t61\n" % (n, len(seq), off))
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + "\n")
+            off += len(seq) + (len(seq) + 59) // 60
+    recs = [(r.qname, names.index(c), r.pos - 1, r.cigar, r.seq) for c, rs in world.reads.items() for r in rs]
+    bam = os.path.join(directory, "reads.bam")
+    bamio.write_bam(bam, [(n, len(world.contigs[n])) for n in names], recs, block_size=block_size)
+    return fa, bam

@@ -7,7 +7,7 @@ the scatter is needed - `vapor_amd.cli` shards the loci over the ranks of a torc
 is the gather side only: the same sorted, block-gzipped table plus its tabix index, written in-process
 (no bgzip / tabix binaries), and a launcher that runs the CLI on N GPUs and then produces them.
 
-    python -m vapor_amd.workflow --gpus 8 --prefix sample1 bed --sv-input x.bed --reference ref.fa \\
+    python -m vapor_amd.workflow --gpus 8 [--ranks-per-gpu R] --prefix sample1 bed --sv-input x.bed --reference ref.fa \\
            --pacbio-input reads.bam --output-path figs/ --output-file sample1.vapor
 
 writes sample1.vapor (the CLI's table, unchanged), sample1.bed.gz and sample1.bed.gz.tbi.
@@ -216,10 +216,12 @@ def merge_tables(tables: Sequence[str], prefix: str, index: bool = True) -> str:
 # ---------------------------------------------------------------------------------------------
 def main(argv: List[str] = None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
-    gpus, prefix, index = 1, None, True
+    gpus, prefix, index, per_gpu = 1, None, True, 1
     while argv and argv[0].startswith("--"):
         if argv[0] == "--gpus":
             gpus = int(argv[1]); argv = argv[2:]
+        elif argv[0] == "--ranks-per-gpu":
+            per_gpu = int(argv[1]); argv = argv[2:]
         elif argv[0] == "--prefix":
             prefix = argv[1]; argv = argv[2:]
         elif argv[0] == "--no-index":
@@ -236,8 +238,11 @@ def main(argv: List[str] = None) -> int:
     table = opt("--sv-input") + ".vapor" if mode == "vcf" else opt("--output-file")
     if prefix is None:
         prefix = re.sub(r"\.vapor$", "", table)
-    if gpus > 1:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+    if gpus * per_gpu > 1:
+        # one rank per GPU over RCCL, or several per GPU (LOCAL_RANK modulo the GPUs; gloo between them): a whole
+        # `vapor` run waits for the host side - BAM decompression, CIGAR walks, the per-locus Python - far longer
+        # than for the kernels, so ranks that share a GPU scale it until the GPU is busy
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus * per_gpu),
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29513"),
                "-m", "vapor_amd.cli"] + argv
         rc = subprocess.call(cmd)
