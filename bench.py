@@ -345,27 +345,48 @@ def sub_record(eng, wl, name, torch, passes: int = 12):
 
 
 def cpu_baseline(w, st, n_pairs, seconds):
+    """The CPU port timed through the same C ABI: oracle/_build/libvapor_cpu.so (oracle/cpu_twin.cpp on vapor_oracle.c)
+    exports include/vapor_hip.h's symbols; a bounded sample of the batch's pairs is run through vapor_plan_run there,
+    chunk by chunk, one thread, and every record is compared with the GPU's."""
+    import ctypes
     from oracle import oracle as orc
+    from vapor_amd import _lib as L
     orc.build()
+    tw = L.bind(ctypes.CDLL(orc.build_twin()))
+    ctx = ctypes.c_void_p()
+    assert tw.vapor_init(0, ctypes.byref(ctx)) == 0
     done = 0
     c_cells = 0
-    t0 = time.perf_counter()
-    while done < n_pairs and time.perf_counter() - t0 < seconds:
-        p = w.pairs[done]
-        exp = orc.pair_stats(int(p["k"]), w.seqs[p["seq1"]], w.seqs[p["seq2"]][int(p["off2"]):])
-        if not int(p["flags"]) & 1:
-            exp[3] = exp[4] = 0
-        if not int(p["flags"]) & 2:
-            exp[5] = exp[6] = exp[9] = 0
-        assert exp[:10].tolist() == st[done, :10].tolist(), "GPU/oracle mismatch on pair %d" % done
-        c_cells += len(w.seqs[p["seq1"]]) * (len(w.seqs[p["seq2"]]) - int(p["off2"]))
-        done += 1
-    ct = time.perf_counter() - t0
+    ct = 0.0
+    chunk = 40
+    while done < n_pairs and ct < seconds:
+        pr = w.pairs[done:done + chunk].copy()
+        ids = sorted(set(pr["seq1"].tolist()) | set(pr["seq2"].tolist()))
+        remap = {s: t for t, s in enumerate(ids)}
+        raw = [w.seqs[s].encode("ascii") for s in ids]
+        ptrs = (ctypes.c_void_p * len(raw))(*[ctypes.cast(ctypes.c_char_p(x), ctypes.c_void_p).value for x in raw])
+        lens = np.array([len(x) for x in raw], dtype=np.int32)
+        pr["seq1"] = [remap[s] for s in pr["seq1"].tolist()]
+        pr["seq2"] = [remap[s] for s in pr["seq2"].tolist()]
+        out = np.zeros((len(pr), 16), dtype=np.int64)
+        ss, pl = ctypes.c_void_p(), ctypes.c_void_p()
+        t0 = time.perf_counter()
+        assert tw.vapor_seqset_create_ptrs(ctx, len(raw), ptrs, L.ptr(lens, ctypes.c_int32), None, None, ctypes.byref(ss)) == 0
+        assert tw.vapor_plan_create(ctx, ss, len(pr), pr.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pl)) == 0
+        assert tw.vapor_plan_run(pl, L.ptr(out, ctypes.c_int64)) == 0
+        ct += time.perf_counter() - t0
+        tw.vapor_plan_destroy(pl); tw.vapor_seqset_destroy(ss)
+        # statistics 0-12: counts, cleaning, and the directed statistics (float64 restatement there, integers here)
+        assert np.array_equal(out[:, :13], st[done:done + len(pr), :13]), "GPU / CPU-twin mismatch in pairs %d..%d" % (done, done + len(pr))
+        for q in w.pairs[done:done + len(pr)]:
+            c_cells += len(w.seqs[q["seq1"]]) * (len(w.seqs[q["seq2"]]) - int(q["off2"]))
+        done += len(pr)
+    tw.vapor_destroy(ctx)
     pairs_per_locus = n_pairs / w.n_loci
     cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "kind": "port",
-           "sample": "first %d of %d (read, allele) dot plots of the same batch (fill + C1/C2 clean + counts, "
-                     "oracle/vapor_oracle.c, gcc -O2, 1 thread, %.1f s); each checked equal to the GPU record"
-                     % (done, n_pairs, ct),
+           "sample": "first %d of %d (read, allele) dot plots of the same batch through libvapor_cpu.so - the CPU oracle behind "
+                     "the same C ABI (oracle/cpu_twin.cpp + vapor_oracle.c: fill, C1/C2 clean, counts, directed statistics; "
+                     "gcc -O2, 1 thread, %.1f s); every record checked equal to the GPU's" % (done, n_pairs, ct),
            "cells_per_s": round(c_cells / ct, 1)}
     rj = _load_json("r02_cpu_ratio.json")
     if rj:

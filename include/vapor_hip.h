@@ -211,6 +211,8 @@ int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* hits_ji, co
  * out[1] = miss_bp.  VAPOR_E_ARG if the CIGAR holds no operation (IndexError in the reference).
  */
 int vapor_cigar2alignstart(const char* cigar, int64_t align_start, int64_t start, int64_t* out);
+/* the same over a BAM record's binary CIGAR (n_ops words, length << 4 | operation code in "MIDNSHP=X" order) */
+int vapor_cigar2alignstart_ops(const uint32_t* ops, int64_t n_ops, int64_t align_start, int64_t start, int64_t* out);
 
 #ifdef __cplusplus
 }

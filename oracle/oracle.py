@@ -31,6 +31,21 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+_TWIN = os.path.join(_HERE, "_build", "libvapor_cpu.so")
+
+
+def build_twin(force: bool = False) -> str:
+    """libvapor_cpu.so: the C ABI of include/vapor_hip.h on this oracle (cpu_twin.cpp; test infrastructure)."""
+    srcs = [os.path.join(_HERE, "cpu_twin.cpp"), os.path.join(_HERE, "vapor_oracle.c"),
+            os.path.join(os.path.dirname(_HERE), "include", "vapor_hip.h")]
+    if force or not os.path.exists(_TWIN) or any(os.path.getmtime(_TWIN) < os.path.getmtime(x) for x in srcs):
+        os.makedirs(os.path.dirname(_TWIN), exist_ok=True)
+        obj = os.path.join(_HERE, "_build", "vapor_oracle_twin.o")
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-c", "-o", obj, srcs[1]])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", _TWIN, srcs[0], obj])
+    return _TWIN
+
+
 def lib():
     global _lib
     if _lib is None:

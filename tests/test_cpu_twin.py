@@ -1,0 +1,101 @@
+"""libvapor_cpu.so (oracle/cpu_twin.cpp): the C ABI of include/vapor_hip.h on the CPU oracle - SURVEY.md 8b's "same
+symbols exported by a CPU build".  TEST INFRASTRUCTURE: bound here explicitly, never by vapor_amd.  It lets the
+CPU-only suite run the real ctypes bindings and the real Engine / Plan / pipeline objects (on the GPU box the same
+code runs on libvapor_hip.so), and it is itself pinned by the reference's vectors: the bodies of the GPU parity
+tests are run against it."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def twin(oracle):
+    """vapor_amd._lib bound to the CPU twin for the duration of this module."""
+    from vapor_amd import _lib
+    so = oracle.build_twin()
+    saved = _lib._lib
+    _lib._lib = _lib.bind(ctypes.CDLL(so))
+    yield so
+    _lib._lib = saved
+
+
+@pytest.fixture()
+def eng(twin):
+    from vapor_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def test_twin_exports_the_whole_header(twin):
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vapor_hip.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(vapor_[a-z_0-9]+)\s*\(", src)))
+    lib = ctypes.CDLL(twin)
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libvapor_cpu.so does not export %s" % n
+
+
+def test_gpu_parity_bodies_on_the_twin(eng, oracle):
+    """The reference-vector checks of tests/test_gpu_parity.py, executed on the twin through the same Engine class."""
+    import test_gpu_parity as G
+    G.test_dotdata_golden(eng)
+    G.test_cleaners_golden(eng, oracle)
+    G.test_scorers_golden_end_to_end(eng)
+    G.test_scorer_inputs_vs_oracle(eng, oracle)
+    G.test_queue_edge(eng, oracle)
+    G.test_deep_loci_device_finish_vs_reference(eng)
+    G.test_device_finish_matches_host_finish(eng, "tiny")
+
+
+def test_pipeline_and_cli_on_the_twin(eng, tmp_path):
+    """`vapor bed` through pipeline.run_batch with the real Engine on the twin: the reference's table."""
+    from conftest import load_golden
+    from vapor_amd import cli, pipeline, seqio, synth
+    case = [c for c in load_golden("locus_bed.json.gz")["cases"] if c["name"] == "bed_hom_alt"][0]
+    pipeline.set_engine(eng)
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
+    try:
+        bed = tmp_path / "in.bed"
+        bed.write_text(case["bed"])
+        out = tmp_path / "out.vapor"
+        assert cli.main(["bed", "--sv-input", str(bed), "--reference", "ref.fa", "--pacbio-input", "x.bam",
+                         "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+        assert out.read_text() == case["vapor_text"]
+    finally:
+        pipeline.set_engine(None)
+        seqio.set_backend(None)
+
+
+def test_complex_types_on_the_twin(eng, tmp_path):
+    import complex_cases as cx
+    from vapor_amd import pipeline
+    pipeline.set_engine(eng)
+    try:
+        cx.check_records(cx.CX["cases"][1], tmp_path)
+        cx.check_disdup_driver()
+    finally:
+        pipeline.set_engine(None)
+
+
+def test_error_codes_and_async_surface(eng):
+    from vapor_amd import _lib as L
+    ss = eng.seqset(["ACGTACGTACGTTTGACCA", "ACGTACGTACGTXACGT", "ACGT"])
+    assert ss.n_invalid.tolist() == [0, 1, 0]
+    st = eng.score(ss, eng.make_pairs([(1, 0, 0, 10, 7), (0, 0, 0, 11, 7), (0, 7, 0, 10, 7), (2, 0, 0, 10, 7)]))
+    assert st[:, 15].tolist() == [L.E_KEYERROR, L.E_ARG, L.E_ARG, 0] and st[3, 0] == 0
+    plan = eng.plan(ss, eng.make_pairs([(0, 0, 0, 10, 3)]))
+    t = np.zeros(1, dtype=L.READ_DTYPE)
+    t["kind"], t["len_ref"], t["len_alt"] = 1, 19, 19
+    plan.set_reads(t, 1)
+    a = plan.run_loci().copy()
+    plan.run_loci_async()
+    plan.then(0); plan.after(0)
+    b = plan.sync().copy()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    plan.close(); ss.close()

@@ -2,6 +2,8 @@
 pipeline.run_batch -> rows.  GPU box.
 
   bench_pipeline.py [n_loci] [--svtypes DEL,DEL,INV,INS] [--profile]        in-memory world, one process
+  bench_pipeline.py [n_loci] --ranks R                                       in-memory world (every rank builds the same
+                                                                            seeded world), R ranks share the GPU (gloo)
   bench_pipeline.py [n_loci] --files [--ranks R]                             FASTA/.fai + BAM/.bai on disk through the
                                                                             in-process readers; R ranks share the GPU
 """
@@ -51,8 +53,19 @@ if "--files" in args:
     print("tables identical:", a == b, " rows:", a.count("\n"))
     sys.exit(0)
 
+if ranks > 1 and "--worker" not in args:
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+                        "127.0.0.1", "--master-port", "29517", os.path.abspath(__file__)] + args + ["--worker"], env=env, cwd=ROOT,
+                       capture_output=True, text=True)
+    print([l for l in p.stdout.splitlines() if "loci/s" in l] or p.stderr[-1500:])
+    sys.exit(p.returncode)
+
 seqio.set_backend(seqio.MemorySamtools(w))
 bed_info = cli.bed_info_readin(bed, tmp)
+if "--worker" in args:
+    from vapor_amd import dist as vdist
+    vdist.init_from_env()
 pipeline.get_engine()
 
 
@@ -70,6 +83,12 @@ run()
 best = 1e9
 for _ in range(3):
     t0 = time.perf_counter(); rows = run(); best = min(best, time.perf_counter() - t0)
+if "--worker" in args:
+    from vapor_amd import dist as vdist
+    if vdist.rank() == 0:
+        print("%d loci in %.3f s -> %.1f loci/s (best of 3, %d ranks sharing one GPU, in-memory world)" % (len(rows), best, len(rows) / best, vdist.world()))
+    vdist.finalize()
+    sys.exit(0)
 print("%d loci in %.3f s -> %.1f loci/s (best of 3, one process, in-memory world)" % (len(rows), best, len(rows) / best))
 if "--profile" in args:
     cProfile.run("run()", "/tmp/pipe.prof")

@@ -35,7 +35,7 @@ EXPORTS = [
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_record_counts", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
     "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync", "vapor_plan_then", "vapor_plan_after",
-    "vapor_cigar2alignstart",
+    "vapor_cigar2alignstart", "vapor_cigar2alignstart_ops",
 ]
 
 _lib = None
@@ -55,7 +55,12 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(SO_PATH):
         raise RuntimeError("%s is missing - the HIP extension has not been built "
                            "(run `python -m vapor_amd.build`); there is no CPU fallback" % SO_PATH)
-    L = ctypes.CDLL(SO_PATH)
+    _lib = bind(ctypes.CDLL(SO_PATH))
+    return _lib
+
+
+def bind(L: ctypes.CDLL) -> ctypes.CDLL:
+    """Declares the argument types of every entry point of include/vapor_hip.h on a loaded library."""
     vp = ctypes.c_void_p
     i32p = ctypes.POINTER(ctypes.c_int32)
     i64p = ctypes.POINTER(ctypes.c_int64)
@@ -81,6 +86,7 @@ def load() -> ctypes.CDLL:
     L.vapor_plan_then.argtypes = [vp, vp]
     L.vapor_plan_after.argtypes = [vp, vp]
     L.vapor_cigar2alignstart.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i64p]
+    L.vapor_cigar2alignstart_ops.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, i64p]
     L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
     L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]
     L.vapor_dotplot_batch.argtypes = [vp, vp, ctypes.c_int64, vp, i32p, ctypes.c_int64, i64p, i64p]
@@ -92,7 +98,6 @@ def load() -> ctypes.CDLL:
     for name in EXPORTS:
         if name not in ("vapor_last_error",):
             getattr(L, name).restype = ctypes.c_int
-    _lib = L
     return L
 
 

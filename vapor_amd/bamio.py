@@ -18,9 +18,20 @@ import struct
 import zlib
 from typing import Dict, Iterator, List, Tuple
 
+import numpy as np
+
 _SEQ = "=ACMGRSVTWYHKDBN"
 _CIG = "MIDNSHP=X"
-_SEQ_LUT = [a + b for a in _SEQ for b in _SEQ]
+_REF_OP = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], dtype=np.uint32)
+_SEQ_LUT16 = None       # byte -> its two bases as one little-endian uint16 (numpy, built on first use)
+
+
+def _decode_seq(sq: bytes, l_seq: int) -> str:
+    """4-bit packed bases -> text, a table lookup per byte done by numpy (reads are tens of kilobases)."""
+    global _SEQ_LUT16
+    if _SEQ_LUT16 is None:
+        _SEQ_LUT16 = np.array([ord(a) | (ord(b) << 8) for a in _SEQ for b in _SEQ], dtype="<u2")
+    return _SEQ_LUT16[np.frombuffer(sq, dtype=np.uint8)].tobytes()[:l_seq].decode("ascii")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -210,7 +221,7 @@ class BamFile:
                 sub, cnt = chr(rec[p]), struct.unpack_from("<i", rec, p + 1)[0]
                 p += 5
                 if tag == b"CG" and sub == "I":
-                    return struct.unpack_from("<%dI" % cnt, rec, p)
+                    return np.frombuffer(rec, dtype="<u4", count=cnt, offset=p)
                 p += cnt * size[sub]
             else:
                 break
@@ -222,19 +233,19 @@ class BamFile:
         p = 32
         name = rec[p:p + l_name - 1].decode()
         p += l_name
-        cig = struct.unpack_from("<%dI" % n_cig, rec, p) if n_cig else ()
+        cig = np.frombuffer(rec, dtype="<u4", count=n_cig, offset=p)
         p += 4 * n_cig
         nb = (l_seq + 1) // 2
         sq = rec[p:p + nb]
-        if n_cig == 2 and (cig[0] & 15) == 4 and (cig[0] >> 4) == l_seq and (cig[1] & 15) == 3:
+        if n_cig == 2 and (int(cig[0]) & 15) == 4 and (int(cig[0]) >> 4) == l_seq and (int(cig[1]) & 15) == 3:
             real = cls._aux_cigar(rec, p + nb + l_seq)      # placeholder <l_seq>S<ref len>N: the operations are in CG
             if real is not None:
                 cig = real
         return ref_id, pos, name, flag, cig, l_seq, sq
 
-    def fetch_records(self, chrom: str, start: int, end: int) -> List[Tuple[str, int, str, str, int]]:
-        """(QNAME, 1-based POS, CIGAR, SEQ, FLAG) of the alignments that overlap the 1-based inclusive region, in
-        file order - what `samtools view bam chrom:start-end` lists."""
+    def fetch_raw(self, chrom: str, start: int, end: int):
+        """(QNAME, 1-based POS, CIGAR operations as a uint32 tuple, packed SEQ bytes, l_seq, FLAG) of the alignments
+        that overlap the 1-based inclusive region, in file order; nothing is decoded to text."""
         tid = self.tid.get(chrom)
         if tid is None:
             return []
@@ -252,13 +263,16 @@ class BamFile:
                     if ref_id > tid or (ref_id == tid and pos >= stop):
                         break
                     continue
-                rlen = sum(c >> 4 for c in cig if (c & 15) in (0, 2, 3, 7, 8))
+                rlen = int(((cig >> 4) * _REF_OP[cig & 15]).sum()) if len(cig) else 0     # M, D, N, =, X consume reference
                 if pos + max(rlen, 1) <= beg:
                     continue
-                cigar = "".join("%d%s" % (c >> 4, _CIG[c & 15]) for c in cig) or "*"
-                seq = "".join(_SEQ_LUT[b] for b in sq)[:l_seq] or "*"
-                out.append((name, pos + 1, cigar, seq, flag))
+                out.append((name, pos + 1, cig, sq, l_seq, flag))
         return out
+
+    def fetch_records(self, chrom: str, start: int, end: int) -> List[Tuple[str, int, str, str, int]]:
+        """(QNAME, 1-based POS, CIGAR, SEQ, FLAG) as text fields - what `samtools view bam chrom:start-end` lists."""
+        return [(name, pos, "".join("%d%s" % (c >> 4, _CIG[c & 15]) for c in cig.tolist()) or "*", _decode_seq(sq, l_seq) or "*", flag)
+                for name, pos, cig, sq, l_seq, flag in self.fetch_raw(chrom, start, end)]
 
     def fetch_lines(self, chrom: str, start: int, end: int) -> List[str]:
         """The same as SAM-ordered text lines (QNAME FLAG RNAME POS MAPQ CIGAR * 0 0 SEQ *)."""
@@ -285,21 +299,25 @@ def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, i
     """records: (qname, tid, pos0, cigar string, seq), will be sorted by (tid, pos).  Writes path and
     path + '.bai'."""
     import re
-    enc = {c: i for i, c in enumerate(_SEQ)}
+    import numpy as np
+    lut = np.full(256, 15, dtype=np.uint8)               # 4-bit codes of "=ACMGRSVTWYHKDBN", anything else N
+    for i, c in enumerate(_SEQ):
+        lut[ord(c)] = i
+        lut[ord(c.lower())] = i
     recs = sorted(records, key=lambda r: (r[1], r[2]))
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     head = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(refs))
-    for name, ln in refs:
-        head += struct.pack("<i", len(name) + 1) + name.encode() + b"\x00" + struct.pack("<i", ln)
+    head += b"".join(struct.pack("<i", len(name) + 1) + name.encode() + b"\x00" + struct.pack("<i", ln) for name, ln in refs)
     blobs = []
     meta = []
     for qname, tid, pos, cigar, seq in recs:
         ops = [(int(n), _CIG.index(o)) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", cigar)]
         rlen = sum(n for n, o in ops if o in (0, 2, 3, 7, 8))
         end = pos + max(rlen, 1)
-        sq = bytearray((len(seq) + 1) // 2)
-        for i, ch in enumerate(seq):
-            sq[i >> 1] |= enc.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
+        codes = lut[np.frombuffer(seq.encode("latin-1", "replace"), dtype=np.uint8)]
+        if len(codes) & 1:
+            codes = np.concatenate((codes, np.zeros(1, dtype=np.uint8)))
+        sq = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
         packed = [(n << 4) | o for n, o in ops]
         aux = b""
         if len(packed) > 65535:
@@ -311,18 +329,23 @@ def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, i
         blobs.append(struct.pack("<i", len(body)) + body)
         meta.append((tid, pos, end))
     # lay the stream out in BGZF blocks, remembering the virtual offset of every record
-    stream = head
     starts = []
+    pos_in_stream = len(head)
     for b in blobs:
-        starts.append(len(stream))
-        stream += b
+        starts.append(pos_in_stream)
+        pos_in_stream += len(b)
+    stream = b"".join([head] + blobs)
     ends = starts[1:] + [len(stream)]
-    out = bytearray()
+    pieces = []
     block_coff = []
+    out_len = 0
     for o in range(0, len(stream), block_size):
-        block_coff.append(len(out))
-        out += _bgzf_block(stream[o:o + block_size])
-    out += _BGZF_EOF
+        block_coff.append(out_len)
+        blk = _bgzf_block(stream[o:o + block_size])
+        pieces.append(blk)
+        out_len += len(blk)
+    pieces.append(_BGZF_EOF)
+    out = b"".join(pieces)
 
     def voff(u: int) -> int:
         b = u // block_size
@@ -330,7 +353,7 @@ def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, i
             return (len(out) - len(_BGZF_EOF)) << 16
         return (block_coff[b] << 16) | (u % block_size)
 
-    open(path, "wb").write(bytes(out))
+    open(path, "wb").write(out)
     bins: List[Dict[int, List[List[int]]]] = [dict() for _ in refs]
     linear: List[List[int]] = [[] for _ in refs]
     for (tid, pos, end), s, e in zip(meta, starts, ends):

@@ -1029,6 +1029,28 @@ extern "C" int vapor_cigar2alignstart(const char* cigar, int64_t align_start, in
     return VAPOR_OK;
 }
 
+// The same walk over a BAM record's binary CIGAR (uint32 per operation: length << 4 | code, codes "MIDNSHP=X"), so that
+// the in-process BAM reader neither formats nor re-parses CIGAR text (thousands of operations per long read).
+extern "C" int vapor_cigar2alignstart_ops(const uint32_t* ops, int64_t n_ops, int64_t align_start, int64_t start, int64_t* out)
+{
+    if (!out || (n_ops > 0 && !ops)) return fail(VAPOR_E_ARG, "vapor_cigar2alignstart_ops: null argument");
+    if (n_ops <= 0) return fail(VAPOR_E_ARG, "vapor_cigar2alignstart_ops: no CIGAR operation");
+    int64_t q = 0, r = align_start;
+    uint32_t last = 0;
+    for (int64_t t = 0; t < n_ops; ++t) {
+        const int64_t n = ops[t] >> 4;
+        last = ops[t] & 15u;
+        if (last == 4u || last == 1u) q += n;                    // S, I
+        else if (last == 0u || last == 7u) { q += n; r += n; }   // M, =
+        else if (last == 2u) r += n;                             // D
+        if (r > start - 1) break;
+    }
+    const int64_t over = r - start;
+    if (last == 0u || last == 7u) { out[0] = q - over; out[1] = 0; }
+    else { out[0] = q; out[1] = over; }
+    return VAPOR_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // The same run without a host round trip per step: enqueue only, vapor_plan_sync() waits and reports.
 constexpr int ASYNC_RING = 64;

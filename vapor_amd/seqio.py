@@ -131,6 +131,32 @@ class InProcessBam(SamtoolsHybrid):
         """(QNAME, POS, CIGAR, SEQ) per alignment overlapping chrom:start-end."""
         return [r[:4] for r in self._open(bam).fetch_records(chrom, int(start), int(end))]
 
+    def chop(self, bam: str, chrom: str, start: int, end: int, flank_length: int):
+        """chop_pacbio_read_by_pos (SF:339-354) straight from the BAM records: the CIGAR is walked in its binary form
+        (the library's host helper) and only the reads that are kept have their bases decoded."""
+        import ctypes
+        import numpy as np
+        from . import _lib, bamio
+        walk = _lib.load().vapor_cigar2alignstart_ops
+        res = np.zeros(2, dtype=np.int64)
+        res_p = res.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        out = []
+        for qname, pos, cig, sq, l_seq, _flag in self._open(bam).fetch_raw(chrom, int(start), int(end)):
+            if not pos < start + 1:
+                continue
+            ops = np.ascontiguousarray(cig, dtype=np.uint32)
+            rc = walk(ops.ctypes.data, len(ops), int(pos), int(start), res_p)
+            if rc != 0:
+                raise IndexError("string index out of range")  # what '' [1] raises in SF:331 for a record without CIGAR
+            q0, miss_bp = int(res[0]), int(res[1])
+            if not miss_bp > flank_length / 2:
+                seq = bamio._decode_seq(sq, l_seq) or "*"
+                tail = seq[q0:]
+                want = end - start - miss_bp
+                if len(tail) > want:
+                    out.append([tail[:want], miss_bp, qname])
+        return out
+
     def _fasta(self, ref: str) -> FaiFasta:
         fa = self._fa.get(ref)
         if fa is None:
@@ -270,6 +296,8 @@ def _cigar2alignstart_py(cigar: str, align_start: int, start: int, end: int):
 
 
 _cigar_out = None
+_cigar_ptr = None
+_cigar_fn = None
 
 
 def cigar2alignstart_by_pos(cigar: str, align_start: int, start: int, end: int):
@@ -278,15 +306,15 @@ def cigar2alignstart_by_pos(cigar: str, align_start: int, start: int, end: int):
     reference (N, H, P and X advance nothing, as in the reference).  Long-read CIGARs hold thousands of
     operations, so the walk is the library's host helper `vapor_cigar2alignstart` (a dozen times faster than the
     interpreter loop); `_cigar2alignstart_py` is the same in Python."""
-    global _cigar_out
-    import ctypes
-    import numpy as np
-    from . import _lib
-    lib = _lib.load()
+    global _cigar_out, _cigar_ptr, _cigar_fn
     if _cigar_out is None:
+        import ctypes
+        import numpy as np
+        from . import _lib
         _cigar_out = np.zeros(2, dtype=np.int64)
-    rc = lib.vapor_cigar2alignstart(cigar.encode("ascii", "replace"), int(align_start), int(start),
-                                    _cigar_out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        _cigar_ptr = _cigar_out.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))     # made once: a ctypes view per call costs more than the walk
+        _cigar_fn = _lib.load().vapor_cigar2alignstart
+    rc = _cigar_fn(cigar.encode("ascii", "replace"), int(align_start), int(start), _cigar_ptr)
     if rc != 0:
         raise IndexError("string index out of range")  # what '' [1] raises in SF:331
     return [int(_cigar_out[0]), int(_cigar_out[1])]
@@ -296,6 +324,8 @@ def chop_pacbio_read_by_pos(bam_in_new, chrom, start, end, flank_length):
     """SF:339-354."""
     out = []
     be = get_backend()
+    if hasattr(be, "chop"):
+        return be.chop(bam_in_new, chrom, start, end, flank_length)
     if hasattr(be, "records"):
         recs = be.records(bam_in_new, chrom, start, end)
     else:
