@@ -425,10 +425,13 @@ __device__ __forceinline__ unsigned long long win2(const uint32_t* plane, uint32
 
 // verify queued candidates [from, from+n), n <= 128, two per lane so that their LDS reads overlap.
 // item = local read position << 16 | entry slot.  The entry's k-mer is compared with the read k-mer in both
-// orientations.  Same-strand dots (about a third of the candidates) are compacted into the queue slots this
-// call has consumed, and 64 of them at a time decide whether they start a run, measure it and write the
-// records as one contiguous piece.  Reverse-complement dots are few outside inversions and are written as
-// single-dot records at once.  The counter moves once per piece: cnt += records | dots << 32.
+// orientations; a same-strand dot also decides, in the same step, whether it starts a run (the symbols just before
+// it differ, or it sits on a 32-aligned read position / the first usable allele position) and how long the run is
+// (XOR of the 32 symbols after the k-mer on both sides, ffs).  Everything a candidate needs - the symbol before the
+// k-mer, the k-mer, the 32 symbols after it - comes out of ONE group of LDS reads per side (the words from one word
+// before the k-mer's first word on), so a call is item -> entry -> windows -> one counter update -> stores: no
+// second pass over the dots.  Reverse-complement dots (few outside inversions) and all dots of pairs that cannot
+// form runs are single-dot records.  The counter moves once per call: cnt += records | dots << 32.
 template <int BPS, int K>
 __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
                                             const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
@@ -443,78 +446,95 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
     // Both candidates of a lane go through the same straight-line code (a lane without a second candidate
     // re-reads item 0 and masks the result): with a branch per candidate the LDS reads of the second would only
     // start when the first is done.
-    bool hit[4];                                   // q * 2 + orientation
+    bool same[2], rcm[2], head[2];
+    int len[2];
     uint32_t who[2];                               // il | e << 11
     uint32_t item[2], e[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) item[q] = myq[from + ((q * 64 + lane < n) ? q * 64 + lane : 0)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) e[q] = entries[item[q] & 0xFFFFu];
+    const int emin = max(0, off2 - ts);            // first allele position of this tile that may carry a dot
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t il = item[q] >> 16;
-        const KT kf = extract_key<BPS, K>(rbuf, il);
-        const KT a = extract_key<BPS, K>(tile, e[q]);
-        const KT kr = revcomp_key<BPS, K>(kf);
         const bool in = (q * 64 + lane < n) && ts + (int)e[q] >= off2;
-        hit[q * 2] = in && (a == kf);
-        hit[q * 2 + 1] = in && (a == kr);
         who[q] = il | (e[q] << 11);
+        len[q] = 1;
+        if (BPS == 2) {
+            // normalised streams: nr[] / na[] start at the k-mer's first symbol; word 0 of the raw windows is the word
+            // before the k-mer's first word (valid LDS even for positions below 16: the strips and the tile are preceded
+            // by other regions, and such a position never consults it)
+            constexpr int EW = (2 * K) / 32, ES = (2 * K) % 32;   // where the 64 symbols-after-the-k-mer bits start
+            constexpr int NN = EW + 3, NV = NN + 2;
+            const uint32_t shr = (il & 15u) * 2u, sha = (e[q] & 15u) * 2u;
+            const uint32_t* rp = rbuf + (int)(il >> 4) - 1;
+            const uint32_t* tp = tile + (int)(e[q] >> 4) - 1;
+            uint32_t rw[NV], tw[NV];
+#pragma unroll
+            for (int x = 0; x < NV; ++x) { rw[x] = rp[x]; tw[x] = tp[x]; }
+            uint32_t nr[NN], na[NN];
+#pragma unroll
+            for (int x = 0; x < NN; ++x) {
+                nr[x] = __builtin_amdgcn_alignbit(rw[x + 2], rw[x + 1], shr);
+                na[x] = __builtin_amdgcn_alignbit(tw[x + 2], tw[x + 1], sha);
+            }
+            KT kf, a;
+#pragma unroll
+            for (int x = 0; x < KT::NW; ++x) { kf.w[x] = nr[x]; a.w[x] = na[x]; }
+            kf.w[KT::NW - 1] &= KT::TOPMASK;
+            a.w[KT::NW - 1] &= KT::TOPMASK;
+            const KT kr = revcomp_key<BPS, K>(kf);
+            same[q] = in && (a == kf);
+            rcm[q] = in && (a == kr);
+            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
+            const uint32_t pr = shr ? (rw[1] >> (shr - 2u)) : (rw[0] >> 30), pa = sha ? (tw[1] >> (sha - 2u)) : (tw[0] >> 30);
+            const bool pred = (il & (VREC_MAX_LEN - 1)) && (int)e[q] > emin && ((pr ^ pa) & 3u) == 0u;
+            head[q] = same[q] && !(merge && pred);
+            if (merge) {
+                const uint32_t xl = (ES ? __builtin_amdgcn_alignbit(nr[EW + 1], nr[EW], ES) : nr[EW]) ^
+                                    (ES ? __builtin_amdgcn_alignbit(na[EW + 1], na[EW], ES) : na[EW]);
+                const uint32_t xh = (ES ? __builtin_amdgcn_alignbit(nr[EW + 2], nr[EW + 1], ES) : nr[EW + 1]) ^
+                                    (ES ? __builtin_amdgcn_alignbit(na[EW + 2], na[EW + 1], ES) : na[EW + 1]);
+                const unsigned long long x = ((unsigned long long)xh << 32) | xl;
+                const int ext = x ? ((__ffsll((long long)x) - 1) >> 1) : 32;
+                len[q] = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e[q]));
+            }
+        } else {
+            const KT kf = extract_key<BPS, K>(rbuf, il);
+            const KT a = extract_key<BPS, K>(tile, e[q]);
+            const KT kr = revcomp_key<BPS, K>(kf);
+            same[q] = in && (a == kf);
+            rcm[q] = in && (a == kr);
+            head[q] = same[q];
+        }
     }
-    const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]), m2 = __ballot(hit[2]), m3 = __ballot(hit[3]);
-    const uint32_t n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-    uint32_t dots = n0 + n1 + n2 + n3;             // not yet added to the counter
+    const unsigned long long ms0 = __ballot(same[0]), ms1 = __ballot(same[1]), mr0 = __ballot(rcm[0]), mr1 = __ballot(rcm[1]);
+    const uint32_t dots = __popcll(ms0) + __popcll(ms1) + __popcll(mr0) + __popcll(mr1);
     if (dots == 0) return;
+    const unsigned long long mh0 = __ballot(head[0]), mh1 = __ballot(head[1]);
+    const uint32_t nh0 = __popcll(mh0), nh1 = __popcll(mh1), nr0 = __popcll(mr0), nrec = nh0 + nh1 + nr0 + __popcll(mr1);
     auto rank = [&](unsigned long long m) {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
-    auto record = [&](uint32_t w, int len, uint32_t rc) -> unsigned long long {
-        const uint32_t il = w & 0x7FFu, e = (w >> 11) & 0x7FFFu;
-        return (unsigned long long)(((uint32_t)(ts + (int)e - off2) << 16) | (uint32_t)(cb + (int)il)) |
-               ((unsigned long long)len << 32) | ((unsigned long long)rc << 48);
+    auto record = [&](uint32_t w, int ln, uint32_t rc) -> unsigned long long {
+        const uint32_t il = w & 0x7FFu, ee = (w >> 11) & 0x7FFFu;
+        return (unsigned long long)(((uint32_t)(ts + (int)ee - off2) << 16) | (uint32_t)(cb + (int)il)) |
+               ((unsigned long long)ln << 32) | ((unsigned long long)rc << 48);
     };
-    uint32_t n_rc = n1 + n3;                        // reverse-complement records not yet written
-    const uint32_t r1 = rank(m1), r3 = n1 + rank(m3);
-    const uint32_t cnt = n0 + n2;                   // same-strand dots: at most 128, the slots [from, from+128) are free
-    uint32_t* stage = myq + from;
-    if (hit[0]) stage[rank(m0)] = who[0];
-    if (hit[2]) stage[n0 + rank(m2)] = who[1];
-    const int emin = max(0, off2 - ts);            // first allele position of this tile that may carry a dot
-    uint32_t c0 = 0;
-    do {
-        const bool act = c0 + (uint32_t)lane < cnt;
-        const uint32_t w = act ? stage[c0 + lane] : 0u;
-        bool head = act;
-        int len = 1;
-        if (BPS == 2 && merge) {
-            const uint32_t il = w & 0x7FFu, e = (w >> 11) & 0x7FFFu;
-            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
-            const bool pred = (il & (VREC_MAX_LEN - 1)) && (int)e > emin && sym2(rbuf, il ? il - 1u : 0u) == sym2(tile, e ? e - 1u : 0u);
-            head = act && !pred;
-            // length: the symbols after the k-mer, compared 32 at a time
-            const unsigned long long x = win2(rbuf, il + K) ^ win2(tile, e + K);
-            const int ext = x ? ((__ffsll((long long)x) - 1) >> 1) : 32;
-            len = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e));
-        }
-        const unsigned long long hm = __ballot(head);
-        const uint32_t nh = __popcll(hm);
-        if (nh + n_rc) {
-            unsigned long long old = 0;
-            if (lane == 0) old = atomicAdd(cnt_r, (unsigned long long)(nh + n_rc) | ((unsigned long long)dots << 32));
-            dots = 0;
-            uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
-            if (n_rc) {
-                if (hit[1] && base + r1 < cap) out[base + r1] = record(who[0], 1, 1u);
-                if (hit[3] && base + r3 < cap) out[base + r3] = record(who[1], 1, 1u);
-                base += n_rc;
-                n_rc = 0;
-            }
-            const uint32_t slot = base + rank(hm);
-            if (head && slot < cap) out[slot] = record(w, len, 0u);
-        }
-        c0 += 64;
-    } while (c0 < cnt);
-    if (dots && lane == 0) atomicAdd(cnt_r, (unsigned long long)dots << 32);   // a piece of continuation dots only
+    unsigned long long old = 0;
+    if (lane == 0) old = atomicAdd(cnt_r, (unsigned long long)nrec | ((unsigned long long)dots << 32));
+    if (nrec == 0) return;                         // a call of continuation dots only
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
+    uint32_t slot;
+    slot = base + rank(mh0);
+    if (head[0] && slot < cap) out[slot] = record(who[0], len[0], 0u);
+    slot = base + nh0 + rank(mh1);
+    if (head[1] && slot < cap) out[slot] = record(who[1], len[1], 0u);
+    slot = base + nh0 + nh1 + rank(mr0);
+    if (rcm[0] && slot < cap) out[slot] = record(who[0], 1, 1u);
+    slot = base + nh0 + nh1 + nr0 + rank(mr1);
+    if (rcm[1] && slot < cap) out[slot] = record(who[1], 1, 1u);
 }
 
 template <typename C, int BPS, int K>

@@ -5,6 +5,7 @@ Device memory stays inside libvapor_hip.so; numpy arrays cross the boundary.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -60,6 +61,7 @@ class SeqSet:
                                              L.ptr(flags, ctypes.c_uint8), L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
         del keep
         self._h = h
+        engine._live.add(self)
         self.n_exc = info[0::2][:self.n].copy()
         self.n_invalid = info[1::2][:self.n].copy()
 
@@ -85,6 +87,7 @@ class Plan:
         L.check(L.load().vapor_plan_create(engine._ctx, seqset._h, self.n, self.pairs.ctypes.data_as(ctypes.c_void_p),
                                            ctypes.byref(h)))
         self._h = h
+        engine._live.add(self)
         self.stats = np.zeros((max(self.n, 1), L.STATS_STRIDE), dtype=np.int64)
 
     def run(self) -> np.ndarray:
@@ -181,6 +184,7 @@ class Engine:
         self._ctx = ctypes.c_void_p()
         L.check(lib.vapor_init(device, ctypes.byref(self._ctx)))
         self.device = device
+        self._live = weakref.WeakSet()      # sequence sets and plans of this context: closed with it, plans first
 
     def set_param(self, name: str, value: int) -> None:
         L.check(L.load().vapor_set_param(self._ctx, name.encode(), int(value)))
@@ -240,6 +244,9 @@ class Engine:
 
     def close(self) -> None:
         if self._ctx:
+            live = list(self._live)
+            for obj in sorted(live, key=lambda o: isinstance(o, SeqSet)):
+                obj.close()
             L.load().vapor_destroy(self._ctx)
             self._ctx = None
 
