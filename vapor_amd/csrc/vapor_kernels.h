@@ -1601,11 +1601,14 @@ __global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ re
     const int r0 = locus_first[l], r1 = locus_first[l + 1];
     int n = 0, npos = 0, nnonpos = 0;
     double res = 0.0;
-    // numpy.add.reduce order for the mean of the positives (pairwise_sum, n <= 128): fewer than 8 values
-    // are added one by one; otherwise eight strided partial sums over the first n - n%8 values are combined
-    // as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the last n%8 values are added after that.  Exact for
-    // loci of up to 256 reads (the reference keeps at most 20, SF:1091); longer synthetic lists are summed
-    // chunk by chunk.
+    // numpy.add.reduce order for the mean of the positives (numpy's pairwise_sum): fewer than 8 values are added one
+    // by one; otherwise eight strided partial sums over the first n - n%8 values are combined as
+    // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the last n%8 values are added after that.  That is numpy's order for up
+    // to 128 values (its block size; above it numpy halves recursively), i.e. VaPoR_QS is bit-identical to np.mean for
+    // loci of up to 128 positive scores - the reference keeps at most 20 reads per locus (SF:1091), the 60-read
+    // loci of BASELINE's largest configuration are covered by tests/golden/deep_loci.json.gz.  Longer synthetic
+    // lists are summed in chunks of 256 reads (a few ulp from numpy); VaPoR_GT / GQ need at most 64 scored reads
+    // (the (k, l) table), beyond that the genotype falls back to 0/1 without a quality.
     for (int base = r0; base < r1; base += 256) {
         const int cnt = min(256, r1 - base);
         for (int t = lane; t < cnt; t += 64) {
