@@ -13,7 +13,11 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <map>
+#include <mutex>
+#include <set>
 #include <string>
+#include <thread>
 #include <array>
 #include <vector>
 
@@ -42,6 +46,27 @@ static int fail(int code, const std::string& msg)
             return fail(VAPOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
     } while (0)
 
+// ------------------------------------------------------------------------------------------
+// Device and pinned-host blocks are recycled inside a context: a caller that works through a sequence of batches
+// creates and destroys a sequence set and a plan per batch, and a dozen hipMalloc / hipHostMalloc / hipFree calls per
+// batch cost more than the batch's kernels.  Freed blocks go to a per-context free list (by capacity) and are handed
+// out again to requests of similar size; vapor_destroy releases them.  A set or plan that outlives its context
+// frees its blocks directly.
+struct BlockPool {
+    std::multimap<size_t, void*> free_dev, free_host;
+    std::map<const void*, size_t> cap_of;               // capacity of every block this pool has handed out or holds
+    size_t cached_dev = 0, cached_host = 0;
+};
+static std::mutex g_live_m;
+static std::set<const void*> g_live_ctx;
+
+static size_t pool_round(size_t bytes)
+{
+    if (bytes <= 256) return 256;
+    if (bytes < ((size_t)1 << 16)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+    return (bytes + 0xFFFF) & ~(size_t)0xFFFF;          // 64 KB steps above that
+}
+
 struct vapor_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -61,7 +86,53 @@ struct vapor_ctx {
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
     bool attrs_set = false;
+    BlockPool pool;
 };
+
+static bool ctx_alive(const vapor_ctx* c)
+{
+    std::lock_guard<std::mutex> g(g_live_m);
+    return g_live_ctx.count(c) != 0;
+}
+
+// one host thread per context (include/vapor_hip.h), so the lists themselves need no lock
+static hipError_t pool_alloc(vapor_ctx* c, void** out, size_t bytes, bool host)
+{
+    const size_t cap = pool_round(bytes);
+    auto& fl = host ? c->pool.free_host : c->pool.free_dev;
+    auto it = fl.lower_bound(cap);
+    if (it != fl.end() && it->first <= 2 * cap + ((size_t)1 << 20)) {
+        *out = it->second;
+        (host ? c->pool.cached_host : c->pool.cached_dev) -= it->first;
+        fl.erase(it);
+        return hipSuccess;
+    }
+    hipError_t e = host ? hipHostMalloc(out, cap) : hipMalloc(out, cap);
+    if (e == hipSuccess) c->pool.cap_of[*out] = cap;
+    return e;
+}
+static hipError_t dmalloc(vapor_ctx* c, void** out, size_t bytes) { return pool_alloc(c, out, bytes, false); }
+static hipError_t hmalloc(vapor_ctx* c, void** out, size_t bytes) { return pool_alloc(c, out, bytes, true); }
+
+static void pool_free(vapor_ctx* c, void* p, bool host)
+{
+    if (!p) return;
+    if (c && ctx_alive(c)) {
+        auto it = c->pool.cap_of.find(p);
+        if (it != c->pool.cap_of.end()) {
+            size_t& cached = host ? c->pool.cached_host : c->pool.cached_dev;
+            if (cached + it->second <= (host ? ((size_t)2 << 30) : ((size_t)16 << 30))) {
+                (host ? c->pool.free_host : c->pool.free_dev).emplace(it->second, p);
+                cached += it->second;
+                return;
+            }
+            c->pool.cap_of.erase(it);
+        }
+    }
+    if (host) (void)hipHostFree(p); else (void)hipFree(p);
+}
+static void dfree(vapor_ctx* c, void* p) { pool_free(c, p, false); }
+static void hfree(vapor_ctx* c, void* p) { pool_free(c, p, true); }
 
 struct vapor_seqset {
     vapor_ctx* ctx = nullptr;
@@ -168,6 +239,7 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(clean): ") + hipGetErrorString(e)); }
     c->own_stream = c->stream;
+    { std::lock_guard<std::mutex> g(g_live_m); g_live_ctx.insert(c); }
     *out = c;
     return VAPOR_OK;
 }
@@ -176,6 +248,10 @@ extern "C" int vapor_destroy(vapor_ctx* c)
 {
     if (!c) return VAPOR_OK;
     (void)hipSetDevice(c->device);
+    { std::lock_guard<std::mutex> g(g_live_m); g_live_ctx.erase(c); }
+    (void)hipDeviceSynchronize();
+    for (auto& b : c->pool.free_dev) (void)hipFree(b.second);
+    for (auto& b : c->pool.free_host) (void)hipHostFree(b.second);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     for (hipStream_t l : c->lane)
         if (l) (void)hipStreamDestroy(l);
@@ -211,10 +287,10 @@ extern "C" int vapor_seqset_destroy(vapor_seqset* s)
 {
     if (!s) return VAPOR_OK;
     (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_seqs);
-    (void)hipFree(s->d_p2);
-    (void)hipFree(s->d_e1);
-    (void)hipFree(s->d_x4);
+    dfree(s->ctx, s->d_seqs);
+    dfree(s->ctx, s->d_p2);
+    dfree(s->ctx, s->d_e1);
+    dfree(s->ctx, s->d_x4);
     delete s;
     return VAPOR_OK;
 }
@@ -271,18 +347,40 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         uint32_t* h_map = reinterpret_cast<uint32_t*>(ctx->h_stage + n_asc * 32);
         uint8_t* d_asc = ctx->d_stage;
         uint32_t* d_map = reinterpret_cast<uint32_t*>(ctx->d_stage + n_asc * 32);
-        for (int32_t i = 0; i < n_seqs; ++i) {
-            const SeqDesc& d = s->h[i];
-            size_t ch = ((size_t)d.len + 31) / 32;
-            uint8_t* dst = h_asc + (size_t)d.asc0 * 32;
-            if (d.len) memcpy(dst, src(i), (size_t)d.len);
-            memset(dst + d.len, 0, ch * 32 - (size_t)d.len);
-            for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
+        // the copy into the pinned staging buffer is the largest part of an upload (a core moves ~8 GB/s, the link
+        // 50): split the sequences over a few host threads when there is enough to copy
+        auto stage_range = [&](int32_t i0, int32_t i1) {
+            for (int32_t i = i0; i < i1; ++i) {
+                const SeqDesc& d = s->h[i];
+                size_t ch = ((size_t)d.len + 31) / 32;
+                uint8_t* dst = h_asc + (size_t)d.asc0 * 32;
+                if (d.len) memcpy(dst, src(i), (size_t)d.len);
+                memset(dst + d.len, 0, ch * 32 - (size_t)d.len);
+                for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
+            }
+        };
+        const int n_thr = (n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? 4 : 1;
+        if (n_thr == 1) {
+            stage_range(0, n_seqs);
+        } else {
+            // cut at equal shares of the bytes
+            std::vector<int32_t> cut(1, 0);
+            for (int t = 1; t < n_thr; ++t) {
+                const uint32_t want = (uint32_t)(n_asc * (size_t)t / (size_t)n_thr);
+                int32_t i = cut.back();
+                while (i < n_seqs && s->h[i].asc0 < want) ++i;
+                cut.push_back(i);
+            }
+            cut.push_back(n_seqs);
+            std::vector<std::thread> th;
+            for (int t = 1; t < n_thr; ++t) th.emplace_back(stage_range, cut[(size_t)t], cut[(size_t)t + 1]);
+            stage_range(cut[0], cut[1]);
+            for (auto& x : th) x.join();
         }
-        SS_CHK(hipMalloc((void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
-        SS_CHK(hipMalloc((void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
-        SS_CHK(hipMalloc((void**)&s->d_e1, pl * sizeof(uint32_t)));
-        SS_CHK(hipMalloc((void**)&s->d_x4, pl * 4 * sizeof(uint32_t)));
+        SS_CHK(dmalloc(ctx, (void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
+        SS_CHK(dmalloc(ctx, (void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
+        SS_CHK(dmalloc(ctx, (void**)&s->d_e1, pl * sizeof(uint32_t)));
+        SS_CHK(dmalloc(ctx, (void**)&s->d_x4, pl * 4 * sizeof(uint32_t)));
         SS_CHK(hipMemsetAsync(s->d_p2, 0, pl * 2 * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemsetAsync(s->d_e1, 0, pl * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
@@ -330,35 +428,36 @@ extern "C" int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n_seqs, const ui
 // ------------------------------------------------------------------------------------------
 static void plan_free_device(vapor_plan* p)
 {
-    (void)hipFree(p->d_pairs); p->d_pairs = nullptr;
-    (void)hipFree(p->d_tasks); p->d_tasks = nullptr;
-    (void)hipFree(p->d_task_pairs); p->d_task_pairs = nullptr;
-    (void)hipFree(p->d_hits); p->d_hits = nullptr;
-    (void)hipFree(p->d_hflags); p->d_hflags = nullptr;
-    (void)hipFree(p->d_nhits); p->d_nhits = nullptr;
-    (void)hipFree(p->d_stats); p->d_stats = nullptr;
-    (void)hipFree(p->d_reads); p->d_reads = nullptr;
-    (void)hipFree(p->d_locus_first); p->d_locus_first = nullptr;
-    (void)hipFree(p->d_gt); p->d_gt = nullptr;
-    (void)hipFree(p->d_read_scores); p->d_read_scores = nullptr;
-    (void)hipFree(p->d_loci); p->d_loci = nullptr;
+    dfree(p->ctx, p->d_pairs); p->d_pairs = nullptr;
+    dfree(p->ctx, p->d_tasks); p->d_tasks = nullptr;
+    dfree(p->ctx, p->d_task_pairs); p->d_task_pairs = nullptr;
+    dfree(p->ctx, p->d_hits); p->d_hits = nullptr;
+    dfree(p->ctx, p->d_hflags); p->d_hflags = nullptr;
+    dfree(p->ctx, p->d_nhits); p->d_nhits = nullptr;
+    dfree(p->ctx, p->d_stats); p->d_stats = nullptr;
+    dfree(p->ctx, p->d_reads); p->d_reads = nullptr;
+    dfree(p->ctx, p->d_locus_first); p->d_locus_first = nullptr;
+    dfree(p->ctx, p->d_gt); p->d_gt = nullptr;
+    dfree(p->ctx, p->d_read_scores); p->d_read_scores = nullptr;
+    dfree(p->ctx, p->d_loci); p->d_loci = nullptr;
 }
 
 extern "C" int vapor_plan_destroy(vapor_plan* p)
 {
     if (!p) return VAPOR_OK;
     (void)hipSetDevice(p->device);
+    if (p->ring_n > 0 && p->lane && ctx_alive(p->ctx)) (void)hipStreamSynchronize(p->lane);   // steps in flight use the blocks
     plan_free_device(p);
-    if (p->h_stats) (void)hipHostFree(p->h_stats);
-    if (p->h_overflow) (void)hipHostFree(p->h_overflow);
-    (void)hipFree(p->d_overflow);
-    (void)hipFree(p->d_big_list);
+    hfree(p->ctx, p->h_stats);
+    hfree(p->ctx, p->h_overflow);
+    dfree(p->ctx, p->d_overflow);
+    dfree(p->ctx, p->d_big_list);
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& r : p->ring)
         for (auto& e : r)
             if (e) (void)hipEventDestroy(e);
-    if (p->h_loci) (void)hipHostFree(p->h_loci);
+    hfree(p->ctx, p->h_loci);
     for (auto& e : p->ev_f)
         if (e) (void)hipEventDestroy(e);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
@@ -381,10 +480,11 @@ static int plan_alloc_hits(vapor_plan* p)
         tot += (int64_t)((d.cap + 3u) & ~3u);
     }
     tot += 4;
-    (void)hipFree(p->d_hits); p->d_hits = nullptr;
-    (void)hipFree(p->d_hflags); p->d_hflags = nullptr;
-    HIPCHK(hipMalloc((void**)&p->d_hits, (size_t)tot * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void**)&p->d_hflags, (size_t)tot));
+    HIPCHK(hipStreamSynchronize(p->ctx->stream));      // (a rerun: nothing may still read the old slots when they are reused)
+    dfree(p->ctx, p->d_hits); p->d_hits = nullptr;
+    dfree(p->ctx, p->d_hflags); p->d_hflags = nullptr;
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_hits, (size_t)tot * sizeof(unsigned long long)));
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_hflags, (size_t)tot));
     p->total_cap = tot;
     HIPCHK(hipMemcpyAsync(p->d_pairs, p->hp.data(), sizeof(DPair) * p->hp.size(), hipMemcpyHostToDevice, p->ctx->stream));
     return VAPOR_OK;
@@ -511,17 +611,17 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     auto chk = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
-    chk(hipMalloc((void**)&p->d_pairs, sizeof(DPair) * p->hp.size()), "hipMalloc pairs");
-    chk(hipMalloc((void**)&p->d_tasks, sizeof(DTask) * std::max<size_t>(p->tasks.size(), 1)), "hipMalloc tasks");
-    chk(hipMalloc((void**)&p->d_task_pairs, sizeof(int32_t) * std::max<size_t>(order.size(), 1)), "hipMalloc task_pairs");
-    chk(hipMalloc((void**)&p->d_nhits, sizeof(unsigned long long) * p->hp.size()), "hipMalloc nhits");
+    chk(dmalloc(ctx, (void**)&p->d_pairs, sizeof(DPair) * p->hp.size()), "hipMalloc pairs");
+    chk(dmalloc(ctx, (void**)&p->d_tasks, sizeof(DTask) * std::max<size_t>(p->tasks.size(), 1)), "hipMalloc tasks");
+    chk(dmalloc(ctx, (void**)&p->d_task_pairs, sizeof(int32_t) * std::max<size_t>(order.size(), 1)), "hipMalloc task_pairs");
+    chk(dmalloc(ctx, (void**)&p->d_nhits, sizeof(unsigned long long) * p->hp.size()), "hipMalloc nhits");
     if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_nhits, 0, sizeof(unsigned long long) * p->hp.size(), ctx->stream), "memset nhits");
-    chk(hipMalloc((void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
-    chk(hipHostMalloc((void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
-    chk(hipMalloc((void**)&p->d_overflow, 4 * sizeof(unsigned int)), "hipMalloc overflow");
+    chk(dmalloc(ctx, (void**)&p->d_stats, sizeof(long long) * 16 * p->hp.size()), "hipMalloc stats");
+    chk(hmalloc(ctx, (void**)&p->h_stats, sizeof(long long) * 16 * p->hp.size()), "hipHostMalloc stats");
+    chk(dmalloc(ctx, (void**)&p->d_overflow, 4 * sizeof(unsigned int)), "hipMalloc overflow");
     if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_overflow, 0, 4 * sizeof(unsigned int), ctx->stream), "memset overflow");
-    chk(hipMalloc((void**)&p->d_big_list, sizeof(int32_t) * p->hp.size()), "hipMalloc big list");
-    chk(hipHostMalloc((void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
+    chk(dmalloc(ctx, (void**)&p->d_big_list, sizeof(int32_t) * p->hp.size()), "hipMalloc big list");
+    chk(hmalloc(ctx, (void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
     chk(hipEventCreate(&p->ev_t0), "hipEventCreate");
@@ -748,11 +848,12 @@ extern "C" int vapor_plan_fetch_hits(vapor_plan* p, int64_t n_sel, const int64_t
         if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
     hipStream_t st = p->ctx->stream;
-    chk(hipMalloc((void**)&d_sel, sizeof(long long) * sel.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_off, sizeof(long long) * off.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_nrec, sizeof(long long) * nrec.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_ji, sizeof(int32_t) * 2 * (size_t)off[n_sel]), "hipMalloc");
-    if (hit_flags) chk(hipMalloc((void**)&d_fl, (size_t)off[n_sel]), "hipMalloc");
+    vapor_ctx* ctx = p->ctx;
+    chk(dmalloc(ctx, (void**)&d_sel, sizeof(long long) * sel.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_off, sizeof(long long) * off.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_nrec, sizeof(long long) * nrec.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_ji, sizeof(int32_t) * 2 * (size_t)off[n_sel]), "hipMalloc");
+    if (hit_flags) chk(dmalloc(ctx, (void**)&d_fl, (size_t)off[n_sel]), "hipMalloc");
     if (rc == VAPOR_OK) {
         chk(hipMemcpyAsync(d_sel, sel.data(), sizeof(long long) * sel.size(), hipMemcpyHostToDevice, st), "copy");
         chk(hipMemcpyAsync(d_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, st), "copy");
@@ -766,7 +867,7 @@ extern "C" int vapor_plan_fetch_hits(vapor_plan* p, int64_t n_sel, const int64_t
         if (hit_flags) chk(hipMemcpyAsync(hit_flags, d_fl, (size_t)off[n_sel], hipMemcpyDeviceToHost, st), "copy");
         chk(hipStreamSynchronize(st), "sync");
     }
-    (void)hipFree(d_sel); (void)hipFree(d_off); (void)hipFree(d_nrec); (void)hipFree(d_ji); (void)hipFree(d_fl);
+    dfree(ctx, d_sel); dfree(ctx, d_off); dfree(ctx, d_nrec); dfree(ctx, d_ji); dfree(ctx, d_fl);
     return rc;
 }
 
@@ -865,13 +966,13 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         if (e != hipSuccess && rc == VAPOR_OK) rc = fail(VAPOR_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     };
     hipStream_t st = ctx->stream;
-    chk(hipMalloc((void**)&d_ov, 4 * sizeof(unsigned int)), "hipMalloc");
-    chk(hipMalloc((void**)&d_big, sizeof(int32_t) * dp.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_dp, sizeof(DPair) * dp.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_nh, sizeof(unsigned long long) * nh.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_hits, sizeof(unsigned long long) * packed.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_fl, packed.size()), "hipMalloc");
-    chk(hipMalloc((void**)&d_st, sizeof(long long) * 16 * (size_t)n_lists), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_ov, 4 * sizeof(unsigned int)), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_big, sizeof(int32_t) * dp.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_dp, sizeof(DPair) * dp.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_nh, sizeof(unsigned long long) * nh.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_hits, sizeof(unsigned long long) * packed.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_fl, packed.size()), "hipMalloc");
+    chk(dmalloc(ctx, (void**)&d_st, sizeof(long long) * 16 * (size_t)n_lists), "hipMalloc");
     if (rc == VAPOR_OK) {
         chk(hipMemsetAsync(d_ov, 0, 4 * sizeof(unsigned int), st), "memset");
         chk(hipMemcpyAsync(d_dp, dp.data(), sizeof(DPair) * dp.size(), hipMemcpyHostToDevice, st), "copy");
@@ -893,7 +994,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         if (!fl.empty() && rc == VAPOR_OK)
             for (int64_t t = 0; t < n_lists; ++t) memcpy(hit_flags + off[t], fl.data() + poff[t], (size_t)(off[t + 1] - off[t]));
     }
-    (void)hipFree(d_ov); (void)hipFree(d_big); (void)hipFree(d_dp); (void)hipFree(d_nh); (void)hipFree(d_hits); (void)hipFree(d_fl); (void)hipFree(d_st);
+    dfree(ctx, d_ov); dfree(ctx, d_big); dfree(ctx, d_dp); dfree(ctx, d_nh); dfree(ctx, d_hits); dfree(ctx, d_fl); dfree(ctx, d_st);
     return rc;
 }
 
@@ -919,13 +1020,13 @@ extern "C" int vapor_plan_set_reads(vapor_plan* p, int64_t n_reads, const vapor_
         first[(size_t)x.locus + 1]++;
     }
     for (int64_t l = 0; l < n_loci; ++l) first[l + 1] += first[l];
-    (void)hipFree(p->d_reads); (void)hipFree(p->d_locus_first); (void)hipFree(p->d_gt); (void)hipFree(p->d_read_scores); (void)hipFree(p->d_loci);
+    dfree(p->ctx, p->d_reads); dfree(p->ctx, p->d_locus_first); dfree(p->ctx, p->d_gt); dfree(p->ctx, p->d_read_scores); dfree(p->ctx, p->d_loci);
     p->d_reads = nullptr; p->d_locus_first = nullptr; p->d_gt = nullptr; p->d_read_scores = nullptr; p->d_loci = nullptr;
-    HIPCHK(hipMalloc((void**)&p->d_reads, sizeof(DRead) * std::max<int64_t>(n_reads, 1)));
-    HIPCHK(hipMalloc((void**)&p->d_locus_first, sizeof(int32_t) * first.size()));
-    HIPCHK(hipMalloc((void**)&p->d_gt, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N));
-    HIPCHK(hipMalloc((void**)&p->d_read_scores, sizeof(double) * std::max<int64_t>(n_reads, 1)));
-    HIPCHK(hipMalloc((void**)&p->d_loci, sizeof(double) * 8 * std::max<int64_t>(n_loci, 1)));
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_reads, sizeof(DRead) * std::max<int64_t>(n_reads, 1)));
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_locus_first, sizeof(int32_t) * first.size()));
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_gt, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N));
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_read_scores, sizeof(double) * std::max<int64_t>(n_reads, 1)));
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_loci, sizeof(double) * 8 * std::max<int64_t>(n_loci, 1)));
     if (n_reads) HIPCHK(hipMemcpy(p->d_reads, reads, sizeof(DRead) * n_reads, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_locus_first, first.data(), sizeof(int32_t) * first.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_gt, gt_table, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N, hipMemcpyHostToDevice));
@@ -1116,7 +1217,7 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
         p->ring.resize(ASYNC_RING);
         for (auto& r : p->ring)
             for (auto& e : r) { e = nullptr; HIPCHK(hipEventCreate(&e)); }
-        HIPCHK(hipHostMalloc((void**)&p->h_loci, sizeof(double) * 8 * (size_t)std::max<int64_t>(p->n_loci, 1)));
+        HIPCHK(hmalloc(p->ctx, (void**)&p->h_loci, sizeof(double) * 8 * (size_t)std::max<int64_t>(p->n_loci, 1)));
         HIPCHK(hipEventCreateWithFlags(&p->ev_last, hipEventDisableTiming));
     }
     if (p->have_after) {                        // vapor_plan_after: what the caller enqueued elsewhere comes first
