@@ -706,13 +706,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                         const uint32_t* src = rplane + (((size_t)cb * BPS) >> 5);
                         for (int x = lane; x < rbuf_words<BPS>(); x += 64) rbuf[x] = x < nw ? src[x] : 0u;
                     }
-                    unsigned long long EE = 0;                     // exception bits of positions i0 .. i0+63
+                    // which of the lane's 16 positions are looked up at all: those inside the read and, for a read with
+                    // symbols outside upper-case ACGT, those whose k-mer holds none (decided once per strip, so that the
+                    // position loop carries one mask bit instead of the 64-bit exception window)
                     const int i0 = cb + 16 * lane;
+                    uint32_t vmask = (1u << min(max(nk1 - i0, 0), 16)) - 1u;
                     if (exc1 && i0 < nk1) {
                         const uint32_t wi = (uint32_t)i0 >> 5, sh = (uint32_t)i0 & 31u;
                         const uint32_t e0 = re[wi], e1w = re[wi + 1], e2w = re[wi + 2];
-                        EE = ((unsigned long long)__builtin_amdgcn_alignbit(e2w, e1w, sh) << 32) |
-                             __builtin_amdgcn_alignbit(e1w, e0, sh);
+                        const unsigned long long EE = ((unsigned long long)__builtin_amdgcn_alignbit(e2w, e1w, sh) << 32) |
+                                                      __builtin_amdgcn_alignbit(e1w, e0, sh);   // exception bits of i0 .. i0+63
+                        constexpr unsigned long long KM = (1ULL << K) - 1ULL;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            if (((EE >> t) & KM) != 0ULL) vmask &= ~(1u << t);
                     }
                     int qlen = 0;                                  // queued candidates (wave-uniform)
                     // lane owns the 16 consecutive positions i0 .. i0+15: its window of the strip
@@ -749,11 +756,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                 kr.w[0] = (kr.w[0] << BPS) | cs;
                                 kr.w[KT::NW - 1] &= KT::TOPMASK;
                             }
-                            bool valid = (i0 + t) < nk1;
-                            if (exc1) {
-                                constexpr unsigned long long KM = (1ULL << K) - 1ULL;
-                                valid = valid && (((EE >> t) & KM) == 0ULL);
-                            }
                             const uint32_t hx = canon_hash<BPS, K>(kf, kr);
                             const uint32_t h = hx >> (32 - JNB_LOG2), fb = hx >> (32 - C::FILT_LOG2);
                             // unconditional reads and an arithmetic mask: a predicated read would put a wait
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             // (bitwise, not `&&`: with a short-circuit the compiler sinks the filter read into the branch on
                             // `valid` and waits for it there, one LDS round trip per position instead of one per four)
                             const uint32_t s0 = start16[h], s1v = start16[h + 1], fw = filt[fb >> 5];
-                            const uint32_t take = (uint32_t)valid & (fw >> (fb & 31u)) & 1u;
+                            const uint32_t take = (vmask >> t) & (fw >> (fb & 31u)) & 1u;
                             sc[t4] = (s0 | ((s1v - s0) << 16)) & (0u - take);
 #ifdef VAPOR_ABL_NOCAND
                             sc[t4] &= 0xFFFFu;
