@@ -435,12 +435,16 @@ __device__ __forceinline__ unsigned long long win2(const uint32_t* plane, uint32
 // before the k-mer's first word on), so a call is item -> entry -> windows -> one counter update -> stores: no
 // second pass over the dots.  Reverse-complement dots (few outside inversions) and all dots of pairs that cannot
 // form runs are single-dot records.  The counter moves once per call: cnt += records | dots << 32.
-template <int BPS, int K>
-__device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
-                                            const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
-                                            int nk1, bool merge, unsigned long long* cnt_r, uint32_t cap,
-                                            unsigned long long* out)
+// MERGE (runs are formed: 2-bit planes, no exception symbol on either side) is a template parameter so that the body is
+// one straight line: with a (uniform) branch on it inside, the compiler reads the symbols after the k-mer in a second
+// round trip under that branch and does not start the second candidate's reads before the first is done.
+template <int BPS, int K, bool MERGE>
+__device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, const uint16_t* entries,
+                                              const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
+                                              int nk1, unsigned long long* cnt_r, uint32_t cap,
+                                              unsigned long long* out)
 {
+    constexpr bool merge = MERGE;
     using KT = KeyT<BPS, K>;
     const int lane = threadIdx.x & 63;
 #ifdef VAPOR_ABL_NOVERIFY
@@ -491,9 +495,12 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
             same[q] = in && (a == kf);
             rcm[q] = in && (a == kr);
             // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
+            // (bitwise on purpose: with `&&` the compiler sinks the reads of word 0 into a branch on the first operand
+            // and waits for them there - a second LDS round trip per candidate)
             const uint32_t pr = shr ? (rw[1] >> (shr - 2u)) : (rw[0] >> 30), pa = sha ? (tw[1] >> (sha - 2u)) : (tw[0] >> 30);
-            const bool pred = (il & (VREC_MAX_LEN - 1)) && (int)e[q] > emin && ((pr ^ pa) & 3u) == 0u;
-            head[q] = same[q] && !(merge && pred);
+            const uint32_t pred = (uint32_t)((il & (VREC_MAX_LEN - 1)) != 0u) & (uint32_t)((int)e[q] > emin) &
+                                  (uint32_t)(((pr ^ pa) & 3u) == 0u) & (uint32_t)merge;
+            head[q] = same[q] & (pred == 0u);
             if (merge) {
                 const uint32_t xl = (ES ? __builtin_amdgcn_alignbit(nr[EW + 1], nr[EW], ES) : nr[EW]) ^
                                     (ES ? __builtin_amdgcn_alignbit(na[EW + 1], na[EW], ES) : na[EW]);
@@ -538,6 +545,16 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
     if (rcm[0] && slot < cap) out[slot] = record(who[0], 1, 1u);
     slot = base + nh0 + nh1 + nr0 + rank(mr1);
     if (rcm[1] && slot < cap) out[slot] = record(who[1], 1, 1u);
+}
+
+template <int BPS, int K>
+__device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
+                                            const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
+                                            int nk1, bool merge, unsigned long long* cnt_r, uint32_t cap,
+                                            unsigned long long* out)
+{
+    if (BPS == 2 && merge) join_verify_t<BPS, K, true>(myq, from, n, entries, rbuf, tile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    else join_verify_t<BPS, K, false>(myq, from, n, entries, rbuf, tile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
 }
 
 template <typename C, int BPS, int K>
