@@ -264,6 +264,9 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
+                         # `achieved` / `frac` price the kernel's interval inside the timed region, where the other plan's
+                         # clean and finish kernels share the CUs with it; alone (the blocking run before the region) it is
+                         "frac_alone": round(alg_bytes / (res.alone["join_ms" if dom == "join_kernel" else "clean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          # what the kernel really moves and what really limits it
                          "record_bytes_per_launch": 8 * n_rec,
                          "traffic_gbs": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic and dom_ms > 0 else None,
