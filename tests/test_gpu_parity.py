@@ -410,3 +410,42 @@ def test_deep_loci_device_finish_vs_reference(eng):
             assert int(loci[li, 4]) == len(scores)
     plan.close()
     ss.close()
+
+
+def test_two_plans_in_flight_and_stream_ordering(eng):
+    """vapor_plan_run_loci_async on two plans (one library stream each), with a stream of the caller's ordered against
+    them by vapor_plan_then / vapor_plan_after: the records every pass leaves in the caller's buffers equal the
+    blocking run's, and vapor_plan_sync reports per-kernel times."""
+    import torch
+    from vapor_amd import workload as wl
+    ws = [wl.make_workload("tiny", seed=s, **wl.WORKLOADS["tiny"]) for s in (21, 22)]
+    sets = [eng.seqset(w.seqs) for w in ws]
+    plans, want, bufs = [], [], []
+    for w, ss in zip(ws, sets):
+        p = eng.plan(ss, w.pairs)
+        p.set_reads(wl.read_table(w), w.n_loci)
+        want.append(p.run_loci().copy())
+        plans.append(p)
+        bufs.append(torch.full((w.n_loci, 8), -1.0, dtype=torch.float64, device="cuda"))
+    mine = torch.cuda.Stream()
+    copies = []
+    for i in range(8):
+        p, b = plans[i % 2], bufs[i % 2]
+        p.run_loci_async(device_out=b.data_ptr())
+        p.then(mine.cuda_stream)                     # my stream reads the records after this pass ...
+        with torch.cuda.stream(mine):
+            copies.append((i % 2, b.clone()))
+            b.fill_(-2.0)                            # ... and scribbles over the buffer
+        p.after(mine.cuda_stream)                    # the plan's next pass overwrites it only after that
+    for p in plans:
+        p.sync()
+    torch.cuda.synchronize()
+    for k, c in copies:
+        got = c.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want[k])) and np.array_equal(got[~np.isnan(got)], want[k][~np.isnan(want[k])])
+    tm = plans[0].timings()
+    assert tm["join_ms"] > 0 and tm["clean_ms"] > 0
+    for p in plans:
+        p.close()
+    for ss in sets:
+        ss.close()
