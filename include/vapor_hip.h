@@ -214,6 +214,25 @@ int vapor_cigar2alignstart(const char* cigar, int64_t align_start, int64_t start
 /* the same over a BAM record's binary CIGAR (n_ops words, length << 4 | operation code in "MIDNSHP=X" order) */
 int vapor_cigar2alignstart_ops(const uint32_t* ops, int64_t n_ops, int64_t align_start, int64_t start, int64_t* out);
 
+/*
+ * Host helpers of the read extraction, no device involved: `samtools view bam chrom:start-end` piped into
+ * chop_pacbio_read_by_pos (SF:339-354), which the reference runs as a process per locus, for one region of an open
+ * BGZF/BAM file.  `chunks` are n_chunks (begin, end) virtual-offset pairs from the .bai index (the caller's lookup);
+ * their blocks are inflated by a few host threads, the records of reference `tid` walked in file order, each CIGAR
+ * walked in binary form to `start` (CG:B,I long CIGARs included), and the reads the reference would keep - alignment
+ * start <= start, miss_bp <= flank / 2, more than end - start - miss_bp bases left - are written as ASCII:
+ * read r is seq_out[meta[4r] .. + meta[4r+1]), meta[4r+2] = miss_bp, its name the C string at names_out + meta[4r+3].
+ * VAPOR_E_OVERFLOW with need[0..2] = bytes of sequence, bytes of names and reads required when a buffer is too small.
+ */
+typedef struct vapor_bam vapor_bam;
+int vapor_bam_open(const char* path, vapor_bam** bam);
+int vapor_bam_close(vapor_bam* bam);
+int vapor_bam_set_threads(vapor_bam* bam, int32_t n_threads);
+const char* vapor_bam_last_error(void);
+int vapor_bam_chop(vapor_bam* bam, int32_t tid, int64_t start, int64_t end, int64_t flank, int32_t n_chunks,
+                   const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
+                   int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need);
+
 #ifdef __cplusplus
 }
 #endif

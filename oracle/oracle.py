@@ -36,13 +36,16 @@ _TWIN = os.path.join(_HERE, "_build", "libvapor_cpu.so")
 
 def build_twin(force: bool = False) -> str:
     """libvapor_cpu.so: the C ABI of include/vapor_hip.h on this oracle (cpu_twin.cpp; test infrastructure)."""
+    # (vapor_bam.cpp: the BGZF/BAM host helper of the product library, plain C++ without device code, is part of the ABI)
+    bam = os.path.join(os.path.dirname(_HERE), "vapor_amd", "csrc", "vapor_bam.cpp")
     srcs = [os.path.join(_HERE, "cpu_twin.cpp"), os.path.join(_HERE, "vapor_oracle.c"),
-            os.path.join(os.path.dirname(_HERE), "include", "vapor_hip.h")]
+            os.path.join(os.path.dirname(_HERE), "include", "vapor_hip.h"), bam]
     if force or not os.path.exists(_TWIN) or any(os.path.getmtime(_TWIN) < os.path.getmtime(x) for x in srcs):
         os.makedirs(os.path.dirname(_TWIN), exist_ok=True)
         obj = os.path.join(_HERE, "_build", "vapor_oracle_twin.o")
         subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-c", "-o", obj, srcs[1]])
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", _TWIN, srcs[0], obj])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread",
+                               "-I" + os.path.join(os.path.dirname(_HERE), "include"), "-o", _TWIN, srcs[0], bam, obj, "-lz"])
     return _TWIN
 
 

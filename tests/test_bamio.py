@@ -201,3 +201,67 @@ def test_linear_index_bounds_every_query(tmp_path):
         b = a + int(rng.choice([1, 50, 3000, 40000]))
         exp = [r[0] for r in order if r[2] < b and r[2] + int(r[3][:-1]) > a - 1]
         assert [r[0] for r in bam.fetch_records("c", a, b)] == exp, (a, b)
+
+
+def _chop_both(path, queries):
+    """(native, python) results of chop_pacbio_read_by_pos for every (chrom, start, end, flank) query."""
+    be = seqio.InProcessBam()
+    nat = [be._open(path).chop_native(c, a, b, f) for c, a, b, f in queries]
+    py = [be.chop_python(path, c, a, b, f) for c, a, b, f in queries]
+    return nat, py
+
+
+def test_native_chop_equals_the_python_statement(tmp_path):
+    """vapor_bam_chop (threaded inflate, binary CIGAR walk, partial decode; vapor_amd/csrc/vapor_bam.cpp) against
+    seqio.InProcessBam.chop_python on: this module's writer with small blocks (records spanning several blocks), the
+    independent encoder's file (aux fields, unmapped read, several references, a 70 000-operation CIGAR in CG:B,I),
+    and reads whose CIGARs start with clips, insertions and deletions around the window start."""
+    rng = np.random.default_rng(31)
+    # 1. own writer, tiny blocks
+    contig = synth.random_dna(rng, 60000)
+    recs = []
+    for i in range(120):
+        n = int(rng.integers(300, 9000))
+        pos = int(rng.integers(0, 50000))
+        read, cg = synth.mutate(rng, contig[pos:pos + n])
+        pre = int(rng.integers(0, 30))
+        cigar = ("%dS" % pre if pre else "") + cg
+        recs.append(("m%d" % i, 0, pos, cigar, synth.random_dna(rng, pre) + read))
+    p1 = str(tmp_path / "own.bam")
+    bamio.write_bam(p1, [("c", 60000)], recs, block_size=1500)
+    q1 = []
+    for _ in range(60):
+        a = int(rng.integers(500, 52000)); w = int(rng.integers(50, 4000)); f = int(rng.choice([50, 200, 500]))
+        q1.append(("c", a - f, a + w + f, f))
+    nat, py = _chop_both(p1, q1)
+    assert nat == py and sum(len(x) for x in py) > 50
+    # 2. the independent encoder's file
+    refs = [("chrA", 200000), ("chrB", 90000)]
+    reads = []
+    for i in range(40):
+        tid = int(rng.integers(0, 2)); pos = int(rng.integers(0, 60000))
+        ops, seq_len = [], 0
+        for _ in range(int(rng.integers(1, 30))):
+            o = "MIDS=X"[int(rng.integers(0, 6))]; n = int(rng.integers(1, 400))
+            ops.append((n, o)); seq_len += n if o in "MIS=X" else 0
+        if seq_len == 0:
+            ops.append((5, "M")); seq_len = 5
+        seq = "".join("ACGTN"[j] for j in rng.integers(0, 5, seq_len))
+        reads.append(("q%d" % i, tid, pos, ops, seq, b"NMC\x05RGZgrp1\0" if i % 2 else b""))
+    n_ops = 70000
+    reads.append(("qlong", 0, 1000, [(1, "M") if j % 2 == 0 else (1, "I") for j in range(n_ops)], "ACGT" * (n_ops // 4), b"NMC\x01"))
+    reads.append(("qun", -1, -1, [], "ACGT", b""))
+    reads.sort(key=lambda r: (r[1] if r[1] >= 0 else 1 << 30, r[2]))
+    p2 = str(tmp_path / "ind.bam")
+    _encode_bam(p2, refs, reads)
+    q2 = [("chrA", 1001, 1400, 100), ("chrA", 20000, 26000, 500), ("chrB", 5000, 9000, 500), ("chrA", 1, 100000, 500),
+          ("chrB", 30000, 30100, 40), ("chrA", 1050, 1100, 20), ("chrZ", 1, 10, 5)]
+    nat, py = _chop_both(p2, q2)
+    assert nat == py
+    assert any(r[2] == "qlong" for r in nat[0]) or any(r[2] == "qlong" for r in nat[5])
+    # 3. buffers that have to grow: a region with many long reads
+    big = [("b%d" % i, 0, 100 + i, "30000M", "ACGT" * 7500) for i in range(300)]
+    p3 = str(tmp_path / "big.bam")
+    bamio.write_bam(p3, [("c", 60000)], big)
+    nat, py = _chop_both(p3, [("c", 500, 25000, 500)])
+    assert nat == py and len(nat[0]) == 300

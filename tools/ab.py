@@ -21,7 +21,7 @@ if "--build" in sys.argv:
         name, _, flags = spec.partition(":")
         cmd = [B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vapor_amd", "csrc"),
-               "-Wno-unused-function", "-o", so(name)] + [f for f in flags.split(",") if f] + B.SOURCES
+               "-Wno-unused-function", "-o", so(name)] + [f for f in flags.split(",") if f] + B.SOURCES + ["-lz"]
         subprocess.check_call(cmd)
         print("built", so(name))
     sys.exit(0)

@@ -36,6 +36,7 @@ EXPORTS = [
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
     "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync", "vapor_plan_then", "vapor_plan_after",
     "vapor_cigar2alignstart", "vapor_cigar2alignstart_ops",
+    "vapor_bam_open", "vapor_bam_close", "vapor_bam_set_threads", "vapor_bam_last_error", "vapor_bam_chop",
 ]
 
 _lib = None
@@ -87,6 +88,12 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_plan_after.argtypes = [vp, vp]
     L.vapor_cigar2alignstart.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, i64p]
     L.vapor_cigar2alignstart_ops.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, i64p]
+    L.vapor_bam_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.vapor_bam_close.argtypes = [vp]
+    L.vapor_bam_set_threads.argtypes = [vp, ctypes.c_int32]
+    L.vapor_bam_last_error.restype = ctypes.c_char_p
+    L.vapor_bam_chop.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp,
+                                 vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), vp]
     L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
     L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]
     L.vapor_dotplot_batch.argtypes = [vp, vp, ctypes.c_int64, vp, i32p, ctypes.c_int64, i64p, i64p]
@@ -96,7 +103,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_plan_set_reads.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, f64p]
     L.vapor_plan_run_loci.argtypes = [vp, vp, f64p, f64p]
     for name in EXPORTS:
-        if name not in ("vapor_last_error",):
+        if name not in ("vapor_last_error", "vapor_bam_last_error"):
             getattr(L, name).restype = ctypes.c_int
     return L
 

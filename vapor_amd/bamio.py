@@ -201,6 +201,7 @@ class BamFile:
             self.refs.append((name, l_ref))
             self.tid[name] = t
         self.first_record = c.tell()
+        self._native = None                 # vapor_bam handle of the HIP library's host helper (opened on first use)
         import os
         bai = path + ".bai" if os.path.exists(path + ".bai") else path[:-4] + ".bai"
         self.index = BaiIndex(bai)
@@ -242,6 +243,63 @@ class BamFile:
             if real is not None:
                 cig = real
         return ref_id, pos, name, flag, cig, l_seq, sq
+
+    def chop_native(self, chrom: str, start: int, end: int, flank_length: int):
+        """chop_pacbio_read_by_pos (SF:339-354) for one region through the library's native reader (vapor_bam_chop:
+        threaded inflate, binary CIGAR walk, only kept bases decoded); the .bai lookup stays here.  Returns the same
+        [[read tail, miss_bp, qname], ...] as the Python statement of it (seqio.InProcessBam.chop_python)."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        tid = self.tid.get(chrom)
+        if tid is None:
+            return []
+        if self._native is None:
+            h = ctypes.c_void_p()
+            if lib.vapor_bam_open(self.path.encode(), ctypes.byref(h)) != 0:
+                raise OSError(lib.vapor_bam_last_error().decode())
+            self._native = h
+            self._buf = {"seq": np.empty(1 << 20, dtype=np.uint8), "names": ctypes.create_string_buffer(1 << 16),
+                         "meta": np.empty(4 * 256, dtype=np.int64), "need": np.zeros(3, dtype=np.int64)}
+        ch = self.index.chunks(tid, max(int(start) - 1, 0), int(end))
+        if not ch:
+            return []
+        chunks = np.asarray(ch, dtype=np.uint64).reshape(-1)
+        n = ctypes.c_int32(0)
+        while True:
+            bf = self._buf
+            rc = lib.vapor_bam_chop(self._native, tid, int(start), int(end), int(flank_length), len(ch), chunks.ctypes.data,
+                                    bf["seq"].ctypes.data, bf["seq"].size, ctypes.cast(bf["names"], ctypes.c_void_p), len(bf["names"]),
+                                    bf["meta"].ctypes.data, bf["meta"].size // 4, ctypes.byref(n), bf["need"].ctypes.data)
+            if rc == 0:
+                break
+            if rc != _lib.E_OVERFLOW:
+                msg = lib.vapor_bam_last_error().decode()
+                if "IndexError" in msg:
+                    raise IndexError("string index out of range")      # what '' [1] raises in SF:331
+                raise ValueError(msg)
+            need = bf["need"]
+            self._buf = {"seq": np.empty(int(need[0]) * 2 + 1024, dtype=np.uint8),
+                         "names": ctypes.create_string_buffer(int(need[1]) * 2 + 256),
+                         "meta": np.empty(4 * (int(need[2]) * 2 + 16), dtype=np.int64), "need": need}
+        seq, meta, names = bf["seq"], bf["meta"], bf["names"].raw
+        out = []
+        for r in range(n.value):
+            o, ln, miss, no = (int(v) for v in meta[4 * r:4 * r + 4])
+            out.append([seq[o:o + ln].tobytes().decode("ascii"), miss, names[no:names.index(b"\0", no)].decode()])
+        return out
+
+    def close(self) -> None:
+        if self._native is not None:
+            from . import _lib
+            _lib.load().vapor_bam_close(self._native)
+            self._native = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
 
     def fetch_raw(self, chrom: str, start: int, end: int):
         """(QNAME, 1-based POS, CIGAR operations as a uint32 tuple, packed SEQ bytes, l_seq, FLAG) of the alignments

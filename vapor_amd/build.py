@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libvapor_hip.so")
-SOURCES = [os.path.join(HERE, "csrc", "vapor_hip.hip")]
+SOURCES = [os.path.join(HERE, "csrc", "vapor_hip.hip"), os.path.join(HERE, "csrc", "vapor_bam.cpp")]
 DEPS = SOURCES + [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(ROOT, "include", "vapor_hip.h")]
 
 
@@ -24,7 +24,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return SO
     cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
-           "-Wall", "-Wno-unused-function", "-o", SO] + SOURCES
+           "-Wall", "-Wno-unused-function", "-o", SO] + SOURCES + ["-lz"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

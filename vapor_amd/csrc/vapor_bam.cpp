@@ -1,0 +1,325 @@
+// vapor_bam.cpp - host side of the read extraction: `samtools view bam chrom:start-end` + chop_pacbio_read_by_pos
+// (SF:339-354) for one region, straight from a BGZF/BAM file.  No device code.
+//
+// The reference starts a samtools process per locus and parses its text; vapor_amd/bamio.py does the same work
+// in-process in Python (and stays the statement this file is tested against, tests/test_bamio.py); this is the native
+// form of its hot loop: the region's BGZF blocks are read with one pread, inflated by a few host threads (zlib),
+// the records of the wanted reference are walked in file order, each CIGAR is walked in its binary form up to the window
+// start (cigar2alignstart_by_pos, SF:309-337; the CG:B,I long-CIGAR convention included) and only the bases that are
+// kept are decoded.  The .bai lookup (bins, linear index) stays in Python: it is a few dictionary reads per locus.
+#include "vapor_hip.h"
+
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct vapor_bam {
+    int fd = -1;
+    std::string path;
+    int n_threads = 4;
+    // the blocks of the chunk being walked: `comp` holds the file bytes from `comp_base` on, `data` their inflated bytes
+    std::vector<uint8_t> comp, data;
+    int64_t comp_base = 0;
+    size_t scan_pos = 0;                // first byte of `comp` that is not part of a parsed block
+    std::vector<int64_t> blk_coff;      // compressed file offset of every block
+    std::vector<int64_t> blk_cpos;      // its position inside `comp`
+    std::vector<int32_t> blk_csize;     // whole block size (header .. trailer)
+    std::vector<int64_t> blk_ustart;    // where its inflated bytes start in `data`
+    std::vector<int32_t> blk_usize;
+};
+
+static thread_local std::string g_bam_err;
+extern "C" const char* vapor_bam_last_error(void) { return g_bam_err.c_str(); }
+static int bfail(int code, const std::string& m) { g_bam_err = m; return code; }
+
+extern "C" int vapor_bam_open(const char* path, vapor_bam** out)
+{
+    if (!path || !out) return bfail(VAPOR_E_ARG, "vapor_bam_open: null argument");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return bfail(VAPOR_E_ARG, std::string("vapor_bam_open: cannot open ") + path);
+    vapor_bam* b = new vapor_bam();
+    b->fd = fd;
+    b->path = path;
+    const unsigned hc = std::thread::hardware_concurrency();
+    b->n_threads = (int)std::max(1u, std::min(4u, hc ? hc / 2 : 1u));
+    *out = b;
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_bam_close(vapor_bam* b)
+{
+    if (b) {
+        if (b->fd >= 0) close(b->fd);
+        delete b;
+    }
+    return VAPOR_OK;
+}
+
+extern "C" int vapor_bam_set_threads(vapor_bam* b, int32_t n)
+{
+    if (!b || n < 1 || n > 64) return bfail(VAPOR_E_ARG, "vapor_bam_set_threads: out of range");
+    b->n_threads = n;
+    return VAPOR_OK;
+}
+
+// Parses the BGZF block headers from scan_pos on and appends the whole blocks found to the block lists (a truncated
+// last block is left for the next read); -1 when the bytes are not BGZF.
+static int scan_blocks(vapor_bam* b)
+{
+    int n = 0;
+    size_t p = b->scan_pos;
+    while (p + 18 <= b->comp.size()) {
+        const uint8_t* h = b->comp.data() + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return -1;
+        const int xlen = h[10] | (h[11] << 8);
+        if (p + 12 + (size_t)xlen > b->comp.size()) break;
+        int bsize = -1;
+        for (int q = 0; q + 4 <= xlen;) {
+            const uint8_t* e = h + 12 + q;
+            const int slen = e[2] | (e[3] << 8);
+            if (e[0] == 66 && e[1] == 67 && slen == 2) bsize = (e[4] | (e[5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 0) return -1;
+        if (p + (size_t)bsize > b->comp.size()) break;
+        const uint8_t* t = h + bsize - 4;
+        b->blk_coff.push_back(b->comp_base + (int64_t)p);
+        b->blk_cpos.push_back((int64_t)p);
+        b->blk_csize.push_back(bsize);
+        b->blk_usize.push_back((int32_t)(t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24)));
+        p += (size_t)bsize;
+        ++n;
+    }
+    b->scan_pos = p;
+    return n;
+}
+
+static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize)
+{
+    if (isize == 0) return true;
+    const int xlen = blk[10] | (blk[11] << 8);
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(blk + 12 + xlen);
+    zs.avail_in = (uInt)(bsize - xlen - 20);
+    zs.next_out = out;
+    zs.avail_out = (uInt)isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+// inflates blocks [b0, b1) into data (their ustart already laid out), a few threads when there are several
+static bool inflate_range(vapor_bam* b, size_t b0, size_t b1)
+{
+    const size_t n = b1 - b0;
+    const int nt = (int)std::min<size_t>((size_t)b->n_threads, n);
+    std::vector<char> ok((size_t)std::max(nt, 1), 1);
+    auto work = [&](int t) {
+        for (size_t i = b0 + (size_t)t; i < b1; i += (size_t)nt)
+            if (!inflate_block(b->comp.data() + b->blk_cpos[i], b->blk_csize[i], b->data.data() + b->blk_ustart[i], b->blk_usize[i])) ok[(size_t)t] = 0;
+    };
+    if (nt <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (char c : ok)
+        if (!c) return false;
+    return true;
+}
+
+// lays the newly scanned blocks [b0, ..) out behind the inflated bytes and inflates them
+static bool take_blocks(vapor_bam* b, size_t b0)
+{
+    int64_t u = (int64_t)b->data.size();
+    for (size_t i = b0; i < b->blk_coff.size(); ++i) { b->blk_ustart.push_back(u); u += b->blk_usize[i]; }
+    b->data.resize((size_t)u);
+    return inflate_range(b, b0, b->blk_coff.size());
+}
+
+// reads `bytes` more file bytes behind `comp`; false at end of file
+static bool read_more(vapor_bam* b, size_t bytes)
+{
+    const size_t old = b->comp.size();
+    b->comp.resize(old + bytes);
+    const ssize_t got = pread(b->fd, b->comp.data() + old, bytes, (off_t)(b->comp_base + (int64_t)old));
+    b->comp.resize(old + (size_t)std::max<ssize_t>(got, 0));
+    return got > 0;
+}
+
+// makes sure `data` holds at least `upto` inflated bytes (a record may run past the chunk's own blocks); false at the end
+// of the file or on bytes that are not BGZF
+static bool ensure(vapor_bam* b, int64_t upto)
+{
+    while ((int64_t)b->data.size() < upto) {
+        if (!read_more(b, (size_t)1 << 18)) return false;
+        const size_t b0 = b->blk_coff.size();
+        if (scan_blocks(b) < 0) return false;
+        if (b->blk_coff.size() == b0) continue;              // not even one whole block yet: read on
+        if (!take_blocks(b, b0)) return false;
+    }
+    return true;
+}
+
+static inline int32_t rd32(const uint8_t* p) { return (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)); }
+
+// the CG:B,I array of a record's aux fields, or null
+static const uint8_t* find_cg(const uint8_t* p, const uint8_t* end, int32_t* count)
+{
+    while (p + 3 <= end) {
+        const uint8_t t0 = p[0], t1 = p[1], ty = p[2];
+        p += 3;
+        int sz = 0;
+        switch (ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': { while (p < end && *p) ++p; ++p; continue; }
+        case 'B': {
+            if (p + 5 > end) return nullptr;
+            const uint8_t sub = p[0];
+            const int32_t cnt = rd32(p + 1);
+            p += 5;
+            const int es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') { *count = cnt; return p; }
+            p += (size_t)cnt * (size_t)es;
+            continue;
+        }
+        default: return nullptr;
+        }
+        p += sz;
+    }
+    return nullptr;
+}
+
+extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t end, int64_t flank, int32_t n_chunks,
+                              const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
+                              int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need)
+{
+    if (!b || !n_reads || (n_chunks && !chunks)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: null argument");
+    static const char* NT16 = "=ACMGRSVTWYHKDBN";
+    const int64_t beg = std::max<int64_t>(start - 1, 0), stop = end;     // 0-based half-open region
+    int64_t seq_used = 0, names_used = 0;
+    int32_t nr = 0;
+    bool overflow = false;
+    for (int32_t c = 0; c < n_chunks; ++c) {
+        const uint64_t cs = chunks[2 * c], ce = chunks[2 * c + 1];
+        // the chunk's own compressed range in one read, its blocks inflated together
+        b->comp.clear(); b->data.clear(); b->scan_pos = 0;
+        b->blk_coff.clear(); b->blk_cpos.clear(); b->blk_csize.clear(); b->blk_ustart.clear(); b->blk_usize.clear();
+        b->comp_base = (int64_t)(cs >> 16);
+        // through the block that holds the chunk's end (none of it when the chunk ends on a block boundary)
+        const size_t span = (size_t)((int64_t)(ce >> 16) - b->comp_base) + ((ce & 0xFFFFu) ? ((size_t)1 << 16) + 64 : 0);
+        if (span == 0 || !read_more(b, span)) continue;
+        if (scan_blocks(b) < 0) return bfail(VAPOR_E_ARG, "vapor_bam_chop: not a BGZF block in " + b->path);
+        if (!take_blocks(b, 0)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: inflate failed in " + b->path);
+        int64_t pos_u = (int64_t)(cs & 0xFFFF);                              // position in `data`
+        size_t blk = 0;
+        for (;;) {
+            // virtual offset of pos_u
+            // virtual offset of pos_u: inside a block that is here, or the start of the block that follows them - decided
+            // before anything more is read, so that the end of the chunk does not cost another read and inflate
+            uint64_t voff;
+            if (pos_u >= (int64_t)b->data.size()) {
+                if (b->blk_coff.empty()) break;
+                voff = (uint64_t)(b->blk_coff.back() + b->blk_csize.back()) << 16;
+            } else {
+                while (blk + 1 < b->blk_ustart.size() && pos_u >= b->blk_ustart[blk + 1]) ++blk;
+                voff = ((uint64_t)b->blk_coff[blk] << 16) | (uint64_t)(pos_u - b->blk_ustart[blk]);
+            }
+            if (voff >= ce) break;
+            if (!ensure(b, pos_u + 4)) break;
+            const int32_t bs = rd32(b->data.data() + pos_u);
+            if (bs < 32 || !ensure(b, pos_u + 4 + bs)) break;
+            const uint8_t* r = b->data.data() + pos_u + 4;
+            pos_u += 4 + bs;
+            const int32_t ref_id = rd32(r), pos = rd32(r + 4);
+            const int l_name = r[8];
+            const int n_cig = r[12] | (r[13] << 8);
+            const int32_t l_seq = rd32(r + 16);
+            if (ref_id != tid || pos >= stop) {
+                if (ref_id > tid || (ref_id == tid && pos >= stop)) break;
+                continue;
+            }
+            const uint8_t* name = r + 32;
+            const uint8_t* cig = name + l_name;
+            const uint8_t* sq = cig + 4 * n_cig;
+            const uint8_t* rec_end = r + bs;
+            const uint8_t* ops = cig;
+            int32_t n_ops = n_cig;
+            if (n_cig == 2) {
+                const uint32_t o0 = (uint32_t)rd32(cig), o1 = (uint32_t)rd32(cig + 4);
+                if ((o0 & 15u) == 4u && (int32_t)(o0 >> 4) == l_seq && (o1 & 15u) == 3u) {
+                    int32_t cnt = 0;
+                    const uint8_t* cg = find_cg(sq + (l_seq + 1) / 2 + l_seq, rec_end, &cnt);
+                    if (cg) { ops = cg; n_ops = cnt; }
+                }
+            }
+            // reference length; the region-overlap rule of `samtools view`
+            int64_t rlen = 0;
+            for (int32_t t = 0; t < n_ops; ++t) {
+                const uint32_t o = (uint32_t)rd32(ops + 4 * t), code = o & 15u;
+                if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) rlen += o >> 4;
+            }
+            if ((int64_t)pos + std::max<int64_t>(rlen, 1) <= beg) continue;
+            // chop_pacbio_read_by_pos: only alignments that start at or before the window start
+            if (!((int64_t)pos + 1 < start + 1)) continue;
+            if (n_ops <= 0) return bfail(VAPOR_E_ARG, "vapor_bam_chop: record without CIGAR (the reference raises IndexError, SF:331)");
+            int64_t q = 0, rr = (int64_t)pos + 1;
+            uint32_t last = 0;
+            for (int32_t t = 0; t < n_ops; ++t) {
+                const uint32_t o = (uint32_t)rd32(ops + 4 * t);
+                const int64_t n = o >> 4;
+                last = o & 15u;
+                if (last == 4u || last == 1u) q += n;
+                else if (last == 0u || last == 7u) { q += n; rr += n; }
+                else if (last == 2u) rr += n;
+                if (rr > start - 1) break;
+            }
+            const int64_t over = rr - start;
+            int64_t q0, miss;
+            if (last == 0u || last == 7u) { q0 = q - over; miss = 0; } else { q0 = q; miss = over; }
+            if (2 * miss > flank) continue;                                   // miss_bp > flank_length / 2
+            const int64_t seq_len = l_seq > 0 ? l_seq : 1;                    // an absent sequence reads "*"
+            const int64_t tail = q0 < seq_len ? seq_len - std::max<int64_t>(q0, 0) : 0;
+            const int64_t want_len = end - start - miss;
+            if (q0 < 0) return bfail(VAPOR_E_ARG, "vapor_bam_chop: negative read offset");
+            if (want_len < 0 || !(tail > want_len)) continue;
+            const int64_t nl = l_name > 0 ? l_name - 1 : 0;
+            if (nr >= max_reads || seq_used + want_len > seq_cap || names_used + nl + 1 > names_cap) {
+                overflow = true;
+                seq_used += want_len; names_used += nl + 1; ++nr;
+                continue;
+            }
+            uint8_t* dst = seq_out + seq_used;
+            if (l_seq > 0) {
+                for (int64_t t = 0; t < want_len; ++t) {
+                    const int64_t i = q0 + t;
+                    const uint8_t byte = sq[i >> 1];
+                    dst[t] = (uint8_t)NT16[(i & 1) ? (byte & 15) : (byte >> 4)];
+                }
+            } else if (want_len > 0) {
+                dst[0] = '*';
+            }
+            memcpy(names_out + names_used, name, (size_t)nl);
+            names_out[names_used + nl] = 0;
+            meta[4 * nr] = seq_used; meta[4 * nr + 1] = want_len; meta[4 * nr + 2] = miss; meta[4 * nr + 3] = names_used;
+            seq_used += want_len; names_used += nl + 1; ++nr;
+        }
+    }
+    *n_reads = nr;
+    if (need) { need[0] = seq_used; need[1] = names_used; need[2] = nr; }
+    if (overflow) return bfail(VAPOR_E_OVERFLOW, "vapor_bam_chop: output buffers too small");
+    return VAPOR_OK;
+}

@@ -132,8 +132,15 @@ class InProcessBam(SamtoolsHybrid):
         return [r[:4] for r in self._open(bam).fetch_records(chrom, int(start), int(end))]
 
     def chop(self, bam: str, chrom: str, start: int, end: int, flank_length: int):
-        """chop_pacbio_read_by_pos (SF:339-354) straight from the BAM records: the CIGAR is walked in its binary form
-        (the library's host helper) and only the reads that are kept have their bases decoded."""
+        """chop_pacbio_read_by_pos (SF:339-354) straight from the BAM file: the library's native reader
+        (vapor_bam_chop), or with VAPOR_BAM_NATIVE=0 the Python statement of the same steps below."""
+        if os.environ.get("VAPOR_BAM_NATIVE", "1") != "0":
+            return self._open(bam).chop_native(chrom, int(start), int(end), int(flank_length))
+        return self.chop_python(bam, chrom, start, end, flank_length)
+
+    def chop_python(self, bam: str, chrom: str, start: int, end: int, flank_length: int):
+        """The same from the records as Python parses them: the CIGAR is walked in its binary form (the library's
+        host helper) and only the reads that are kept have their bases decoded."""
         import ctypes
         import numpy as np
         from . import _lib, bamio
