@@ -1,0 +1,17 @@
+import os, sys, tempfile, time, cProfile, pstats
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+from vapor_amd import cli, pipeline, seqio, synth
+n = 600
+w = synth.make_world(seed=11, n_loci=n, svtypes=("DEL", "DEL", "INV", "INS"), span_range=(100, 4000), read_len=9500, n_reads=20)
+for c in w.reads:
+    w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+tmp = tempfile.mkdtemp()
+fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
+bed = os.path.join(tmp, "in.bed"); open(bed, "w").write(synth.bed_text(w))
+def run(tag):
+    return cli.main(["bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam, "--output-path", tmp + "/f", "--output-file", tmp + "/o%s.vapor" % tag, "--no-figures"])
+run("a")
+t0 = time.perf_counter(); run("b"); dt = time.perf_counter() - t0
+print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt))
+cProfile.run('run("c")', "/tmp/pf.prof")
+pstats.Stats("/tmp/pf.prof").sort_stats("tottime").print_stats(18)
