@@ -261,7 +261,10 @@ def main() -> None:
                           "device_total": round(avg["total_ms"], 4), "join_launches": launches,
                           "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)}},
             "upload_pack_s": round(res.upload_s, 4),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: what the counters say limits the kernel (profiles/r02_cfg2_util.json: no unit saturated, waves parked
+            # on LDS round trips and barriers).  achieved / peak / frac are still priced against the HBM roof the task
+            # names, with SURVEY 8d's algorithmic bytes; traffic_* use the bytes the kernel really moves.
+            "roofline": {"bound": "latency", "priced_against": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          # `achieved` / `frac` price the kernel's interval inside the timed region, where the other plan's
