@@ -45,14 +45,21 @@ for name, c in agg.items():
         if us:
             cyc = us * 1e-6 * 2.4e9                        # at the 2.4 GHz maximum clock: utilisations are lower bounds on idle time
             u["valu_issue_util_at_2_cycles_per_wave64_op"] = round(u["valu_wave_instructions"] * 2 / (1024 * cyc), 3)
+            # measured issue rates of the instruction classes these kernels are made of (tools/micro/valu_peak.hip,
+            # profiles/r02_valu_peak.txt, 4 and 8 waves per SIMD, cycles at 2.4 GHz): two-operand VOP1/VOP2 forms 2.4-2.6,
+            # three-operand VOP3 integer forms (v_alignbit, v_bfe, v_lshl_or, v_bcnt, v_mad_u32_u24, v_cndmask_e64 ...)
+            # 4.3-4.5, v_mul_lo_u32 about 6.  VOP3_SHARE = their share of the kernel's vector instructions (static count
+            # over the ISA of the k = 10 join: 1 238 of 3 180).
+            VOP2_CYC, VOP3_CYC, VOP3_SHARE = 2.5, 4.4, 0.39
+            u["valu_issue_util_at_measured_class_rates"] = round(u["valu_wave_instructions"] * (VOP3_SHARE * VOP3_CYC + (1 - VOP3_SHARE) * VOP2_CYC) / (1024 * cyc), 3)
             if "SQ_LDS_IDX_ACTIVE" in m:
                 u["lds_array_busy"] = round(m["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 3)
         if "SQ_LDS_IDX_ACTIVE" in m and m["SQ_LDS_IDX_ACTIVE"]:
             u["lds_bank_conflict_share_of_lds_cycles"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"], 3)
-        u["limit"] = ("latency: no unit is saturated (VALU issue, LDS array and fabric all well under half busy); the waves "
-                      "spend most of their time parked on LDS round trips and barriers at 4 waves per SIMD, which one "
-                      "159 KB table per CU fixes") if name == "join_kernel" else \
-                     "latency: workgroup start-up and dependent global/LDS round trips; no unit saturated"
+        u["limit"] = ("vector issue first (about 0.6 of what the unit sustains for this mix of two- and three-operand integer "
+                      "instructions, measured), then LDS round trips at 4 waves per SIMD (one 159 KB table per CU); LDS array "
+                      "under half busy, fabric traffic 2 % of HBM peak") if name == "join_kernel" else \
+                     "workgroup start-up and dependent global/LDS round trips; vector issue about 0.5 of what the unit sustains"
         util[name] = u
 if traffic:
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, workload)), "w"), indent=1)
