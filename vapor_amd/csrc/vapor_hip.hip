@@ -204,9 +204,18 @@ struct vapor_plan {
 extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION; }
 extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 
+#ifdef VAPOR_AB_DYN_LDS
+#define JOIN_DYN_LDS(BPS) (join_lds_bytes<JoinCfg, BPS>())
+#else
+#define JOIN_DYN_LDS(BPS) 0            // the join's LDS is a static array of the kernel
+#endif
+
 template <int BPS, int K>
 static hipError_t set_join_attr()
 {
+#ifndef VAPOR_AB_DYN_LDS
+    return hipSuccess;
+#endif
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinCfg, BPS, K>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<JoinCfg, BPS>());
 }
@@ -641,7 +650,7 @@ template <int BPS, int K>
 static void launch_join(vapor_plan* p, const Launch& L, bool first, hipStream_t st)
 {
     const vapor_seqset* s = p->set;
-    hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), (join_lds_bytes<JoinCfg, BPS>()),
+    hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
                        st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
                        p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }

@@ -453,8 +453,12 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     // Both candidates of a lane go through the same straight-line code (a lane without a second candidate
     // re-reads item 0 and masks the result): with a branch per candidate the LDS reads of the second would only
     // start when the first is done.
+    // (for the 2-bit planes the three verdicts of a candidate are kept as integers that are ZERO when true - differences
+    // OR-ed with all-ones masks from sign shifts - so that each wave vote is one v_cmp_eq: a vote on a boolean that is
+    // the AND of several compares costs a select and a second compare on top of them, and those issue alone)
     bool same[2], rcm[2], head[2];
     int len[2];
+    const uint32_t out0 = (uint32_t)((lane - n) >> 31), out1 = (uint32_t)((lane + 64 - n) >> 31);   // ~0 if the slot is filled
     uint32_t who[2];                               // il | e << 11
     uint32_t item[2], e[2];
 #pragma unroll
@@ -492,15 +496,31 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
             kf.w[KT::NW - 1] &= KT::TOPMASK;
             a.w[KT::NW - 1] &= KT::TOPMASK;
             const KT kr = revcomp_key<BPS, K>(kf);
+#ifdef VAPOR_AB_BOOLVOTE
             same[q] = in && (a == kf);
             rcm[q] = in && (a == kr);
-            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
-            // (bitwise on purpose: with `&&` the compiler sinks the reads of word 0 into a branch on the first operand
-            // and waits for them there - a second LDS round trip per candidate)
             const uint32_t pr = shr ? (rw[1] >> (shr - 2u)) : (rw[0] >> 30), pa = sha ? (tw[1] >> (sha - 2u)) : (tw[0] >> 30);
             const uint32_t pred = (uint32_t)((il & (VREC_MAX_LEN - 1)) != 0u) & (uint32_t)((int)e[q] > emin) &
                                   (uint32_t)(((pr ^ pa) & 3u) == 0u) & (uint32_t)merge;
             head[q] = same[q] & (pred == 0u);
+#else
+            (void)in;
+            // not a candidate at all: an empty slot of the call, or an allele position before the pair's window
+            const uint32_t notin = ~(q ? out1 : out0) | (uint32_t)(((int)e[q] - (off2 - ts)) >> 31);
+            uint32_t df = notin, dr = notin;
+#pragma unroll
+            for (int x = 0; x < KT::NW; ++x) { df |= a.w[x] ^ kf.w[x]; dr |= a.w[x] ^ kr.w[x]; }
+            same[q] = df == 0u;
+            rcm[q] = dr == 0u;
+            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
+            // (no `&&` anywhere: with a short-circuit the compiler sinks the reads of word 0 into a branch on the first
+            // operand and waits for them there - a second LDS round trip per candidate)
+            const uint32_t pr = shr ? (rw[1] >> (shr - 2u)) : (rw[0] >> 30), pa = sha ? (tw[1] >> (sha - 2u)) : (tw[0] >> 30);
+            const uint32_t cont = merge ? ((il & (VREC_MAX_LEN - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
+                                           (uint32_t)((int)(((pr ^ pa) & 3u) - 1u) >> 31))
+                                        : 0u;                  // non-zero: the run started at an earlier dot
+            head[q] = (df | cont) == 0u;
+#endif
             if (merge) {
                 const uint32_t xl = (ES ? __builtin_amdgcn_alignbit(nr[EW + 1], nr[EW], ES) : nr[EW]) ^
                                     (ES ? __builtin_amdgcn_alignbit(na[EW + 1], na[EW], ES) : na[EW]);
@@ -573,10 +593,19 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     constexpr int JQCAP = C::QCAP;
     constexpr int JOIN_THREADS = C::THREADS, JOIN_WAVES = C::THREADS / 64;
     constexpr int JNB_LOG2 = C::NB_LOG2, JNB = 1 << C::NB_LOG2;
+#ifdef VAPOR_AB_DYN_LDS
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* start32 = lds;                                                  // JNB/2 + 2 words: u16 pairs
-    uint32_t* filt = start32 + (JNB / 2 + 2);                                // 2^FILT_LOG2 bits
-    uint32_t* tile = filt + (1 << C::FILT_LOG2) / 32;
+#else
+    // statically sized: the compiler then knows every table's LDS address and folds it into the offset field of
+    // the ds_ instructions instead of adding a base per access
+    __shared__ __attribute__((aligned(16))) uint32_t lds[join_lds_bytes<C, BPS>() / sizeof(uint32_t) + 1];
+#endif
+    // (filter first: both tables of the position loop then lie within the 64 KB an LDS instruction's offset field
+    // reaches and are addressed without adding a base.  Moving the tile, the strips and the queues below 64 KB as well
+    // gains nothing: their reads are ds_read2_b32, whose offsets reach 1 KB)
+    uint32_t* filt = lds;                                                     // 2^FILT_LOG2 bits
+    uint32_t* start32 = filt + (1 << C::FILT_LOG2) / 32;                     // JNB/2 + 2 words: u16 pairs
+    uint32_t* tile = start32 + (JNB / 2 + 2);
     uint32_t* etile = tile + tile_words<C, BPS>();
     // (the 64-bit counters need 8-byte alignment whatever the sizes before them add up to)
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(
@@ -615,7 +644,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
         for (int ts = 0; ts < nk2; ts += TA) {
             const int tn = min(TA, nk2 - ts);
             __syncthreads();                       // previous table fully probed
-            for (int x = tid; x < JNB / 2 + 2 + (1 << C::FILT_LOG2) / 32; x += JOIN_THREADS) start32[x] = 0u;   // counters and filter
+            for (int x = tid; x < JNB / 2 + 2 + (1 << C::FILT_LOG2) / 32; x += JOIN_THREADS) lds[x] = 0u;   // filter and counters
             {
                 const uint32_t* src = plane + (size_t)s2.chunk0 * WPC + (((size_t)ts * BPS) >> 5);
                 const int nw = ((tn + K - 1) * BPS + 31) / 32 + 2;
@@ -756,6 +785,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                         }
                         // ---- keys and bucket bounds of four positions (their LDS reads are in flight together)
                         uint32_t sc[4];                            // first slot | bucket size << 16
+                        const uint32_t vm4 = vmask >> (4 * g);
 #pragma unroll
                         for (int t4 = 0; t4 < 4; ++t4) {
                             const int t = g * 4 + t4;
@@ -785,8 +815,16 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             // (bitwise, not `&&`: with a short-circuit the compiler sinks the filter read into the branch on
                             // `valid` and waits for it there, one LDS round trip per position instead of one per four)
                             const uint32_t s0 = start16[h], s1v = start16[h + 1], fw = filt[fb >> 5];
+#ifdef VAPOR_AB_OLDTAKE
                             const uint32_t take = (vmask >> t) & (fw >> (fb & 31u)) & 1u;
                             sc[t4] = (s0 | ((s1v - s0) << 16)) & (0u - take);
+#else
+                            // (bit 0 spread over the word by one v_bfe_i32; written as `0 - (x & 1)` the compiler turns
+                            // it into and + compare + select, two of which cannot share an issue slot; the same happens to the builtin)
+                            uint32_t take;
+                            asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(take) : "v"((vm4 >> t4) & (fw >> (fb & 31u))));
+                            sc[t4] = (s0 | ((s1v - s0) << 16)) & take;
+#endif
 #ifdef VAPOR_ABL_NOCAND
                             sc[t4] &= 0xFFFFu;
 #endif
@@ -801,23 +839,28 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             const uint32_t c0 = sc[0] >> 16, c1 = sc[1] >> 16, c2 = sc[2] >> 16, c3 = sc[3] >> 16;
                             const uint32_t big = c0 | c1 | c2 | c3;
                             // (the totals of the four positions leave the vector unit together: one v_readlane of the packed
-                            // sums, the fields are taken apart by the scalar unit)
-                            if (!__ballot(big >= 4u)) {
+                            // sums, the fields are taken apart by the scalar unit.  The packed scan runs unconditionally and
+                            // the rare wider cases overwrite its results: as three exclusive branches the totals were
+                            // undefined on some edge of the structurised flow, which cost eight v_readfirstlane per group)
+                            {
                                 const uint32_t p = wave_scan<OpAdd>(c0 | (c1 << 8) | (c2 << 16) | (c3 << 24), 0u);
                                 incl[0] = p & 0xFFu; incl[1] = (p >> 8) & 0xFFu; incl[2] = (p >> 16) & 0xFFu; incl[3] = p >> 24;
                                 const uint32_t p63 = __builtin_amdgcn_readlane(p, 63);
                                 tots[0] = p63 & 0xFFu; tots[1] = (p63 >> 8) & 0xFFu; tots[2] = (p63 >> 16) & 0xFFu; tots[3] = p63 >> 24;
-                            } else if (!__ballot(big >= 512u)) {
-                                const uint32_t p = wave_scan<OpAdd>(c0 | (c1 << 16), 0u), q = wave_scan<OpAdd>(c2 | (c3 << 16), 0u);
-                                incl[0] = p & 0xFFFFu; incl[1] = p >> 16; incl[2] = q & 0xFFFFu; incl[3] = q >> 16;
-                                const uint32_t p63 = __builtin_amdgcn_readlane(p, 63), q63 = __builtin_amdgcn_readlane(q, 63);
-                                tots[0] = p63 & 0xFFFFu; tots[1] = p63 >> 16; tots[2] = q63 & 0xFFFFu; tots[3] = q63 >> 16;
-                            } else {
-                                incl[0] = c0; incl[1] = c1; incl[2] = c2; incl[3] = c3;
+                            }
+                            if (__ballot(big >= 4u)) {
+                                if (!__ballot(big >= 512u)) {
+                                    const uint32_t p = wave_scan<OpAdd>(c0 | (c1 << 16), 0u), q = wave_scan<OpAdd>(c2 | (c3 << 16), 0u);
+                                    incl[0] = p & 0xFFFFu; incl[1] = p >> 16; incl[2] = q & 0xFFFFu; incl[3] = q >> 16;
+                                    const uint32_t p63 = __builtin_amdgcn_readlane(p, 63), q63 = __builtin_amdgcn_readlane(q, 63);
+                                    tots[0] = p63 & 0xFFFFu; tots[1] = p63 >> 16; tots[2] = q63 & 0xFFFFu; tots[3] = q63 >> 16;
+                                } else {
+                                    incl[0] = c0; incl[1] = c1; incl[2] = c2; incl[3] = c3;
 #pragma unroll
-                                for (int x = 0; x < 4; ++x) {
-                                    incl[x] = wave_scan<OpAdd>(incl[x], 0u);
-                                    tots[x] = __builtin_amdgcn_readlane(incl[x], 63);
+                                    for (int x = 0; x < 4; ++x) {
+                                        incl[x] = wave_scan<OpAdd>(incl[x], 0u);
+                                        tots[x] = __builtin_amdgcn_readlane(incl[x], 63);
+                                    }
                                 }
                             }
                         }
