@@ -8,7 +8,7 @@ if "--build" in sys.argv:
     from vapor_amd import build as B
     subprocess.check_call([B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DVAPOR_BLOCK_TIMING",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vapor_amd", "csrc"),
-                           "-Wno-unused-function", "-o", SO] + B.SOURCES)
+                           "-Wno-unused-function", "-o", SO] + B.SOURCES + ["-lz"])
     print(SO); sys.exit(0)
 os.environ["VAPOR_HIP_LIB"] = SO
 import numpy as np

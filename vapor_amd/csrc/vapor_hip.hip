@@ -1307,6 +1307,30 @@ extern "C" int vapor_debug_block_ticks(double* out, int32_t n)
     return 0;
 }
 #endif
+#if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
+extern "C" int vapor_debug_block_info(double* info, double* phase, int32_t n)
+{
+    std::vector<unsigned long long> h(4096 * 4), ph(4096 * 8), z(4096 * 8, 0ULL);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(vapor::g_block_info), sizeof(unsigned long long) * 4096 * 4) != hipSuccess) return -1;
+    for (int x = 0; x < n * 4 && x < 4096 * 4; ++x) info[x] = (double)h[(size_t)x];
+#ifdef VAPOR_PHASE_TIMING
+    if (hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(vapor::g_block_phase), sizeof(unsigned long long) * 4096 * 8) != hipSuccess) return -1;
+    for (int x = 0; x < n * 8 && x < 4096 * 8; ++x) phase[x] = (double)ph[(size_t)x];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vapor::g_block_phase), z.data(), sizeof(unsigned long long) * 4096 * 8) != hipSuccess) return -1;
+#endif
+    return 0;
+}
+// developer build only: the join tasks of a plan (first index into the sorted pair list, pairs in the task) and
+// the sorted pair list itself
+extern "C" int vapor_debug_plan_tasks(vapor_plan* p, int32_t* first, int32_t* n_reads, int32_t cap, int32_t* order, int32_t order_cap)
+{
+    if (!p) return -1;
+    const int n = (int)p->tasks.size();
+    for (int x = 0; x < n && x < cap; ++x) { first[x] = p->tasks[(size_t)x].first; n_reads[x] = p->tasks[(size_t)x].n_reads; }
+    for (int x = 0; x < (int)p->task_pairs.size() && x < order_cap; ++x) order[x] = p->task_pairs[(size_t)x];
+    return n;
+}
+#endif
 #ifdef VAPOR_PHASE_TIMING
 // developer build only: read (and clear) the per-phase tick sums
 extern "C" int vapor_debug_phases(double* out, int32_t n)

@@ -342,6 +342,8 @@ __device__ __forceinline__ T wave_scan(T v, T identity)
 // over the stamping lanes into g_phase[].  Compiled out of the product library.
 #if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
 __device__ unsigned long long g_block_ticks[4096];     // join_kernel: 100 MHz ticks from start to end of every workgroup
+__device__ unsigned long long g_block_info[4096 * 4];  // HW_ID, XCC_ID, start, end (100 MHz) of every workgroup
+__device__ unsigned long long g_block_phase[4096 * 8]; // per workgroup: the phase ticks of its 16 stamping lanes
 #endif
 #ifdef VAPOR_PHASE_TIMING
 __device__ unsigned long long g_phase[64];
@@ -376,6 +378,11 @@ struct PhaseClockT {
 #pragma unroll
             for (int x = 0; x < N; ++x)
                 if (acc[x]) atomicAdd(&g_phase[BASE + x], acc[x]);
+            if (BASE == 0 && blockIdx.x < 4096) {
+#pragma unroll
+                for (int x = 0; x < N && x < 8; ++x)
+                    if (acc[x]) atomicAdd(&g_block_phase[blockIdx.x * 8 + x], acc[x]);
+            }
         }
     }
 };
@@ -934,7 +941,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     pc.mark(6, pw);                                // waiting for the block's last wave
     pc.flush(pw);
 #if defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING)
-    if (tid == 0 && blockIdx.x < 4096) g_block_ticks[blockIdx.x] = (unsigned long long)(wall_clock64() - t_block0);
+    if (tid == 0 && blockIdx.x < 4096) {
+        const long long t_end = wall_clock64();
+        g_block_ticks[blockIdx.x] = (unsigned long long)(t_end - t_block0);
+        g_block_info[blockIdx.x * 4 + 0] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        g_block_info[blockIdx.x * 4 + 1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        g_block_info[blockIdx.x * 4 + 2] = (unsigned long long)t_block0;
+        g_block_info[blockIdx.x * 4 + 3] = (unsigned long long)t_end;
+    }
 #endif
     if (tid < task.n_reads) n_hits[task_pairs[task.first + tid]] = cnt[tid];
 }
