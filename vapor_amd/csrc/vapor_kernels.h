@@ -466,75 +466,77 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     bool same[2], rcm[2], head[2];
     int len[2];
     const uint32_t out0 = (uint32_t)((lane - n) >> 31), out1 = (uint32_t)((lane + 64 - n) >> 31);   // ~0 if the slot is filled
-    uint32_t who[2];                               // il | e << 11
+    uint32_t who[2];                               // il | e << 16
     uint32_t item[2], e[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) item[q] = myq[from + ((q * 64 + lane < n) ? q * 64 + lane : 0)];
 #pragma unroll
     for (int q = 0; q < 2; ++q) e[q] = entries[item[q] & 0xFFFFu];
     const int emin = max(0, off2 - ts);            // first allele position of this tile that may carry a dot
+    // records are assembled by one add: (e << 16 | il) + (ts - off2) << 16 + cb (neither field carries: both stay below 2^16)
+    const uint32_t rec_bias = ((uint32_t)(ts - off2) << 16) + (uint32_t)cb;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t il = item[q] >> 16;
         const bool in = (q * 64 + lane < n) && ts + (int)e[q] >= off2;
-        who[q] = il | (e[q] << 11);
+        who[q] = il | (e[q] << 16);
         len[q] = 1;
         if (BPS == 2) {
-            // normalised streams: nr[] / na[] start at the k-mer's first symbol; word 0 of the raw windows is the word
-            // before the k-mer's first word (valid LDS even for positions below 16: the strips and the tile are preceded
-            // by other regions, and such a position never consults it)
-            constexpr int EW = (2 * K) / 32, ES = (2 * K) % 32;   // where the 64 symbols-after-the-k-mer bits start
-            constexpr int NN = EW + 3, NV = NN + 2;
-            const uint32_t shr = (il & 15u) * 2u, sha = (e[q] & 15u) * 2u;
-            const uint32_t* rp = rbuf + (int)(il >> 4) - 1;
-            const uint32_t* tp = tile + (int)(e[q] >> 4) - 1;
-            uint32_t rw[NV], tw[NV];
+            // Both sides are read as a stream that starts ONE symbol before the k-mer (word (pos - 1) >> 4 on; valid LDS
+            // even for position 0: the strips and the tile are preceded by other regions, and such a position never
+            // consults that symbol): bits 0-1 are the symbol before, bits 2 .. 2K+1 the k-mer, the next 64 the symbols a run
+            // can extend over.  One XOR of the two streams answers all three questions.
+            constexpr int SB = 2 * (K + 1);
+            constexpr int EW = SB / 32, ES = SB % 32;            // where the 64 bits after the k-mer start
+            constexpr int NN = EW + 3;
+            const int pr1 = (int)il - 1, pa1 = (int)e[q] - 1;
+            const uint32_t shr = (uint32_t)(pr1 & 15) * 2u, sha = (uint32_t)(pa1 & 15) * 2u;
+            const uint32_t* rp = rbuf + (pr1 >> 4);
+            const uint32_t* tp = tile + (pa1 >> 4);
+            uint32_t rw[NN + 1], tw[NN + 1];
 #pragma unroll
-            for (int x = 0; x < NV; ++x) { rw[x] = rp[x]; tw[x] = tp[x]; }
-            uint32_t nr[NN], na[NN];
+            for (int x = 0; x <= NN; ++x) { rw[x] = rp[x]; tw[x] = tp[x]; }
+            uint32_t sr[NN], sx[NN];                              // read stream; read stream XOR allele stream
 #pragma unroll
             for (int x = 0; x < NN; ++x) {
-                nr[x] = __builtin_amdgcn_alignbit(rw[x + 2], rw[x + 1], shr);
-                na[x] = __builtin_amdgcn_alignbit(tw[x + 2], tw[x + 1], sha);
+                sr[x] = __builtin_amdgcn_alignbit(rw[x + 1], rw[x], shr);
+                sx[x] = sr[x] ^ __builtin_amdgcn_alignbit(tw[x + 1], tw[x], sha);
             }
-            KT kf, a;
-#pragma unroll
-            for (int x = 0; x < KT::NW; ++x) { kf.w[x] = nr[x]; a.w[x] = na[x]; }
-            kf.w[KT::NW - 1] &= KT::TOPMASK;
-            a.w[KT::NW - 1] &= KT::TOPMASK;
-            const KT kr = revcomp_key<BPS, K>(kf);
-#ifdef VAPOR_AB_BOOLVOTE
-            same[q] = in && (a == kf);
-            rcm[q] = in && (a == kr);
-            const uint32_t pr = shr ? (rw[1] >> (shr - 2u)) : (rw[0] >> 30), pa = sha ? (tw[1] >> (sha - 2u)) : (tw[0] >> 30);
-            const uint32_t pred = (uint32_t)((il & (VREC_MAX_LEN - 1)) != 0u) & (uint32_t)((int)e[q] > emin) &
-                                  (uint32_t)(((pr ^ pa) & 3u) == 0u) & (uint32_t)merge;
-            head[q] = same[q] & (pred == 0u);
-#else
-            (void)in;
             // not a candidate at all: an empty slot of the call, or an allele position before the pair's window
+            (void)in;
             const uint32_t notin = ~(q ? out1 : out0) | (uint32_t)(((int)e[q] - (off2 - ts)) >> 31);
-            uint32_t df = notin, dr = notin;
+            uint32_t df = notin;
 #pragma unroll
-            for (int x = 0; x < KT::NW; ++x) { df |= a.w[x] ^ kf.w[x]; dr |= a.w[x] ^ kr.w[x]; }
+            for (int x = 0; x <= EW; ++x) {
+                const uint32_t m = (x == EW ? ((1u << ES) - 1u) : 0xFFFFFFFFu) & (x == 0 ? ~3u : 0xFFFFFFFFu);
+                if (m) df |= sx[x] & m;
+            }
+            KT kf;
+#pragma unroll
+            for (int x = 0; x < KT::NW; ++x)
+                kf.w[x] = (SB <= 32) ? (sr[0] >> 2) : __builtin_amdgcn_alignbit(sr[x + 1], sr[x], 2);
+            kf.w[KT::NW - 1] &= KT::TOPMASK;
+            const KT kr = revcomp_key<BPS, K>(kf);
+            uint32_t dr = notin;
+#pragma unroll
+            for (int x = 0; x < KT::NW; ++x) {
+                // allele k-mer word = (read stream XOR difference) >> 2
+                const uint32_t aw = (SB <= 32) ? ((sr[0] ^ sx[0]) >> 2) : __builtin_amdgcn_alignbit(sr[x + 1] ^ sx[x + 1], sr[x] ^ sx[x], 2);
+                dr |= (x == KT::NW - 1 ? aw & KT::TOPMASK : aw) ^ kr.w[x];
+            }
             same[q] = df == 0u;
             rcm[q] = dr == 0u;
-            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there)
-            // (no `&&` anywhere: with a short-circuit the compiler sinks the reads of word 0 into a branch on the first
-            // operand and waits for them there - a second LDS round trip per candidate)
-            const uint32_t pr = shr ? (rw[1] >> (shr - 2u)) : (rw[0] >> 30), pa = sha ? (tw[1] >> (sha - 2u)) : (tw[0] >> 30);
+            // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there): then it
+            // is not the head of its run
             const uint32_t cont = merge ? ((il & (VREC_MAX_LEN - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
-                                           (uint32_t)((int)(((pr ^ pa) & 3u) - 1u) >> 31))
-                                        : 0u;                  // non-zero: the run started at an earlier dot
+                                           (uint32_t)((int)((sx[0] & 3u) - 1u) >> 31))
+                                        : 0u;
             head[q] = (df | cont) == 0u;
-#endif
             if (merge) {
-                const uint32_t xl = (ES ? __builtin_amdgcn_alignbit(nr[EW + 1], nr[EW], ES) : nr[EW]) ^
-                                    (ES ? __builtin_amdgcn_alignbit(na[EW + 1], na[EW], ES) : na[EW]);
-                const uint32_t xh = (ES ? __builtin_amdgcn_alignbit(nr[EW + 2], nr[EW + 1], ES) : nr[EW + 1]) ^
-                                    (ES ? __builtin_amdgcn_alignbit(na[EW + 2], na[EW + 1], ES) : na[EW + 1]);
-                const unsigned long long x = ((unsigned long long)xh << 32) | xl;
-                const int ext = x ? ((__ffsll((long long)x) - 1) >> 1) : 32;
+                const uint32_t xl = ES ? __builtin_amdgcn_alignbit(sx[EW + 1], sx[EW], ES) : sx[EW];
+                const uint32_t xh = (ES ? __builtin_amdgcn_alignbit(sx[EW + 2], sx[EW + 1], ES) : sx[EW + 1]) | 0x40000000u;
+                // (a run holds at most VREC_MAX_LEN = 32 dots, so 31 symbols after the k-mer decide: the set bit 62 ends the search)
+                const int ext = __builtin_ctzll(((unsigned long long)xh << 32) | xl) >> 1;
                 len[q] = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e[q]));
             }
         } else {
@@ -555,9 +557,7 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
     auto record = [&](uint32_t w, int ln, uint32_t rc) -> unsigned long long {
-        const uint32_t il = w & 0x7FFu, ee = (w >> 11) & 0x7FFFu;
-        return (unsigned long long)(((uint32_t)(ts + (int)ee - off2) << 16) | (uint32_t)(cb + (int)il)) |
-               ((unsigned long long)ln << 32) | ((unsigned long long)rc << 48);
+        return (unsigned long long)(w + rec_bias) | ((unsigned long long)ln << 32) | ((unsigned long long)rc << 48);
     };
     unsigned long long old = 0;
     if (lane == 0) old = atomicAdd(cnt_r, (unsigned long long)nrec | ((unsigned long long)dots << 32));
