@@ -630,6 +630,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     constexpr int WPC = (BPS == 2) ? VP_P2_WORDS_PER_CHUNK : VP_X4_WORDS_PER_CHUNK;
     uint32_t* myq = queue + wave * (JQCAP + 4);    // JQCAP slots + a dump slot for lanes that have nothing to store
     uint32_t* rbuf = rbufs + wave * rbuf_words<BPS>();
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    const uint32_t qbase = (uint32_t)(uintptr_t)(lds_u32_t*)myq;            // LDS byte address of the wave's queue
 
     if (tid < MAX_READS_PER_TASK) cnt[tid] = 0ULL;
     JoinClock pc;
@@ -909,11 +911,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                 // three unconditional stores (a lane without that candidate writes the dump slot:
                                 // no execution-mask juggling, no branch), a uniform loop only for buckets of four
                                 // entries and more
+                                // (byte addresses, so that a store is one compare and one select between the lane's slot and the
+                                // dump slot, with the +1 / +2 in the instruction's offset field)
                                 const uint32_t pos = (uint32_t)qlen + incl[x] - c;
                                 const uint32_t item = (il << 16) | s0;
-                                myq[c > 0u ? pos : (uint32_t)JQCAP] = item;
-                                myq[c > 1u ? pos + 1u : (uint32_t)JQCAP] = item + 1u;
-                                myq[c > 2u ? pos + 2u : (uint32_t)JQCAP] = item + 2u;
+                                const uint32_t full = qbase + pos * 4u;
+                                ((lds_u32_t*)(uintptr_t)(c > 0u ? full : qbase + (uint32_t)JQCAP * 4u))[0] = item;
+                                ((lds_u32_t*)(uintptr_t)(c > 1u ? full : qbase + (uint32_t)(JQCAP - 1) * 4u))[1] = item + 1u;
+                                ((lds_u32_t*)(uintptr_t)(c > 2u ? full : qbase + (uint32_t)(JQCAP - 2) * 4u))[2] = item + 2u;
                                 for (uint32_t u = 3; __ballot(c > u); ++u)
                                     if (c > u) myq[pos + u] = item + u;
                             }
