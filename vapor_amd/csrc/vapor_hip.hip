@@ -196,7 +196,9 @@ struct vapor_plan {
     double* d_loci = nullptr;
     unsigned int* d_overflow = nullptr;   // [0] pairs whose slot overflowed, [1] length of d_big_list
     int32_t* d_big_list = nullptr;        // pairs with more dots than clean_kernel stages in LDS
-    unsigned int* h_overflow = nullptr;   // pinned
+    unsigned int* h_overflow = nullptr;   // pinned, two counters: pairs that overflowed their slot, pairs left to clean_big_kernel
+    bool big_known = false;               // a blocking run has reported how many pairs clean_kernel leaves to clean_big_kernel
+    unsigned int n_big = 0;
     double t_finish = 0;
 };
 
@@ -630,7 +632,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     chk(dmalloc(ctx, (void**)&p->d_overflow, 4 * sizeof(unsigned int)), "hipMalloc overflow");
     if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_overflow, 0, 4 * sizeof(unsigned int), ctx->stream), "memset overflow");
     chk(dmalloc(ctx, (void**)&p->d_big_list, sizeof(int32_t) * p->hp.size()), "hipMalloc big list");
-    chk(hmalloc(ctx, (void**)&p->h_overflow, sizeof(unsigned int)), "hipHostMalloc overflow");
+    chk(hmalloc(ctx, (void**)&p->h_overflow, 2 * sizeof(unsigned int)), "hipHostMalloc overflow");
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
     chk(hipEventCreate(&p->ev_t0), "hipEventCreate");
@@ -697,7 +699,7 @@ static int clean_hcap(int range_words_cap, int want)
 
 static int async_fold(vapor_plan* p);
 
-static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr)
+static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr, bool skip_big = false)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = on ? on : c->stream;
@@ -728,12 +730,18 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st,
                            p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
-                           p->range_words_cap, clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list);
+                           p->range_words_cap, clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list,
+                           skip_big ? 0 : 1);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(p->n_pairs, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
-                           clean_fixed_bytes(p->range_words_cap, true), st, p->d_pairs, p->d_nhits, p->d_hits, p->d_hflags,
-                           p->d_stats, p->range_words_cap, clean_groups_cap(p->range_words_cap), p->d_overflow, p->d_big_list);
-        HIPCHK(hipGetLastError());
+        // (clean_big_kernel needs a CU with free LDS like any other clean workgroup: behind another plan's join it sits
+        // on the stream until that join is over even with nothing to do, and holds back the finish kernel and the
+        // plan's next step with it - so an asynchronous step leaves it out when the plan's blocking run left it no pair)
+        if (!skip_big) {
+            hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(p->n_pairs, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
+                               clean_fixed_bytes(p->range_words_cap, true), st, p->d_pairs, p->d_nhits, p->d_hits, p->d_hflags,
+                               p->d_stats, p->range_words_cap, clean_groups_cap(p->range_words_cap), p->d_overflow, p->d_big_list);
+            HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(hipEventRecord(ev[2], st));
     if (p->n_pairs > 0 && fetch_stats)
@@ -991,7 +999,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     if (rc == VAPOR_OK) {
         int hcap = clean_hcap(rw, 4096);
         hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_dp,
-                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_lds(rw, hcap), hcap, d_ov, d_big);
+                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1);
         chk(hipGetLastError(), "clean launch");
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);
@@ -1076,12 +1084,12 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
     double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
     if (p->n_loci > 0) {
         hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, st, p->d_reads, p->d_locus_first, p->d_stats,
-                           p->d_gt, p->d_read_scores, d_out);
+                           p->d_gt, p->d_read_scores, d_out, (double*)nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(e1, st));
     // only the overflow count has to come back (after the finish kernel, so that nothing sits between the kernels)
-    HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(p->h_overflow, p->d_overflow, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     if (loci_out && p->n_loci)
         HIPCHK(hipMemcpyAsync(loci_out, d_out, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
     if (read_scores && p->n_reads)
@@ -1097,6 +1105,8 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
             if (p->last_stats[16 * (size_t)i + 15] == VAPOR_E_OVERFLOW) { p->overflow_final = true; break; }
         return vapor_plan_run_loci(p, d_loci_out, loci_out, read_scores);
     }
+    p->big_known = true;
+    p->n_big = p->h_overflow[1];
     float f = 0, a = 0, b = 0, t = 0;
     HIPCHK(hipEventElapsedTime(&f, p->ev[2], e1));
     p->t_finish = f;
@@ -1234,14 +1244,14 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
         p->have_after = false;
     }
     hipEvent_t* ev = p->ring[(size_t)p->ring_n].data();
-    rc = plan_run_once(p, false, ev, st);
+    rc = plan_run_once(p, false, ev, st, p->big_known && p->n_big == 0);
     if (rc != VAPOR_OK) return rc;
     double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
     if (p->n_loci > 0) {
+        // (the finish kernel writes the pinned host copy itself: no copy kernel behind it)
         hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, st, p->d_reads, p->d_locus_first, p->d_stats,
-                           p->d_gt, p->d_read_scores, d_out);
+                           p->d_gt, p->d_read_scores, d_out, p->h_loci);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(p->h_loci, d_out, sizeof(double) * 8 * (size_t)p->n_loci, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipEventRecord(ev[3], st));
     HIPCHK(hipEventRecord(p->ev_last, st));

@@ -1540,7 +1540,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const unsigned long long* __restrict__ recs_all,
     uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
-    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list)
+    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list, int big_follows)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
@@ -1564,7 +1564,12 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     }
     const int n = (int)nrec;                   // cap < 2^31
     if (n > hcap || ndots > 65535u) {
-        if (tid == 0) big_list[atomicAdd(&overflow[1], 1u)] = p;
+        if (tid == 0) {
+            big_list[atomicAdd(&overflow[1], 1u)] = p;
+            // an asynchronous step that left clean_big_kernel out because the plan's blocking run saw no such pair:
+            // the sticky counter makes vapor_plan_sync ask for a blocking run
+            if (!big_follows) atomicAdd(&overflow[2], 1u);
+        }
         return;
     }
     clean_pair<true>(p, lds, sh, pr, n, (int)ndots, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
@@ -1687,8 +1692,11 @@ __device__ __forceinline__ bool score_s3(const long long* r, const long long* a,
 // one wave per locus; reads of a locus are contiguous (locus_first[l] .. locus_first[l+1])
 __global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ reads, const int32_t* __restrict__ locus_first,
                                                    const long long* __restrict__ stats, const double* __restrict__ gt_table,
-                                                   double* __restrict__ read_scores, double* __restrict__ loci_out)
+                                                   double* __restrict__ read_scores, double* __restrict__ loci_out,
+                                                   double* __restrict__ loci_out2)
 {
+    // loci_out2 (may be NULL): a second copy of the locus records, e.g. pinned host memory, so that an asynchronous step
+    // needs no copy kernel behind this one
     __shared__ double sc[256];
     const int l = blockIdx.x, lane = threadIdx.x;
     const int r0 = locus_first[l], r1 = locus_first[l + 1];
@@ -1764,9 +1772,10 @@ __global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ re
     }
     if (lane == 0) {
         double* o = loci_out + 8LL * l;
+        double* o2 = loci_out2 ? loci_out2 + 8LL * l : o;
         if (n == 0) {
-            for (int t = 0; t < 8; ++t) o[t] = __builtin_nan("");
-            o[4] = 0.0;
+            for (int t = 0; t < 8; ++t) o2[t] = o[t] = __builtin_nan("");
+            o2[4] = o[4] = 0.0;
             return;
         }
         const double qs = npos > 0 ? res / (double)npos : 0.0;
@@ -1779,6 +1788,9 @@ __global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ re
         }
         if (gt == 0 && gs > 0.15) gt = 1;
         o[0] = qs; o[1] = gs; o[2] = (double)gt; o[3] = gq; o[4] = (double)n; o[5] = (double)npos; o[6] = (double)nnonpos; o[7] = 0.0;
+        if (loci_out2) {
+            o2[0] = qs; o2[1] = gs; o2[2] = (double)gt; o2[3] = gq; o2[4] = (double)n; o2[5] = (double)npos; o2[6] = (double)nnonpos; o2[7] = 0.0;
+        }
     }
 }
 
