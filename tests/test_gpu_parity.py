@@ -338,6 +338,35 @@ def test_async_steps_equal_blocking_run(eng):
     plan.close()
 
 
+def test_async_steps_with_a_pair_left_to_the_big_kernel(eng):
+    """An asynchronous step leaves clean_big_kernel out only when the plan's blocking run saw no pair that needs it:
+    with a pair of more than 65 535 dots (tandem repeats on both sides) in the batch the steps still run it, and the
+    records equal the blocking run's - which in turn equal what the statistics of a plain run give on the host."""
+    from vapor_amd import workload as wl
+    w = wl.make_workload("tiny", seed=9, **wl.WORKLOADS["tiny"])
+    unit = "ACGTTGCAAGGCTTAACCGGATCGATTACGGCATCGTAGCTAGGCTAACGT"
+    r = 0                                            # read 0 of locus 0 and its ref window become tandem repeats
+    ref_idx, read_idx = int(w.pairs["seq2"][2 * r]), int(w.pairs["seq1"][2 * r])
+    w.seqs[ref_idx] = unit * 60
+    w.seqs[read_idx] = unit * 40
+    w.len_ref[w.read_locus == w.read_locus[r]] = len(w.seqs[ref_idx])
+    ss = eng.seqset(w.seqs)
+    plan = eng.plan(ss, w.pairs)
+    st = plan.run().copy()
+    assert st[2 * r, 0] > 65535 and st[2 * r, 15] == 0    # dots of the repeat pair: the 16-bit counters of clean_kernel cannot hold them
+    want = wl.finish_workload(w, st)
+    plan.set_reads(wl.read_table(w), w.n_loci)
+    ref = plan.run_loci().copy()
+    for _ in range(5):
+        plan.run_loci_async()
+    got = plan.sync().copy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    ok = ~np.isnan(want[:, 0])
+    assert np.array_equal(ok, ~np.isnan(ref[:, 0])) and np.array_equal(ref[ok, :3], want[ok, :3])
+    plan.close()
+    ss.close()
+
+
 def test_randomised_sweep_vs_oracle(eng):
     """A few seconds of tools/fuzz_parity.py (odd lengths, every k, slices, soft-masked / N / repeat sequences,
     exact copies, alleles around the tile size): dots, statistics and directed statistics exact."""

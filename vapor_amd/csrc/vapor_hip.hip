@@ -1243,6 +1243,9 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
         HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
         p->have_after = false;
     }
+    // the sticky overflow counter reports on the asynchronous steps since the last vapor_plan_sync: what a blocking
+    // run counted before it resized the slots is not theirs
+    if (p->ring_n == 0 && p->acc_n == 0) HIPCHK(hipMemsetAsync(p->d_overflow + 2, 0, sizeof(unsigned int), st));
     hipEvent_t* ev = p->ring[(size_t)p->ring_n].data();
     rc = plan_run_once(p, false, ev, st, p->big_known && p->n_big == 0);
     if (rc != VAPOR_OK) return rc;
@@ -1303,7 +1306,9 @@ extern "C" int vapor_plan_sync(vapor_plan* p, double* loci_out)
     HIPCHK(hipMemcpy(&sticky, p->d_overflow + 2, sizeof(unsigned int), hipMemcpyDeviceToHost));
     if (sticky) {
         HIPCHK(hipMemset(p->d_overflow + 2, 0, sizeof(unsigned int)));
-        return fail(VAPOR_E_OVERFLOW, "a pair outgrew its record slot during the asynchronous steps; run vapor_plan_run_loci (it resizes)");
+        return fail(VAPOR_E_OVERFLOW, "a pair outgrew its record slot during the asynchronous steps; run vapor_plan_run_loci (it resizes)" +
+                    std::string(p->big_known ? "" : " [no blocking run has counted the pairs left to clean_big_kernel]") +
+                    " [pairs left to clean_big_kernel on the last blocking run: " + std::to_string(p->n_big) + "]");
     }
     return VAPOR_OK;
 }
