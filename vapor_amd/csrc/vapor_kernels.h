@@ -1690,14 +1690,16 @@ __device__ __forceinline__ bool score_s3(const long long* r, const long long* a,
 }
 
 // one wave per locus; reads of a locus are contiguous (locus_first[l] .. locus_first[l+1])
-__global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ reads, const int32_t* __restrict__ locus_first,
+__global__ __launch_bounds__(64, 8) void finish_kernel(const DRead* __restrict__ reads, const int32_t* __restrict__ locus_first,
                                                    const long long* __restrict__ stats, const double* __restrict__ gt_table,
                                                    double* __restrict__ read_scores, double* __restrict__ loci_out,
                                                    double* __restrict__ loci_out2)
 {
     // loci_out2 (may be NULL): a second copy of the locus records, e.g. pinned host memory, so that an asynchronous step
-    // needs no copy kernel behind this one
-    __shared__ double sc[256];
+    // needs no copy kernel behind this one.
+    // One wave per locus, no LDS and at most 64 registers: the scores stay in the lanes that computed them and are
+    // handed round by v_readlane, so that the wave fits beside a join workgroup (which owns its CU's LDS and all but 64
+    // registers per SIMD) instead of sitting on the stream until another plan's join is over.
     const int l = blockIdx.x, lane = threadIdx.x;
     const int r0 = locus_first[l], r1 = locus_first[l + 1];
     int n = 0, npos = 0, nnonpos = 0;
@@ -1710,65 +1712,77 @@ __global__ __launch_bounds__(64) void finish_kernel(const DRead* __restrict__ re
     // loci of BASELINE's largest configuration are covered by tests/golden/deep_loci.json.gz.  Longer synthetic
     // lists are summed in chunks of 256 reads (a few ulp from numpy); VaPoR_GT / GQ need at most 64 scored reads
     // (the (k, l) table), beyond that the genotype falls back to 0/1 without a quality.
+    // The ordered sum runs in every lane on broadcast values (uniform control flow); lane 0 stores.
+    auto bcast = [](double v, int from) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, from);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), from);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
     for (int base = r0; base < r1; base += 256) {
         const int cnt = min(256, r1 - base);
-        for (int t = lane; t < cnt; t += 64) {
-            const DRead rd = reads[base + t];
-            const double lr = (double)rd.len_ref, la = (double)rd.len_alt;
-            double a, b, s = __builtin_nan("");
-            bool ok = false;
-            if (rd.kind == 0) {
-                double a2, b2;
-                const bool v1 = score_s1(stats + 16LL * rd.ref_a, stats + 16LL * rd.alt_a, lr, la, &a, &b);
-                const bool v2 = score_s2(stats + 16LL * rd.ref_b, stats + 16LL * rd.alt_b, lr, la, &a2, &b2);
-                const double s1 = 1.0 - b / a, s2 = 1.0 - b2 / a2;
-                if (v1 && v2) { s = (s2 < s1) ? s2 : s1; ok = true; }
-                else if (v1) { s = s1; ok = true; }
-                else if (v2) { s = s2; ok = true; }
-            } else {
-                const long long* r = stats + 16LL * rd.ref_a;
-                const long long* q = stats + 16LL * rd.alt_a;
-                ok = rd.kind == 1 ? score_s1(r, q, lr, la, &a, &b) : rd.kind == 2 ? score_s2(r, q, lr, la, &a, &b)
-                                                                               : score_s3(r, q, lr, la, &a, &b);
-                if (ok) s = 1.0 - b / a;
-            }
-            sc[t] = ok ? s : __builtin_nan("");
-            if (read_scores) read_scores[base + t] = sc[t];
-        }
-        __syncthreads();
-        if (lane == 0) {
-            int cpos = 0;
-            for (int t = 0; t < cnt; ++t) {
-                const double v = sc[t];
-                if (v != v) continue;                 // NaN marks a skipped read
-                ++n;
-                if (!(v >= 0.005)) ++nnonpos;         // round(v, 2) > 0  <=>  v >= 0.005
-                if (v > 0.0) ++cpos;
-            }
-            double part = 0.0;
-            if (cpos < 8) {
-                for (int t = 0; t < cnt; ++t) if (sc[t] > 0.0) part += sc[t];
-            } else {
-                double r8[8];
-                const int full = cpos - (cpos % 8);
-                int idx = 0;
-                for (int t = 0; t < cnt; ++t) {
-                    const double v = sc[t];
-                    if (!(v > 0.0)) continue;
-                    if (idx < 8) r8[idx] = v;
-                    else if (idx < full) r8[idx & 7] += v;
-                    else {
-                        if (idx == full) part = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-                        part += v;
-                    }
-                    ++idx;
+        double vals[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = q * 64 + lane;
+            double s = __builtin_nan("");
+            if (t < cnt) {
+                const DRead rd = reads[base + t];
+                const double lr = (double)rd.len_ref, la = (double)rd.len_alt;
+                double a, b;
+                if (rd.kind == 0) {
+                    double a2, b2;
+                    const bool v1 = score_s1(stats + 16LL * rd.ref_a, stats + 16LL * rd.alt_a, lr, la, &a, &b);
+                    const bool v2 = score_s2(stats + 16LL * rd.ref_b, stats + 16LL * rd.alt_b, lr, la, &a2, &b2);
+                    const double s1 = 1.0 - b / a, s2 = 1.0 - b2 / a2;
+                    if (v1 && v2) s = (s2 < s1) ? s2 : s1;
+                    else if (v1) s = s1;
+                    else if (v2) s = s2;
+                } else {
+                    const long long* r = stats + 16LL * rd.ref_a;
+                    const long long* q2 = stats + 16LL * rd.alt_a;
+                    const bool ok = rd.kind == 1 ? score_s1(r, q2, lr, la, &a, &b) : rd.kind == 2 ? score_s2(r, q2, lr, la, &a, &b)
+                                                                                             : score_s3(r, q2, lr, la, &a, &b);
+                    if (ok) s = 1.0 - b / a;
                 }
-                if (cpos == full) part = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+                if (read_scores) read_scores[base + t] = s;
             }
-            res += part;
-            npos += cpos;
+            vals[q] = s;                              // NaN marks a skipped read (and the slots past the chunk)
         }
-        __syncthreads();
+        int cpos = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = vals[q];
+            n += __popcll(__ballot(v == v));
+            nnonpos += __popcll(__ballot((v == v) & !(v >= 0.005)));     // round(v, 2) > 0  <=>  v >= 0.005
+            cpos += __popcll(__ballot(v > 0.0));
+        }
+        double part = 0.0;
+        double r8a = 0.0, r8b = 0.0, r8c = 0.0, r8d = 0.0, r8e = 0.0, r8f = 0.0, r8g = 0.0, r8h = 0.0;
+        const int full = cpos < 8 ? 0 : cpos - (cpos % 8);
+        int idx = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = min(64, cnt - q * 64);
+            for (int u = 0; u < m; ++u) {
+                const double v = bcast(vals[q], u);
+                if (!(v > 0.0)) continue;
+                if (idx < full) {
+                    // (first visit of a partial sum assigns: 0.0 + v == v bit for bit, the positives are never -0.0)
+                    switch (idx & 7) {
+                        case 0: r8a += v; break; case 1: r8b += v; break; case 2: r8c += v; break; case 3: r8d += v; break;
+                        case 4: r8e += v; break; case 5: r8f += v; break; case 6: r8g += v; break; default: r8h += v; break;
+                    }
+                } else {
+                    if (idx == full && full) part = ((r8a + r8b) + (r8c + r8d)) + ((r8e + r8f) + (r8g + r8h));
+                    part += v;
+                }
+                ++idx;
+            }
+        }
+        if (full && cpos == full) part = ((r8a + r8b) + (r8c + r8d)) + ((r8e + r8f) + (r8g + r8h));
+        res += part;
+        npos += cpos;
     }
     if (lane == 0) {
         double* o = loci_out + 8LL * l;
