@@ -12,6 +12,11 @@ SOURCES = [os.path.join(HERE, "csrc", "vapor_hip.hip"), os.path.join(HERE, "csrc
 DEPS = SOURCES + [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(ROOT, "include", "vapor_hip.h")]
 
 
+# The kernels issue their wave-level atomics from one lane already (`if (lane == 0) atomicAdd(...)`); LLVM's atomic
+# optimizer wraps each of them in another mbcnt / compare / exec-mask sequence.  Off: clean_kernel 0.0837 -> 0.0826 ms.
+EXTRA_FLAGS = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -22,7 +27,7 @@ def hipcc() -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in DEPS):
         return SO
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + EXTRA_FLAGS + [
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            "-Wall", "-Wno-unused-function", "-o", SO] + SOURCES + ["-lz"]
     if verbose:

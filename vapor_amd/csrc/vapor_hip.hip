@@ -245,7 +245,9 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
                        set_join_attr<4, 10>(), set_join_attr<4, 20>(), set_join_attr<4, 30>(), set_join_attr<4, 40>()};
     for (hipError_t x : a)
         if (x != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(join): ") + hipGetErrorString(x)); }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel<CLEAN_PER_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(clean): ") + hipGetErrorString(e)); }
@@ -659,6 +661,16 @@ static void launch_join(vapor_plan* p, const Launch& L, bool first, hipStream_t 
 
 static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 / 10 + 8; }
 
+// clean_kernel is instantiated for 4, 8 and CLEAN_PER_MAX bitmap words per thread: the smallest that covers the value range
+template <typename... A>
+static void launch_clean(int range_words_cap, unsigned grid, size_t lds, hipStream_t st, A... a)
+{
+    const int per = (range_words_cap + CLEAN_THREADS - 1) / CLEAN_THREADS;
+    if (per <= 4) hipLaunchKernelGGL(clean_kernel<4>, dim3(grid), dim3(CLEAN_THREADS), lds, st, a...);
+    else if (per <= 8) hipLaunchKernelGGL(clean_kernel<8>, dim3(grid), dim3(CLEAN_THREADS), lds, st, a...);
+    else hipLaunchKernelGGL(clean_kernel<CLEAN_PER_MAX>, dim3(grid), dim3(CLEAN_THREADS), lds, st, a...);
+}
+
 // clean_kernel's LDS: bitmap + 16-bit ranks + group sizes (+ staged hits).  Pairs cleaned out of LDS use
 // 16-bit group counters; pairs that stream their hits need 32-bit ones, which must fit as well.
 constexpr int CLEAN_BIG_GRID = 1024;      // clean_big_kernel walks its list with at most this many workgroups
@@ -728,10 +740,10 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
     if (p->n_pairs > 0) {
         int hcap = clean_hcap(p->range_words_cap, p->hcap_want);
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
-        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)p->n_pairs), dim3(CLEAN_THREADS), lds, st,
-                           p->d_pairs, (const int32_t*)nullptr, p->d_nhits, p->d_hits, p->d_hflags, p->d_stats,
-                           p->range_words_cap, clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list,
-                           skip_big ? 0 : 1);
+        launch_clean(p->range_words_cap, (unsigned)p->n_pairs, lds, st,
+                     (const DPair*)p->d_pairs, (const int32_t*)nullptr, (const unsigned long long*)p->d_nhits,
+                     (const unsigned long long*)p->d_hits, p->d_hflags, p->d_stats, p->range_words_cap,
+                     clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1);
         HIPCHK(hipGetLastError());
         // (clean_big_kernel needs a CU with free LDS like any other clean workgroup: behind another plan's join it sits
         // on the stream until that join is over even with nothing to do, and holds back the finish kernel and the
@@ -998,8 +1010,9 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
     }
     if (rc == VAPOR_OK) {
         int hcap = clean_hcap(rw, 4096);
-        hipLaunchKernelGGL(clean_kernel, dim3((unsigned)n_lists), dim3(CLEAN_THREADS), clean_lds_bytes(rw, hcap), st, d_dp,
-                           (const int32_t*)nullptr, d_nh, d_hits, d_fl, d_st, rw, clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1);
+        launch_clean(rw, (unsigned)n_lists, clean_lds_bytes(rw, hcap), st, (const DPair*)d_dp, (const int32_t*)nullptr,
+                     (const unsigned long long*)d_nh, (const unsigned long long*)d_hits, d_fl, d_st, rw,
+                     clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1);
         chk(hipGetLastError(), "clean launch");
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);

@@ -59,6 +59,7 @@ constexpr int CLEAN_THREADS = VAPOR_CLEAN_THREADS;
 constexpr int CLEAN_WAVES = CLEAN_THREADS / 64;
 // words of the clean kernels' value bitmap: values i + j and i - j + len2 stay below 2 * 65536 (positions are 16 bit)
 constexpr int CLEAN_RANGE_WORDS_MAX = 4096;
+constexpr int CLEAN_PER_MAX = (CLEAN_RANGE_WORDS_MAX + CLEAN_THREADS - 1) / CLEAN_THREADS;   // bitmap words per thread at the largest value range
 
 // per-hit working flags inside clean_kernel (upper nibble) and the public ones (lower)
 #define HF_C1 1u
@@ -1056,7 +1057,7 @@ __device__ __forceinline__ void mark_values(uint32_t* bm, uint32_t v0, int len, 
 // FINAL: this is the last clustering step of the pair; its flag pass also does the reductions over the
 // finished flags (kept counts, sum |j-i|, count10, range of i-j over the C1-kept dots) and leaves the
 // public VAPOR_HF_* bits in the flag bytes.
-template <bool AXIS_A, bool NARROW, bool HAVE_BM, bool FINAL, typename HP, typename FP>
+template <bool AXIS_A, bool NARROW, bool HAVE_BM, bool FINAL, int PER_MAX, typename HP, typename FP>
 __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbias, int range_words, uint32_t* bm,
                                              uint16_t* wrank, uint32_t* gcnt, CleanShared* sh,
                                              uint32_t need_clear, uint32_t set_gt10, uint32_t set_rule, CleanClock& pc, int phase0 = 16)
@@ -1087,7 +1088,8 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
     const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
     const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
     uint32_t local = 0;
-    constexpr int PER_MAX = (CLEAN_RANGE_WORDS_MAX + CLEAN_THREADS - 1) / CLEAN_THREADS;   // range_words <= the cap
+    // (PER_MAX: bitmap words per thread the kernel was instantiated for - 4, 8 or 16; the host picks the smallest that
+    // covers the batch's value range, so that a 30 kb range does not walk twelve empty predicated iterations)
     uint32_t stv[PER_MAX];
 #pragma unroll
     for (int q = 0; q < PER_MAX; ++q) {
@@ -1409,7 +1411,7 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
 }
 
 // everything after the records are in place (LDS copy or global), for one pair
-template <bool NARROW, typename HP, typename FP>
+template <bool NARROW, int PER_MAX, typename HP, typename FP>
 __device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots, const DPair& pr, int len2, int range_words,
                                            uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, CleanShared* sh, long long* st, CleanClock& pc)
 {
@@ -1418,19 +1420,19 @@ __device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots
     // i - j over all dots (its bitmap was filled while the records were staged): C1's diagonal groups (>10)
     // and C2's diagonal step; then i + j over all dots (C1) and / or over the dots the diagonal step left (C2)
     if (c1 && c2) {
-        cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
-        cluster_axis<true, NARROW, false, false>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
-        cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
+        cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
+        cluster_axis<true, NARROW, false, false, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
+        cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     } else if (c1) {
 #ifndef VAPOR_ABL_NOAXIS1
-        cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
+        cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
 #endif
 #ifndef VAPOR_ABL_NOAXIS2
-        cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
+        cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
 #endif
     } else if (c2) {
-        cluster_axis<false, NARROW, true, false>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
-        cluster_axis<true, NARROW, false, true>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
+        cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
+        cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     }
 #ifndef VAPOR_ABL_NODIR
     if (s3) directed_stats<NARROW>(recs, hflags, n, gcnt, sh, pc);
@@ -1445,7 +1447,7 @@ __device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots
 
 // One pair of n records / n_dots dots.  Dynamic LDS: bitmap (range_words_cap words) | wrank (u16 each) | group
 // sizes | (IN_LDS: record copy (hcap x 8 B, 8-byte aligned) | flag bytes (hcap)).
-template <bool IN_LDS>
+template <bool IN_LDS, int PER_MAX>
 __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh, const DPair& pr, int n, int n_dots, int len2,
                                            int range_words, const unsigned long long* __restrict__ recs_all,
                                            uint8_t* __restrict__ hflags_all, long long* __restrict__ stats,
@@ -1516,7 +1518,7 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
     __syncthreads();
     pc.mark(8, tid == 0);                          // pass 0
     if (IN_LDS) {
-        clean_body<true>((const unsigned long long*)lrecs, lflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+        clean_body<true, PER_MAX>((const unsigned long long*)lrecs, lflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
         __syncthreads();
         pc.mark(9, tid == 0);                      // what the nested stamps left of clean_body
         // four flag bytes per store (the pair's slot and the LDS copy are both padded to a multiple of four)
@@ -1527,7 +1529,7 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
         }
         pc.mark(10, tid == 0);
     } else {
-        clean_body<false>(grecs, gflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+        clean_body<false, PER_MAX>(grecs, gflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
     }
     pc.flush(tid == 0);
 }
@@ -1536,6 +1538,7 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
 // LDS with 16-bit group counters; the others are appended to big_list for clean_big_kernel.
 // n_hits[p] = records | dots << 32 (join_verify).  len2 and the value range come with the pair record, so the
 // only dependent global reads before the records are the pair record and its counts.
+template <int PER_MAX>
 __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const unsigned long long* __restrict__ recs_all,
@@ -1572,7 +1575,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
         }
         return;
     }
-    clean_pair<true>(p, lds, sh, pr, n, (int)ndots, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
+    clean_pair<true, PER_MAX>(p, lds, sh, pr, n, (int)ndots, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
                      recs_all, hflags_all, stats, range_words_cap, groups_cap, hcap);
 }
 
@@ -1592,7 +1595,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
         const DPair pr = pairs[p];
         const unsigned long long cnt = n_hits[p];
         __syncthreads();                       // the previous pair's statistics have been read
-        clean_pair<false>(p, lds, sh, pr, (int)(uint32_t)cnt, (int)(uint32_t)(cnt >> 32), pr.len2,
+        clean_pair<false, CLEAN_PER_MAX>(p, lds, sh, pr, (int)(uint32_t)cnt, (int)(uint32_t)(cnt >> 32), pr.len2,
                           min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap), recs_all, hflags_all, stats,
                           range_words_cap, groups_cap, 0);
     }
