@@ -280,7 +280,8 @@ constexpr size_t join_lds_bytes()
            sizeof(uint32_t) * tile_words<C, BPS>() +
            sizeof(uint32_t) * etile_words<C, BPS>() + sizeof(unsigned long long) * MAX_READS_PER_TASK +
            sizeof(uint32_t) * (C::THREADS / 64) * (C::QCAP + 4) + sizeof(uint32_t) * (C::THREADS / 64) * rbuf_words<BPS>() +
-           sizeof(uint32_t) * (2 * (C::THREADS / 64) + 4 + MAX_READS_PER_TASK + 2) + sizeof(uint16_t) * tile_pos<C, BPS>();
+           sizeof(uint32_t) * (2 * (C::THREADS / 64) + 4 + MAX_READS_PER_TASK + 2) + sizeof(uint32_t) * 4 * MAX_READS_PER_TASK +
+           sizeof(uint16_t) * tile_pos<C, BPS>();
 }
 
 template <int BPS, int K>
@@ -622,7 +623,13 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     uint32_t* rbufs = queue + JOIN_WAVES * (JQCAP + 4);                        // JOIN_WAVES * rbuf_words
     uint32_t* wtot = rbufs + JOIN_WAVES * rbuf_words<BPS>();                   // 2 * JOIN_WAVES + 4
     int* cstart = reinterpret_cast<int*>(wtot + 2 * JOIN_WAVES + 4);              // MAX_READS_PER_TASK + 2: strip prefix of the group's reads
-    uint16_t* entries = reinterpret_cast<uint16_t*>(cstart + MAX_READS_PER_TASK + 2);  // TA
+    // what the probe needs of every read of the task: pair index, first plane chunk (bit 31: the read has symbols
+    // outside upper-case ACGT), length, allele.  Fetched once per task by one wave (three dependent global loads for all
+    // reads at once); the group boundaries, the strip prefix and every strip's set-up then come out of LDS.  (Before, the
+    // group loop and the strip prefix walked the reads one by one through chains of dependent scalar loads - about
+    // 17 us per table build - and every strip started with a chain of three.)
+    uint32_t* rinfo = reinterpret_cast<uint32_t*>(cstart + MAX_READS_PER_TASK + 2);    // 4 * MAX_READS_PER_TASK
+    uint16_t* entries = reinterpret_cast<uint16_t*>(rinfo + 4 * MAX_READS_PER_TASK);    // TA
     const uint16_t* start16 = reinterpret_cast<const uint16_t*>(start32);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -641,12 +648,24 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     const long long t_block0 = wall_clock64();     // constant-rate clock: comparable between CUs
 #endif
 
+    if (wave == 0 && lane < task.n_reads) {
+        const int idx = task_pairs[task.first + lane];
+        const DPair pp = pairs[idx];
+        const SeqDesc sd = seqs[pp.seq1];
+        rinfo[4 * lane + 0] = (uint32_t)idx;
+        rinfo[4 * lane + 1] = sd.chunk0 | ((BPS == 2 && sd.n_exc > 0) ? 0x80000000u : 0u);
+        rinfo[4 * lane + 2] = (uint32_t)sd.len;
+        rinfo[4 * lane + 3] = (uint32_t)pp.seq2;
+    }
+    __syncthreads();
+
     int g0 = 0;
     while (g0 < task.n_reads) {
-        // group of consecutive pairs that share the allele
-        const int seq2 = pairs[task_pairs[task.first + g0]].seq2;
-        int g1 = g0 + 1;
-        while (g1 < task.n_reads && pairs[task_pairs[task.first + g1]].seq2 == seq2) ++g1;
+        // group of consecutive pairs that share the allele: up to the first pair whose allele differs
+        const int seq2 = __builtin_amdgcn_readfirstlane((int)rinfo[4 * g0 + 3]);
+        const unsigned long long differs =
+            __ballot((uint32_t)(lane >= g0) & ((uint32_t)(lane >= task.n_reads) | (uint32_t)((int)rinfo[4 * lane + 3] != seq2)));
+        const int g1 = differs ? (int)__builtin_ctzll(differs) : task.n_reads;
         const SeqDesc s2 = seqs[seq2];
         const int nk2 = s2.len - K + 1;
         const bool exc2 = (BPS == 2) && s2.n_exc > 0;
@@ -725,15 +744,21 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
             __syncthreads();
             // ---- probe: every read of the group.  The 1024-position strips of ALL reads of the group are
             // dealt round-robin to the waves (a 10 kb read alone has only 10 strips for 16 waves).
-            if (tid == 0) {
-                int acc = 0;
-                for (int r = g0; r < g1; ++r) {
-                    cstart[r - g0] = acc;
-                    const int nk = seqs[pairs[task_pairs[task.first + r]].seq1].len - K + 1;
-                    acc += nk > 0 ? (nk + JCHUNK - 1) / JCHUNK : 0;
+            if (wave == 0) {
+                // strip prefix of the group's reads: one lane per read, a wave prefix sum
+                const int t = g0 + lane;
+                int strips = 0;
+                if (t < g1) {
+                    const int nk = (int)rinfo[4 * t + 2] - K + 1;
+                    strips = nk > 0 ? (nk + JCHUNK - 1) / JCHUNK : 0;
                 }
-                cstart[g1 - g0] = acc;
-                wtot[2 * JOIN_WAVES] = 0u;                 // next strip to hand out
+                const int incl = (int)wave_incl_scan_u32((uint32_t)strips);
+                if (t < g1) cstart[lane] = incl - strips;
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (lane == 0) {
+                    cstart[g1 - g0] = total;
+                    wtot[2 * JOIN_WAVES] = 0u;             // next strip to hand out
+                }
             }
             __syncthreads();
             pc.mark(0, pw);                        // table build (incl. waiting for the slowest wave of the last probe)
@@ -751,12 +776,14 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     if (si >= total_strips) break;
                     while (si >= cstart[r - g0 + 1]) ++r;
                     const int cb = (si - cstart[r - g0]) * JCHUNK;
-                    const DPair pr = pairs[task_pairs[task.first + r]];
-                    const SeqDesc s1 = seqs[pr.seq1];
-                    const int nk1 = s1.len - K + 1;
-                    const uint32_t* rplane = plane + (size_t)s1.chunk0 * WPC;
-                    const uint32_t* re = e1 + (size_t)s1.chunk0;
-                    const bool exc1 = (BPS == 2) && s1.n_exc > 0;
+                    const uint32_t ri_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)rinfo[4 * r + 0]);
+                    const uint32_t ri_chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)rinfo[4 * r + 1]);
+                    const int nk1 = __builtin_amdgcn_readfirstlane((int)rinfo[4 * r + 2]) - K + 1;
+                    const DPair pr = pairs[ri_idx];                // one load; the strip's words below do not wait for it
+                    const uint32_t chunk1 = ri_chunk & 0x7FFFFFFFu;
+                    const uint32_t* rplane = plane + (size_t)chunk1 * WPC;
+                    const uint32_t* re = e1 + (size_t)chunk1;
+                    const bool exc1 = (BPS == 2) && (ri_chunk >> 31) != 0u;
                     unsigned long long* out = hits + pr.hit_off;
                     const bool merge = (BPS == 2) && !exc1 && !exc2;
                     // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
