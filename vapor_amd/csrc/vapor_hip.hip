@@ -76,6 +76,7 @@ struct vapor_ctx {
     // kernels of the other plan fill the CUs it has not reached or has already left).  A caller's stream
     // (vapor_set_stream) replaces both.
     hipStream_t lane[2] = {nullptr, nullptr};
+    hipStream_t fin[2] = {nullptr, nullptr};   // per lane: the stream its plans' finish kernels go to (highest priority)
     unsigned lane_rr = 0;
     bool user_stream = false;
     // staging for vapor_seqset_create*, kept between calls (pinned allocations are slow): ASCII chunks + chunk map
@@ -181,6 +182,10 @@ struct vapor_plan {
     double* h_loci = nullptr;                  // pinned copy of the per-locus records of the last async step
     hipEvent_t ev_t0 = nullptr;
     hipStream_t lane = nullptr;                // the stream this plan's asynchronous steps are enqueued on
+    hipStream_t fin = nullptr;                 // ... and the one their finish kernels go to (NULL: the lane itself)
+    hipEvent_t ev_clean = nullptr;             // the clean kernels of the last enqueued step are done (lane -> fin)
+    hipEvent_t ev_fin = nullptr;               // its finish kernel is done (fin -> lane: the next step's clean kernels wait for it)
+    bool have_fin = false;
     hipEvent_t ev_last = nullptr;              // end of the most recently enqueued asynchronous step
     hipEvent_t ev_after = nullptr;             // vapor_plan_after: the next step waits for it
     bool have_last = false, have_after = false;
@@ -267,6 +272,8 @@ extern "C" int vapor_destroy(vapor_ctx* c)
     for (auto& b : c->pool.free_host) (void)hipHostFree(b.second);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     for (hipStream_t l : c->lane)
+        if (l) (void)hipStreamDestroy(l);
+    for (hipStream_t l : c->fin)
         if (l) (void)hipStreamDestroy(l);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_stage) (void)hipFree(c->d_stage);
@@ -459,7 +466,10 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
 {
     if (!p) return VAPOR_OK;
     (void)hipSetDevice(p->device);
-    if (p->ring_n > 0 && p->lane && ctx_alive(p->ctx)) (void)hipStreamSynchronize(p->lane);   // steps in flight use the blocks
+    if (p->ring_n > 0 && p->lane && ctx_alive(p->ctx)) {                                       // steps in flight use the blocks
+        (void)hipStreamSynchronize(p->lane);
+        if (p->fin) (void)hipStreamSynchronize(p->fin);
+    }
     plan_free_device(p);
     hfree(p->ctx, p->h_stats);
     hfree(p->ctx, p->h_overflow);
@@ -475,6 +485,8 @@ extern "C" int vapor_plan_destroy(vapor_plan* p)
         if (e) (void)hipEventDestroy(e);
     if (p->ev_t0) (void)hipEventDestroy(p->ev_t0);
     if (p->ev_last) (void)hipEventDestroy(p->ev_last);
+    if (p->ev_clean) (void)hipEventDestroy(p->ev_clean);
+    if (p->ev_fin) (void)hipEventDestroy(p->ev_fin);
     if (p->ev_after) (void)hipEventDestroy(p->ev_after);
     delete p;
     return VAPOR_OK;
@@ -711,7 +723,8 @@ static int clean_hcap(int range_words_cap, int want)
 
 static int async_fold(vapor_plan* p);
 
-static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr, bool skip_big = false)
+static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr, bool skip_big = false,
+                         hipEvent_t before_clean = nullptr)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = on ? on : c->stream;
@@ -737,6 +750,8 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ev[1], st));
+    // (the clean kernels overwrite the statistics the previous step's finish kernel reads on its own stream)
+    if (before_clean) HIPCHK(hipStreamWaitEvent(st, before_clean, 0));
     if (p->n_pairs > 0) {
         int hcap = clean_hcap(p->range_words_cap, p->hcap_want);
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
@@ -1204,7 +1219,13 @@ static int plan_lane(vapor_plan* p, hipStream_t* out)
     if (!p->lane) {
         const unsigned l = c->lane_rr++ & 1u;
         if (!c->lane[l]) HIPCHK(hipStreamCreateWithFlags(&c->lane[l], hipStreamNonBlocking));
+        if (!c->fin[l]) {
+            int lo = 0, hi = 0;                  // (numerically lowest = highest priority)
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&c->fin[l], hipStreamNonBlocking, hi));
+        }
         p->lane = c->lane[l];
+        p->fin = c->fin[l];
     }
     *out = p->lane;
     return VAPOR_OK;
@@ -1217,6 +1238,7 @@ static int async_fold(vapor_plan* p)
     int rc = plan_lane(p, &st);
     if (rc != VAPOR_OK) return rc;
     HIPCHK(hipStreamSynchronize(st));
+    if (p->fin && p->fin != st) HIPCHK(hipStreamSynchronize(p->fin));
     for (int i = 0; i < p->ring_n; ++i) {
         float x = 0;
         hipEvent_t* ev = p->ring[(size_t)i].data();
@@ -1251,26 +1273,41 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
             for (auto& e : r) { e = nullptr; HIPCHK(hipEventCreate(&e)); }
         HIPCHK(hmalloc(p->ctx, (void**)&p->h_loci, sizeof(double) * 8 * (size_t)std::max<int64_t>(p->n_loci, 1)));
         HIPCHK(hipEventCreateWithFlags(&p->ev_last, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_clean, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_fin, hipEventDisableTiming));
     }
+    // The finish kernel goes to a stream of its own (highest priority): as a kernel it needs a CU with 56 free registers
+    // per SIMD, which another plan's join (4 waves x 120) does not leave, so behind the clean kernels on the plan's
+    // stream it held back the plan's next join until that other join was over (7 % of cfg2's rate).  On its own stream
+    // it takes the first CU a join workgroup leaves; the next step's clean kernels wait for it, its join does not.
+    hipStream_t fs = (p->fin && !p->ctx->user_stream) ? p->fin : st;
     if (p->have_after) {                        // vapor_plan_after: what the caller enqueued elsewhere comes first
-        HIPCHK(hipStreamWaitEvent(st, p->ev_after, 0));
+        HIPCHK(hipStreamWaitEvent(fs, p->ev_after, 0));   // (it is the finish kernel that overwrites the records)
         p->have_after = false;
     }
     // the sticky overflow counter reports on the asynchronous steps since the last vapor_plan_sync: what a blocking
     // run counted before it resized the slots is not theirs
     if (p->ring_n == 0 && p->acc_n == 0) HIPCHK(hipMemsetAsync(p->d_overflow + 2, 0, sizeof(unsigned int), st));
     hipEvent_t* ev = p->ring[(size_t)p->ring_n].data();
-    rc = plan_run_once(p, false, ev, st, p->big_known && p->n_big == 0);
+    rc = plan_run_once(p, false, ev, st, p->big_known && p->n_big == 0, (fs != st && p->have_fin) ? p->ev_fin : nullptr);
     if (rc != VAPOR_OK) return rc;
     double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
+    if (fs != st) {
+        HIPCHK(hipEventRecord(p->ev_clean, st));
+        HIPCHK(hipStreamWaitEvent(fs, p->ev_clean, 0));
+    }
     if (p->n_loci > 0) {
         // (the finish kernel writes the pinned host copy itself: no copy kernel behind it)
-        hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, st, p->d_reads, p->d_locus_first, p->d_stats,
+        hipLaunchKernelGGL(finish_kernel, dim3((unsigned)p->n_loci), dim3(64), 0, fs, p->d_reads, p->d_locus_first, p->d_stats,
                            p->d_gt, p->d_read_scores, d_out, p->h_loci);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(ev[3], st));
-    HIPCHK(hipEventRecord(p->ev_last, st));
+    HIPCHK(hipEventRecord(ev[3], fs));
+    HIPCHK(hipEventRecord(p->ev_last, fs));
+    if (fs != st) {
+        HIPCHK(hipEventRecord(p->ev_fin, fs));
+        p->have_fin = true;
+    }
     p->have_last = true;
     ++p->ring_n;
     return VAPOR_OK;
