@@ -261,11 +261,12 @@ def main() -> None:
                           "device_total": round(avg["total_ms"], 4), "join_launches": launches,
                           "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)}},
             "upload_pack_s": round(res.upload_s, 4),
-            # `bound`: the roof the kernel is nearest to.  The counter passes (profiles/r02_cfg2_util.json) and the measured
-            # issue rates of its instruction classes (profiles/r02_valu_peak.txt) put the join at about 0.6 of what the
-            # vector unit sustains for its mix, the LDS array under half busy, the fabric at 2 % of HBM peak.  achieved /
-            # peak / frac are still priced against the HBM roof the task names, with SURVEY 8d's algorithmic bytes;
-            # traffic_* use the bytes the kernel really moves; binds.* hold the utilisations.
+            # `bound`: the roof the kernel sits under.  The counter passes (profiles/r02_cfg2_util.json) give the occupancy of
+            # the vector ALUs directly - (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / SQ_BUSY_CU_CYCLES, gfx950 issues two simple
+            # vector instructions of different waves in one quad-cycle (profiles/r02_valu_ops.txt) - 0.78 for the join, the LDS
+            # array half busy, the fabric at 2 % of HBM peak.  achieved / peak / frac are still priced against the HBM roof
+            # the task names, with SURVEY 8d's algorithmic bytes; traffic_* use the bytes the kernel really moves; binds.*
+            # hold the utilisations.
             "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
