@@ -18,6 +18,17 @@ _utf8.restype = ctypes.c_void_p
 _utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
 
 
+def _ascii_data_offset() -> int:
+    """Where the characters of a compact ASCII str lie relative to id(str) in this interpreter (measured, not assumed)."""
+    probe = "ACGTACGTACGTACGT" * 4
+    size = ctypes.c_ssize_t()
+    p = _utf8(probe, ctypes.byref(size))
+    return (p - id(probe)) if p and size.value == len(probe) else -1
+
+
+_ASCII_OFF = _ascii_data_offset()
+
+
 def _as_bytes(s) -> bytes:
     return s if isinstance(s, (bytes, bytearray)) else s.encode("latin-1", "replace")
 
@@ -34,10 +45,25 @@ class SeqSet:
         # keeps it one byte per character; PyUnicode_AsUTF8AndSize returns that buffer), anything else as the
         # bytes it is or encodes to (characters outside Latin-1 become '?', which matches nothing anyway).
         keep = []
-        ptrs = (ctypes.c_void_p * n1)()
         self.lens = np.zeros(self.n, dtype=np.int32)
         size = ctypes.c_ssize_t()
-        for t, sq in enumerate(seqs):
+        fast = (self.n > 64 and 0 < _ASCII_OFF < 256 and isinstance(seqs, (list, tuple)) and set(map(type, seqs)) == {str}
+                and all(map(str.isascii, seqs)))
+        if fast:
+            # all ASCII str (the usual case): the characters of every one lie at the same offset behind the object, so the
+            # pointers are id() + offset - four passes of map() instead of a ctypes call per sequence (2 200 sequences:
+            # 1.1 ms -> 0.3 ms of a 2.4 ms upload)
+            addr = np.fromiter(map(id, seqs), dtype=np.uint64, count=self.n) + np.uint64(_ASCII_OFF)
+            self.lens = np.fromiter(map(len, seqs), dtype=np.int32, count=self.n)
+            for t in (0, self.n // 2, self.n - 1):          # (spot check against the interpreter's own answer)
+                if _utf8(seqs[t], ctypes.byref(size)) != int(addr[t]) or size.value != int(self.lens[t]):
+                    fast = False
+        if fast:
+            ptrs = ctypes.cast(addr.ctypes.data, ctypes.POINTER(ctypes.c_void_p))
+            keep.append(addr)
+        else:
+            ptrs = (ctypes.c_void_p * n1)()
+        for t, sq in enumerate(() if fast else seqs):
             if isinstance(sq, str):
                 p = _utf8(sq, ctypes.byref(size))
                 if p and size.value == len(sq):
