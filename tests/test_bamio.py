@@ -265,3 +265,29 @@ def test_native_chop_equals_the_python_statement(tmp_path):
     bamio.write_bam(p3, [("c", 60000)], big)
     nat, py = _chop_both(p3, [("c", 500, 25000, 500)])
     assert nat == py and len(nat[0]) == 300
+
+
+def test_native_chop_from_several_threads(tmp_path):
+    """One BamFile read from eight threads at once (every thread gets its own library handle, the index is shared):
+    the regions come back exactly as from one thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(77)
+    contig = synth.random_dna(rng, 80000)
+    recs = []
+    for i in range(200):
+        n = int(rng.integers(500, 7000))
+        pos = int(rng.integers(0, 70000))
+        read, cg = synth.mutate(rng, contig[pos:pos + n])
+        recs.append(("t%d" % i, 0, pos, cg, read))
+    path = str(tmp_path / "thr.bam")
+    bamio.write_bam(path, [("c", 80000)], recs, block_size=4000)
+    qs = []
+    for _ in range(160):
+        a = int(rng.integers(600, 70000)); w = int(rng.integers(100, 5000)); f = int(rng.choice([50, 200, 500]))
+        qs.append((a - f, a + w + f, f))
+    b = bamio.BamFile(path)
+    serial = [b.chop_native("c", a, e, f) for a, e, f in qs]
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        threaded = list(pool.map(lambda q: b.chop_native("c", *q), qs))
+    b.close()
+    assert threaded == serial and sum(len(x) for x in serial) > 100

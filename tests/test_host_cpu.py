@@ -419,6 +419,32 @@ def test_bed_cli_from_files_without_samtools(fake, case, tmp_path):
     assert got == exp and len(exp.splitlines()) == len(case["vapor_text"].splitlines())
 
 
+def test_loci_started_on_threads_give_the_same_table(fake, tmp_path, monkeypatch):
+    """pipeline.run_batch starts the loci of a batch on several threads when the backend reads files in-process (the
+    BGZF inflation releases the GIL): the table is the one a single thread writes, row for row."""
+    world = synth.make_world(seed=23, n_loci=40, svtypes=("DEL", "INV", "INS", "DEL"), span_range=(100, 1500), read_len=2500,
+                             n_reads=6)
+    for c in world.reads:
+        world.reads[c] = sorted(world.reads[c], key=lambda r: r.pos)
+    bed = tmp_path / "in.bed"
+    bed.write_text(synth.bed_text(world))
+    fa, bam = _world_to_files(world, tmp_path)
+
+    def run(threads, out):
+        monkeypatch.setenv("VAPOR_PREFETCH_THREADS", str(threads))
+        seqio.set_backend(seqio.InProcessBam())
+        try:
+            assert cli.main(["bed", "--sv-input", str(bed), "--reference", fa, "--pacbio-input", bam,
+                             "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+        finally:
+            seqio.set_backend(None)
+        return out.read_text()
+
+    one = run(1, tmp_path / "one.vapor")
+    many = run(6, tmp_path / "many.vapor")
+    assert many == one and len(one.splitlines()) >= 40
+
+
 def test_native_cigar_walk_equals_the_python_statement():
     """vapor_cigar2alignstart (host helper in the C ABI) against the Python restatement of SF:309-337: the survey's
     known answers and random CIGARs with every operation, junk characters, empty strings and long walks."""

@@ -15,6 +15,7 @@ environment (the reference bundles none), so it has not been run on one.
 from __future__ import annotations
 
 import struct
+import threading
 import zlib
 from typing import Dict, Iterator, List, Tuple
 
@@ -201,7 +202,11 @@ class BamFile:
             self.refs.append((name, l_ref))
             self.tid[name] = t
         self.first_record = c.tell()
-        self._native = None                 # vapor_bam handle of the HIP library's host helper (opened on first use)
+        # vapor_bam handles of the HIP library's host helper, one per thread that reads (opened on first use; a handle owns
+        # its inflate buffers, the .bai index above is shared): pipeline.run_batch starts the loci of a batch on a few threads
+        self._tls = threading.local()
+        self._handles = []
+        self._lock = threading.Lock()
         import os
         bai = path + ".bai" if os.path.exists(path + ".bai") else path[:-4] + ".bai"
         self.index = BaiIndex(bai)
@@ -254,21 +259,26 @@ class BamFile:
         tid = self.tid.get(chrom)
         if tid is None:
             return []
-        if self._native is None:
+        tl = self._tls
+        if getattr(tl, "native", None) is None:
             h = ctypes.c_void_p()
             if lib.vapor_bam_open(self.path.encode(), ctypes.byref(h)) != 0:
                 raise OSError(lib.vapor_bam_last_error().decode())
-            self._native = h
-            self._buf = {"seq": np.empty(1 << 20, dtype=np.uint8), "names": ctypes.create_string_buffer(1 << 16),
-                         "meta": np.empty(4 * 256, dtype=np.int64), "need": np.zeros(3, dtype=np.int64)}
+            if threading.current_thread() is not threading.main_thread():
+                lib.vapor_bam_set_threads(h, 2)       # several readers at once: fewer inflate threads each
+            tl.native = h
+            tl.buf = {"seq": np.empty(1 << 20, dtype=np.uint8), "names": ctypes.create_string_buffer(1 << 16),
+                      "meta": np.empty(4 * 256, dtype=np.int64), "need": np.zeros(3, dtype=np.int64)}
+            with self._lock:
+                self._handles.append(h)
         ch = self.index.chunks(tid, max(int(start) - 1, 0), int(end))
         if not ch:
             return []
         chunks = np.asarray(ch, dtype=np.uint64).reshape(-1)
         n = ctypes.c_int32(0)
         while True:
-            bf = self._buf
-            rc = lib.vapor_bam_chop(self._native, tid, int(start), int(end), int(flank_length), len(ch), chunks.ctypes.data,
+            bf = tl.buf
+            rc = lib.vapor_bam_chop(tl.native, tid, int(start), int(end), int(flank_length), len(ch), chunks.ctypes.data,
                                     bf["seq"].ctypes.data, bf["seq"].size, ctypes.cast(bf["names"], ctypes.c_void_p), len(bf["names"]),
                                     bf["meta"].ctypes.data, bf["meta"].size // 4, ctypes.byref(n), bf["need"].ctypes.data)
             if rc == 0:
@@ -279,7 +289,7 @@ class BamFile:
                     raise IndexError("string index out of range")      # what '' [1] raises in SF:331
                 raise ValueError(msg)
             need = bf["need"]
-            self._buf = {"seq": np.empty(int(need[0]) * 2 + 1024, dtype=np.uint8),
+            tl.buf = {"seq": np.empty(int(need[0]) * 2 + 1024, dtype=np.uint8),
                          "names": ctypes.create_string_buffer(int(need[1]) * 2 + 256),
                          "meta": np.empty(4 * (int(need[2]) * 2 + 16), dtype=np.int64), "need": need}
         seq, meta, names = bf["seq"], bf["meta"], bf["names"].raw
@@ -290,10 +300,13 @@ class BamFile:
         return out
 
     def close(self) -> None:
-        if self._native is not None:
+        with self._lock:
+            hs, self._handles = self._handles, []
+        if hs:
             from . import _lib
-            _lib.load().vapor_bam_close(self._native)
-            self._native = None
+            for h in hs:
+                _lib.load().vapor_bam_close(h)
+        self._tls = threading.local()
 
     def __del__(self):
         try:

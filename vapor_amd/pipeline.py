@@ -314,6 +314,22 @@ def run_sync(gen, engine=None, figure_fn: Optional[Callable] = None):
         return e.value
 
 
+def _prefetch_threads(n_gens: int) -> int:
+    """Threads that start the loci of a batch (VAPOR_PREFETCH_THREADS; default up to 8, 1 = off)."""
+    import os
+    from . import seqio
+    if n_gens < 16 or not getattr(seqio.get_backend(), "threads_ok", False) or os.environ.get("VAPOR_BAM_NATIVE", "1") == "0":
+        return 1
+    want = os.environ.get("VAPOR_PREFETCH_THREADS")
+    if want is not None:
+        return max(1, int(want))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(8, cores // 2))
+
+
 def run_batch(gens: Sequence, engine=None, figure_fn: Optional[Callable] = None) -> List[object]:
     """Drive many locus generators in lockstep.  Returns, per generator, its score list or the
     exception it ended with."""
@@ -338,8 +354,17 @@ def run_batch(gens: Sequence, engine=None, figure_fn: Optional[Callable] = None)
             results[t] = e
             pending.pop(t, None)
 
-    for t in range(len(gens)):
-        advance(t, first=True)
+    # The first stretch of a locus generator is its read extraction (window from the FASTA, reads of the region from the
+    # BAM: BGZF inflation in the library's host helper, which releases the GIL).  With a backend whose handles are per
+    # thread the loci of a batch start on a few threads, so that one locus inflates while another's Python runs.
+    n_thr = _prefetch_threads(len(gens))
+    if n_thr > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=n_thr) as pool:
+            list(pool.map(lambda t: advance(t, first=True), range(len(gens))))
+    else:
+        for t in range(len(gens)):
+            advance(t, first=True)
     while pending:
         idx = sorted(pending)
         ans = _answer(engine, [pending[t] for t in idx], figure_fn)

@@ -15,6 +15,7 @@ reference's semantics exactly; they are host-side integer/string work.
 from __future__ import annotations
 
 import os
+import threading
 import re
 import shutil
 import subprocess
@@ -73,8 +74,7 @@ class FaiFasta:
         a, b = start - 1, end
         first = offset + (a // linebases) * linewidth + a % linebases
         last = offset + ((b - 1) // linebases) * linewidth + (b - 1) % linebases + 1
-        self._fh.seek(first)
-        raw = self._fh.read(last - first)
+        raw = os.pread(self._fh.fileno(), last - first, first)      # (positioned read: several threads may fetch at once)
         return raw.replace(b"\n", b"").replace(b"\r", b"").decode("ascii")
 
     def lines(self, region: str) -> List[str]:
@@ -110,16 +110,22 @@ class InProcessBam(SamtoolsHybrid):
     """BAM and BAI read in-process as well (vapor_amd.bamio): no process per locus at all, and the records reach
     the trimming code as fields, not as text to be split again.  The default backend."""
 
+    threads_ok = True                  # pipeline.run_batch may start loci on several threads (native chop, positioned reads)
+
     def __init__(self) -> None:        # noqa: D401 - does not require the samtools binary
         self.exe = None
         self._fa = {}
         self._bam = {}
+        self._open_lock = threading.Lock()
 
     def _open(self, bam: str):
         from . import bamio
         b = self._bam.get(bam)
         if b is None:
-            b = self._bam[bam] = bamio.BamFile(bam)
+            with self._open_lock:
+                b = self._bam.get(bam)
+                if b is None:
+                    b = self._bam[bam] = bamio.BamFile(bam)
         return b
 
     def view_lines(self, bam: str, region: str) -> Iterable[str]:
@@ -167,7 +173,10 @@ class InProcessBam(SamtoolsHybrid):
     def _fasta(self, ref: str) -> FaiFasta:
         fa = self._fa.get(ref)
         if fa is None:
-            fa = self._fa[ref] = FaiFasta(ref)
+            with self._open_lock:
+                fa = self._fa.get(ref)
+                if fa is None:
+                    fa = self._fa[ref] = FaiFasta(ref)
         return fa
 
     def faidx_lines(self, ref: str, region: str) -> Iterable[str]:
