@@ -338,6 +338,41 @@ def test_async_steps_equal_blocking_run(eng):
     plan.close()
 
 
+def test_async_steps_on_a_stream_of_the_callers(eng):
+    """vapor_set_stream: everything - the asynchronous steps and their finish kernel too - runs on the caller's stream,
+    in order with what the caller enqueues there; back on the library's own streams afterwards."""
+    import torch
+    from vapor_amd import workload as wl
+    w = wl.make_workload("tiny", seed=13, **wl.WORKLOADS["tiny"])
+    ss = eng.seqset(w.seqs)
+    plan = eng.plan(ss, w.pairs)
+    plan.set_reads(wl.read_table(w), w.n_loci)
+    ref = plan.run_loci().copy()
+    buf = torch.full((w.n_loci, 8), -1.0, dtype=torch.float64, device="cuda")   # (first: this is what initialises torch's device)
+    mine = torch.cuda.Stream()
+    eng.set_stream(mine.cuda_stream)
+    try:
+        copies = []
+        for _ in range(4):
+            plan.run_loci_async(device_out=buf.data_ptr())
+            with torch.cuda.stream(mine):
+                copies.append(buf.clone())               # same stream: ordered after the step without any event
+                buf.fill_(-3.0)
+        got = plan.sync().copy()
+    finally:
+        eng.set_stream(0)
+    torch.cuda.synchronize()
+    for c in copies + [torch.from_numpy(got)]:
+        c = c.cpu().numpy()
+        assert np.array_equal(np.isnan(c), np.isnan(ref)) and np.array_equal(c[~np.isnan(c)], ref[~np.isnan(ref)])
+    for _ in range(3):
+        plan.run_loci_async()
+    got = plan.sync().copy()
+    assert np.array_equal(got[~np.isnan(got)], ref[~np.isnan(ref)])
+    plan.close()
+    ss.close()
+
+
 def test_async_steps_with_a_pair_left_to_the_big_kernel(eng):
     """An asynchronous step leaves clean_big_kernel out only when the plan's blocking run saw no pair that needs it:
     with a pair of more than 65 535 dots (tandem repeats on both sides) in the batch the steps still run it, and the

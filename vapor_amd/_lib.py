@@ -48,15 +48,39 @@ class VaporHipError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  A PyTorch-ROCm wheel carries its own libamdhip64 / libhsa-runtime64; when this library
+    is loaded first it binds to the system's copy, and torch's copy then finds no GPU ("No HIP GPUs are available"): two
+    runtimes do not share the device.  Loaded after torch it binds to torch's copy (same SONAME) and all is well - so when
+    torch is installed but not imported yet, its runtime is loaded here (the shared object only, not the package), and
+    the order of imports stops mattering.  VAPOR_HIP_RUNTIME=system keeps the system's copy."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("VAPOR_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        where = list(spec.submodule_search_locations or []) if spec else []
+        for d in where:
+            p = os.path.join(d, "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+                return
+    except Exception:            # noqa: BLE001 - best effort; the plain load below still works when torch comes first or never
+        pass
+
+
 def load() -> ctypes.CDLL:
     """Load the HIP library or fail loudly."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    lib_path = SO_PATH
+    if not os.path.exists(lib_path):
         raise RuntimeError("%s is missing - the HIP extension has not been built "
-                           "(run `python -m vapor_amd.build`); there is no CPU fallback" % SO_PATH)
-    _lib = bind(ctypes.CDLL(SO_PATH))
+                           "(run `python -m vapor_amd.build`); there is no CPU fallback" % lib_path)
+    _share_torch_hip_runtime()
+    _lib = bind(ctypes.CDLL(lib_path))
     return _lib
 
 
