@@ -19,6 +19,8 @@ _pg = None
 def _device_ordinal() -> int:
     """LOCAL_RANK folded onto the GPUs present (several ranks may share one GPU)."""
     lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if lr == 0:
+        return 0                       # (a single process never pays the import of torch: 1.5 s of a short run)
     try:
         import torch
         n = torch.cuda.device_count()
