@@ -327,7 +327,8 @@ def _prefetch_threads(n_gens: int) -> int:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return max(1, min(8, cores // 2))
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))       # ranks sharing this host's cores (torchrun)
+    return max(1, min(8, cores // (2 * ranks_here)))
 
 
 def run_batch(gens: Sequence, engine=None, figure_fn: Optional[Callable] = None) -> List[object]:
