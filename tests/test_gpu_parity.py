@@ -318,6 +318,30 @@ def test_run_records_expand_to_the_oracle_dots(eng, oracle):
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "runs")
 
 
+def test_sequences_at_the_length_limit(eng, oracle):
+    """VAPOR_MAX_SEQ_LEN = 65 535 bases on both sides (three allele tiles, strips up to the 16-bit position limit, the
+    clean kernels' value range at its 4 096-word cap): statistics exact for every window size and scorer; one base more
+    is refused per pair with VAPOR_E_ARG, the other pairs of the batch are unaffected."""
+    from vapor_amd import synth
+    from vapor_amd import _lib as L
+    rng = np.random.default_rng(65535)
+    n = L.MAX_SEQ_LEN
+    allele = synth.random_dna(rng, n)
+    read = (synth.mutate(np.random.default_rng(3), allele[2000:60000], 0.01, 0.03, 0.03)[0] + synth.random_dna(rng, n))[:n]
+    exact_tail = allele[n - 9000:]                       # a read that ends on the allele's last base
+    seqs = [allele, read, exact_tail]
+    rows = [(1, 0, 0, 10, 7), (1, 0, 0, 20, 3), (1, 0, 30000, 30, 1), (1, 0, 0, 40, 3), (2, 0, 0, 10, 7), (2, 0, 50000, 10, 3)]
+    assert len(read) == n and len(allele) == n
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "limit")
+    too_long = allele + "A"
+    seqs2 = [allele, exact_tail, too_long]
+    ss = eng.seqset(seqs2)
+    st = eng.score(ss, eng.make_pairs([(1, 0, 0, 10, 7), (1, 2, 0, 10, 7), (2, 0, 0, 10, 7)]))
+    assert st[0, 15] == 0 and st[0, 0] > 8000
+    assert st[1, 15] == L.E_ARG and st[2, 15] == L.E_ARG
+    ss.close()
+
+
 def test_async_steps_equal_blocking_run(eng):
     """vapor_plan_run_loci_async / vapor_plan_sync: the enqueue-only steps give the records of the blocking run,
     more steps than event sets are fine, and the timings are per-step averages."""
