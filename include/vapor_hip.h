@@ -171,7 +171,9 @@ int vapor_plan_run_loci(vapor_plan* plan, void* d_loci_out, double* loci_out, do
  * in one of them.
  * Streams: every plan keeps to one of two streams the context owns, dealt out in turn, so the steps of two plans in
  * flight overlap on the device (a caller that works through a sequence of batches gets this by keeping two plans
- * alive: the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage).  vapor_plan_then makes a
+ * alive: the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage).  The finish kernel of a step
+ * goes to a third, high-priority stream: the plan's next join does not wait for it, its next clean kernels do, and
+ * vapor_plan_then / vapor_plan_sync see it through the step's end event.  vapor_plan_then makes a
  * stream of the caller's wait, on the device, for the plan's most recently enqueued step (e.g. before a
  * collective that reads d_loci_out); vapor_plan_after makes the plan's next step wait for what the caller has
  * enqueued on its stream so far (before d_loci_out is overwritten).  vapor_set_stream makes the library enqueue
