@@ -1229,8 +1229,14 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
         if (need_clear && (hflags[h] & need_clear)) continue;
         const RecV r = rec_decode(recs[h]);
         const uint32_t g = group_of(first_value(r));
-        if (NARROW) atomicAdd(&gcnt[g >> 1], (uint32_t)r.len << ((g & 1u) * 16));
-        else atomicAdd(&gcnt[g], (uint32_t)r.len);
+        if (NARROW) {
+            atomicAdd(&gcnt[g >> 1], (uint32_t)r.len << ((g & 1u) * 16));
+            // (the LDS copy of a record has 15 spare bits above the strand bit: the flag pass takes the group from there
+            // instead of ranking the value again - two LDS reads and a popcount per record)
+            reinterpret_cast<uint16_t*>(const_cast<unsigned long long*>(&recs[h]))[3] = (uint16_t)((g << 1) | (r.rc ? 1u : 0u));
+        } else {
+            atomicAdd(&gcnt[g], (uint32_t)r.len);
+        }
     }
     __syncthreads();
     if (set_rule) {
@@ -1249,9 +1255,10 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
         uint32_t f = hflags[h];
         const bool sel = !(need_clear && (f & need_clear));
         if (!(sel || FINAL)) continue;
-        const RecV r = rec_decode(recs[h]);
+        const unsigned long long raw = recs[h];
+        const RecV r = rec_decode(raw);
         if (sel) {
-            const uint32_t c = gsize(group_of(first_value(r)));
+            const uint32_t c = gsize(NARROW ? (uint32_t)(raw >> 49) : group_of(first_value(r)));
             if (set_gt10 && c > 10u) f |= set_gt10;
             if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
         }
