@@ -362,6 +362,41 @@ def test_async_steps_equal_blocking_run(eng):
     plan.close()
 
 
+def test_runs_with_a_soft_masked_allele(eng, oracle):
+    """Alleles with symbols outside upper-case ACGT (lower-case stretches as in a soft-masked reference, N, IUPAC) and reads
+    without: the join still forms runs - they end before the first such symbol and never start behind one - so the
+    records stay a fraction of the dots, and the dots and every statistic are the oracle's, for every window size."""
+    from vapor_amd import synth
+    rng = np.random.default_rng(57)
+    allele = synth.random_dna(rng, 9000)
+    b = bytearray(allele.encode())
+    for a, n in ((300, 40), (1500, 700), (2300, 1), (2301, 1), (4000, 25), (6990, 30), (8960, 40)):
+        b[a:a + n] = bytes(b[a:a + n]).lower()
+    for a, ch in ((3000, "N"), (3050, "R"), (5000, "N"), (5001, "N"), (5031, "n"), (7000, "Y")):
+        b[a] = ord(ch)
+    masked = b.decode()
+    exact = allele[100:8900]                            # every k-mer of the read lies on the allele's diagonal
+    noisy = synth.mutate(np.random.default_rng(9), allele[200:8800], 0.002, 0.004, 0.004)[0]
+    inv = allele[500:3000] + synth.revcomp(allele[3000:5500]) + allele[5500:8000]
+    seqs = [masked, exact, noisy, inv, allele]
+    rows = [(1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (3, 0, 0, 10, 7), (1, 0, 0, 20, 3), (2, 0, 1234, 30, 1), (1, 0, 0, 40, 3),
+            (1, 4, 0, 10, 7)]
+    ss = eng.seqset(seqs)
+    plan = eng.plan(ss, eng.make_pairs(rows))
+    st = plan.run().copy()
+    rec = plan.record_counts()
+    hits, _fl, off = plan.fetch_hits(range(len(rows)), want_flags=True)
+    for t, (s1, s2, off2, k, _f) in enumerate(rows):
+        exp = oracle.dotdata_array(k, seqs[s1], seqs[s2][off2:])
+        got = hits[off[t]:off[t + 1]]
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert st[t, 0] == len(exp) and got.tolist() == exp.tolist(), (t, rows[t])
+    assert st[0, 0] > 6000 and rec[0] * 8 < st[0, 0]      # runs despite the exceptions: a few hundred records for thousands of dots
+    assert st[0, 0] < st[6, 0]                              # the masked stretches carry no dots
+    plan.close()
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "soft-masked")
+
+
 def test_async_steps_on_a_stream_of_the_callers(eng):
     """vapor_set_stream: everything - the asynchronous steps and their finish kernel too - runs on the caller's stream,
     in order with what the caller enqueues there; back on the library's own streams afterwards."""

@@ -147,6 +147,7 @@ struct vapor_seqset {
 
 struct Launch {
     int bps, k, task_begin, n_tasks;
+    bool aexc;     // 2-bit planes, alleles with symbols outside upper-case ACGT (join_kernel<.., AEXC = true>)
 };
 
 struct vapor_plan {
@@ -220,10 +221,11 @@ extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 template <int BPS, int K>
 static hipError_t set_join_attr()
 {
+    if constexpr (BPS == 2) (void)&join_kernel<JoinCfg, BPS, K, true>;
 #ifndef VAPOR_AB_DYN_LDS
     return hipSuccess;
 #endif
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinCfg, BPS, K>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinCfg, BPS, K, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<JoinCfg, BPS>());
 }
 
@@ -553,7 +555,9 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         int64_t n1 = s1.len, n2 = std::max(0, s2.len - a.off2);
         int64_t cap = std::min(n1, n2) + ((n1 * n2) >> 17) + 1024;
         d.cap = (uint32_t)std::min<int64_t>(cap, ctx->max_pair_cap);
-        mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : 2;
+        // 2: 2-bit planes; 3: 2-bit planes, the allele has symbols outside upper-case ACGT (a launch of its own: the table
+        // leaves their k-mers out and runs end before them); 4: both sides have such symbols - the 4-bit planes
+        mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : (s2.n_exc > 0 ? 3 : 2);
         rw = std::max(rw, (s1.len + s2.len + 2 + 31) / 32);
         // records expected: the shared diagonal in runs of a few dots plus the chance dots
         hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 10 + ((n1 * n2) >> 19) + 192);
@@ -572,8 +576,8 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         return x < y;
     });
     p->task_pairs = order;
-    auto tiles_of = [&](int32_t seq2, int k, int bps) {
-        const int ta = bps == 2 ? tile_pos<JoinCfg, 2>() : tile_pos<JoinCfg, 4>();
+    auto tiles_of = [&](int32_t seq2, int k, int m) {
+        const int ta = m != 4 ? tile_pos<JoinCfg, 2>() : tile_pos<JoinCfg, 4>();
         return std::max(1, (set->h[seq2].len - k + 1 + ta - 1) / ta);
     };
     for (size_t q = 0; q < order.size();) {
@@ -622,7 +626,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         }
         std::vector<size_t> cuts;
         pack(lo, &cuts);
-        p->launches.push_back(Launch{m, k, (int)p->tasks.size(), 0});
+        p->launches.push_back(Launch{m == 4 ? 4 : 2, k, (int)p->tasks.size(), 0, m == 3});
         for (size_t c = 0; c < cuts.size(); ++c) {
             const size_t t0 = q + cuts[c], t1 = q + (c + 1 < cuts.size() ? cuts[c + 1] : n);
             DTask tk;
@@ -666,9 +670,14 @@ template <int BPS, int K>
 static void launch_join(vapor_plan* p, const Launch& L, bool first, hipStream_t st)
 {
     const vapor_seqset* s = p->set;
-    hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
-                       st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
-                       p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
+    if (BPS == 2 && L.aexc)
+        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, (BPS == 2)>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
+                           st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
+                           p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
+    else
+        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, false>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
+                           st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
+                           p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }
 
 static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 / 10 + 8; }

@@ -447,13 +447,17 @@ __device__ __forceinline__ unsigned long long win2(const uint32_t* plane, uint32
 // MERGE (runs are formed: 2-bit planes, no exception symbol on either side) is a template parameter so that the body is
 // one straight line: with a (uniform) branch on it inside, the compiler reads the symbols after the k-mer in a second
 // round trip under that branch and does not start the second candidate's reads before the first is done.
-template <int BPS, int K, bool MERGE>
+// MERGE: 0 = every dot its own record; 1 = runs, neither side has a symbol outside upper-case ACGT; 2 = runs, the allele has
+// such symbols (soft-masked references: the usual case with real genomes for the scorers that do not upper-case) - a
+// k-mer that covers one is not in the table, so a run ends before the first of them and the dot before a candidate
+// exists only if the symbol before it is none.  The allele's exception bits come from etile.
+template <int BPS, int K, int MERGE>
 __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, const uint16_t* entries,
-                                              const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
-                                              int nk1, unsigned long long* cnt_r, uint32_t cap,
+                                              const uint32_t* rbuf, const uint32_t* tile, const uint32_t* etile, int cb, int ts,
+                                              int off2, int tn, int nk1, unsigned long long* cnt_r, uint32_t cap,
                                               unsigned long long* out)
 {
-    constexpr bool merge = MERGE;
+    constexpr bool merge = MERGE != 0;
     using KT = KeyT<BPS, K>;
     const int lane = threadIdx.x & 63;
 #ifdef VAPOR_ABL_NOVERIFY
@@ -530,9 +534,14 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
             rcm[q] = dr == 0u;
             // the dot before this one exists <=> the symbols just before match (and nothing forbids a run there): then it
             // is not the head of its run
-            const uint32_t cont = merge ? ((il & (VREC_MAX_LEN - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
-                                           (uint32_t)((int)((sx[0] & 3u) - 1u) >> 31))
-                                        : 0u;
+            uint32_t cont = merge ? ((il & (VREC_MAX_LEN - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
+                                     (uint32_t)((int)((sx[0] & 3u) - 1u) >> 31))
+                                  : 0u;
+            if (MERGE == 2) {
+                // ... and the allele symbol before the k-mer is an ordinary one (else no k-mer starts there)
+                const uint32_t eb = (etile[pa1 >> 5] >> ((uint32_t)pa1 & 31u)) & 1u;
+                cont &= eb - 1u;
+            }
             head[q] = (df | cont) == 0u;
             if (merge) {
                 const uint32_t xl = ES ? __builtin_amdgcn_alignbit(sx[EW + 1], sx[EW], ES) : sx[EW];
@@ -540,6 +549,15 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
                 // (a run holds at most VREC_MAX_LEN = 32 dots, so 31 symbols after the k-mer decide: the set bit 62 ends the search)
                 const int ext = __builtin_ctzll(((unsigned long long)xh << 32) | xl) >> 1;
                 len[q] = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e[q]));
+                if (MERGE == 2) {
+                    // the k-mers e .. e+len-1 cover the symbols up to e+len-1+K-1: the first exception symbol at or after
+                    // e+K, d symbols on, allows d + 1 dots
+                    const uint32_t p = e[q] + (uint32_t)K;
+                    const uint32_t w0 = etile[p >> 5], w1 = etile[(p >> 5) + 1], w2 = etile[(p >> 5) + 2];
+                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, p & 31u);
+                    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, p & 31u) | 0x80000000u;
+                    len[q] = min(len[q], 1 + (int)__builtin_ctzll(((unsigned long long)hi << 32) | lo));
+                }
             }
         } else {
             const KT kf = extract_key<BPS, K>(rbuf, il);
@@ -576,14 +594,14 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     if (rcm[1] && slot < cap) out[slot] = record(who[1], 1, 1u);
 }
 
-template <int BPS, int K>
+template <int BPS, int K, bool AEXC>
 __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
-                                            const uint32_t* rbuf, const uint32_t* tile, int cb, int ts, int off2, int tn,
-                                            int nk1, bool merge, unsigned long long* cnt_r, uint32_t cap,
+                                            const uint32_t* rbuf, const uint32_t* tile, const uint32_t* etile, int cb, int ts,
+                                            int off2, int tn, int nk1, bool merge, unsigned long long* cnt_r, uint32_t cap,
                                             unsigned long long* out)
 {
-    if (BPS == 2 && merge) join_verify_t<BPS, K, true>(myq, from, n, entries, rbuf, tile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
-    else join_verify_t<BPS, K, false>(myq, from, n, entries, rbuf, tile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    if (BPS == 2 && merge) join_verify_t<BPS, K, AEXC ? 2 : 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    else join_verify_t<BPS, K, 0>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
 }
 
 // Table build, plain case (2-bit plane, no exception symbol in the allele): a thread hashes 16 CONSECUTIVE positions out
@@ -591,10 +609,18 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
 // instead of extracting and reverse-complementing a key from scratch per position (about 50 instructions per visit: the
 // build was vector-issue-bound like the probe, 12 us of a 150 us task).  `f(t4, hx[4], valid[4])` is called for every four
 // positions with their hashes, so that the LDS reads / returning atomics of four positions are in flight together.
-template <int BPS, int K, typename F>
-__device__ __forceinline__ void build_walk16(const uint32_t* tile, int p0, int tn, F&& f)
+template <int BPS, int K, bool AEXC, typename F>
+__device__ __forceinline__ void build_walk16(const uint32_t* tile, const uint32_t* etile, int p0, int tn, F&& f)
 {
     using KT = KeyT<BPS, K>;
+    // AEXC: a position whose k-mer covers an exception symbol is not valid - 56 exception bits from p0 on decide all sixteen
+    unsigned long long EX = 0ULL;
+    if (AEXC) {
+        const uint32_t wi = (uint32_t)p0 >> 5, sh = (uint32_t)p0 & 31u;
+        const uint32_t w0 = etile[wi], w1 = etile[wi + 1], w2 = etile[wi + 2];
+        EX = ((unsigned long long)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+    }
+    constexpr unsigned long long KM = (K >= 64) ? ~0ULL : ((1ULL << K) - 1ULL);
     constexpr int NWIN = ((15 + K) * BPS + 31) / 32;
     uint32_t W[NWIN + 1];
 #pragma unroll
@@ -624,13 +650,15 @@ __device__ __forceinline__ void build_walk16(const uint32_t* tile, int p0, int t
                 kr.w[KT::NW - 1] &= KT::TOPMASK;
             }
             hx[t4] = canon_hash<BPS, K>(kf, kr);
-            valid[t4] = p0 + t < tn;
+            valid[t4] = (p0 + t < tn) & (!AEXC || ((EX >> t) & KM) == 0ULL);
         }
         f(g * 4, hx, valid);
     }
 }
 
-template <typename C, int BPS, int K>
+// AEXC: the launch holds the pairs whose ALLELE has symbols outside upper-case ACGT (2-bit planes; the host groups them):
+// the table leaves out the k-mers that cover one, runs end before them.  The plain launch carries none of that code.
+template <typename C, int BPS, int K, bool AEXC>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
@@ -712,7 +740,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
         const int g1 = differs ? (int)__builtin_ctzll(differs) : task.n_reads;
         const SeqDesc s2 = seqs[seq2];
         const int nk2 = s2.len - K + 1;
-        const bool exc2 = (BPS == 2) && s2.n_exc > 0;
+        constexpr bool exc2 = (BPS == 2) && AEXC;
 
         for (int ts = 0; ts < nk2; ts += TA) {
             const int tn = min(TA, nk2 - ts);
@@ -730,10 +758,10 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
             }
             __syncthreads();
             // ---- build 1/3: bucket sizes (two 16-bit counters per LDS word) --------------------
-            const bool plain2 = (BPS == 2) && !exc2;
+            constexpr bool plain2 = (BPS == 2);      // (with or without exception symbols in the allele: see build_walk16)
             if (plain2) {
                 for (int p0 = tid * 16; p0 < tn; p0 += 16 * JOIN_THREADS)
-                    build_walk16<BPS, K>(tile, p0, tn, [&](int, const uint32_t (&hx)[4], const bool (&valid)[4]) {
+                    build_walk16<BPS, K, exc2>(tile, etile, p0, tn, [&](int, const uint32_t (&hx)[4], const bool (&valid)[4]) {
                         uint32_t fw[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) fw[u] = filt[hx[u] >> (32 - C::FILT_LOG2 + 5)];
@@ -790,7 +818,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
             // ---- build 3/3: fill every bucket from its end; the counter ends as the bucket start
             if (plain2) {
                 for (int p0 = tid * 16; p0 < tn; p0 += 16 * JOIN_THREADS)
-                    build_walk16<BPS, K>(tile, p0, tn, [&](int t0, const uint32_t (&hx)[4], const bool (&valid)[4]) {
+                    build_walk16<BPS, K, exc2>(tile, etile, p0, tn, [&](int t0, const uint32_t (&hx)[4], const bool (&valid)[4]) {
                         uint32_t old[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -861,7 +889,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     const uint32_t* re = e1 + (size_t)chunk1;
                     const bool exc1 = (BPS == 2) && (ri_chunk >> 31) != 0u;
                     unsigned long long* out = hits + pr.hit_off;
-                    const bool merge = (BPS == 2) && !exc1 && !exc2;
+                    const bool merge = (BPS == 2) && !exc1;
                     // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
                     {
                         const int nw = min(rbuf_words<BPS>(), (int)((((size_t)(nk1 + K - 1 - cb)) * BPS + 31) >> 5) + 2);
@@ -1001,7 +1029,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                     }
                                     qlen += __popcll(m);
                                     if (qlen >= 128) {
-                                        join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, tn,
+                                        join_verify<BPS, K, AEXC>(myq, qlen - 128, 128, entries, rbuf, tile, etile, cb, ts, pr.off2, tn,
                                                             nk1, merge, &cnt[r], pr.cap, out);
                                         qlen -= 128;
                                     }
@@ -1029,7 +1057,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             qlen += (int)tot;
                             if (qlen >= 128) {
                                 pc.mark(4, pw);            // queue fill
-                                join_verify<BPS, K>(myq, qlen - 128, 128, entries, rbuf, tile, cb, ts, pr.off2, tn, nk1,
+                                join_verify<BPS, K, AEXC>(myq, qlen - 128, 128, entries, rbuf, tile, etile, cb, ts, pr.off2, tn, nk1,
                                                     merge, &cnt[r], pr.cap, out);
                                 qlen -= 128;
                                 pc.mark(5, pw);            // verify + store
@@ -1039,7 +1067,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     }
                     // the strip changes: drain
                     if (qlen > 0)
-                        join_verify<BPS, K>(myq, 0, qlen, entries, rbuf, tile, cb, ts, pr.off2, tn, nk1, merge, &cnt[r], pr.cap, out);
+                        join_verify<BPS, K, AEXC>(myq, 0, qlen, entries, rbuf, tile, etile, cb, ts, pr.off2, tn, nk1, merge, &cnt[r], pr.cap, out);
                     pc.mark(5, pw);
                 }
             }
