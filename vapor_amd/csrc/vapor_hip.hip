@@ -1246,6 +1246,8 @@ static int async_fold(vapor_plan* p)
     hipStream_t st = nullptr;
     int rc = plan_lane(p, &st);
     if (rc != VAPOR_OK) return rc;
+    // (the plan's own streams as well when the caller has switched streams with steps in flight)
+    if (p->lane && p->lane != st) HIPCHK(hipStreamSynchronize(p->lane));
     HIPCHK(hipStreamSynchronize(st));
     if (p->fin && p->fin != st) HIPCHK(hipStreamSynchronize(p->fin));
     for (int i = 0; i < p->ring_n; ++i) {
