@@ -397,6 +397,42 @@ def test_runs_with_a_soft_masked_allele(eng, oracle):
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "soft-masked")
 
 
+def test_runs_on_the_four_bit_planes(eng, oracle):
+    """Both sides hold symbols outside upper-case ACGT (the self plot of a soft-masked window, a lower-case read against
+    a lower-case allele): the 4-bit planes, where lower case matches lower case and N matches N.  Runs are formed there
+    too (window sizes 10 and 20); the expanded dots are dotdata()'s, the statistics the oracle's."""
+    from vapor_amd import synth
+    rng = np.random.default_rng(58)
+    base = synth.random_dna(rng, 7000)
+    b = bytearray(base.encode())
+    for a, n in ((200, 900), (2500, 40), (4100, 1500), (6950, 50)):
+        b[a:a + n] = bytes(b[a:a + n]).lower()
+    for a in (1500, 1501, 3000, 5000):
+        b[a] = ord("N")
+    masked = b.decode()
+    shifted = masked[300:6500]                         # a read that carries the same lower-case stretches and Ns
+    other = synth.mutate(np.random.default_rng(4), base[100:6000], 0.003, 0.004, 0.004)[0]
+    other = other[:1000] + other[1000:2000].lower() + other[2000:]
+    seqs = [masked, shifted, other]
+    rows = [(0, 0, 0, 10, 0), (0, 0, 0, 20, 0), (1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (1, 0, 777, 20, 3), (0, 0, 0, 30, 0)]
+    ss = eng.seqset(seqs)
+    assert ss.n_exc[0] > 0 and ss.n_exc[1] > 0 and ss.n_exc[2] > 0
+    plan = eng.plan(ss, eng.make_pairs(rows))
+    st = plan.run().copy()
+    rec = plan.record_counts()
+    hits, _fl, off = plan.fetch_hits(range(len(rows)), want_flags=True)
+    for t, (s1, s2, off2, k, _f) in enumerate(rows):
+        exp = oracle.dotdata_array(k, seqs[s1], seqs[s2][off2:])
+        got = hits[off[t]:off[t + 1]]
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert st[t, 0] == len(exp) and got.tolist() == exp.tolist(), (t, rows[t])
+    assert st[0, 0] >= 6900 and rec[0] * 10 < st[0, 0]      # the self plot's diagonal in runs of up to 32
+    assert rec[1] * 10 < st[1, 0]
+    assert rec[5] == st[5, 0]                               # window size 30: single-dot records on these planes
+    plan.close()
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "x4 runs")
+
+
 def test_async_steps_on_a_stream_of_the_callers(eng):
     """vapor_set_stream: everything - the asynchronous steps and their finish kernel too - runs on the caller's stream,
     in order with what the caller enqueues there; back on the library's own streams afterwards."""

@@ -559,6 +559,55 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
                     len[q] = min(len[q], 1 + (int)__builtin_ctzll(((unsigned long long)hi << 32) | lo));
                 }
             }
+        } else if (merge) {
+            // 4-bit planes (both sides hold symbols outside upper-case ACGT, e.g. the self plot of a soft-masked window;
+            // no symbol of the allele is one that matches nothing - the caller's condition for `merge` here): the same
+            // stream from one symbol before the k-mer, a nibble per symbol, 128 bits of extension
+            constexpr int SB = 4 * (K + 1);
+            constexpr int EW = SB / 32, ES = SB % 32;
+            constexpr int NN = EW + 5;
+            const int pr1 = (int)il - 1, pa1 = (int)e[q] - 1;
+            const uint32_t shr = (uint32_t)(pr1 & 7) * 4u, sha = (uint32_t)(pa1 & 7) * 4u;
+            const uint32_t* rp = rbuf + (pr1 >> 3);
+            const uint32_t* tp = tile + (pa1 >> 3);
+            uint32_t sr[NN], sx[NN];
+#pragma unroll
+            for (int x = 0; x < NN; ++x) {
+                sr[x] = __builtin_amdgcn_alignbit(rp[x + 1], rp[x], shr);
+                sx[x] = sr[x] ^ __builtin_amdgcn_alignbit(tp[x + 1], tp[x], sha);
+            }
+            (void)in;
+            const uint32_t notin = ~(q ? out1 : out0) | (uint32_t)(((int)e[q] - (off2 - ts)) >> 31);
+            uint32_t df = notin;
+#pragma unroll
+            for (int x = 0; x <= EW; ++x) {
+                const uint32_t m = (x == EW ? ((1u << ES) - 1u) : 0xFFFFFFFFu) & (x == 0 ? ~15u : 0xFFFFFFFFu);
+                if (m) df |= sx[x] & m;
+            }
+            KT kf, a;
+#pragma unroll
+            for (int x = 0; x < KT::NW; ++x) {
+                kf.w[x] = __builtin_amdgcn_alignbit(sr[x + 1], sr[x], 4);
+                a.w[x] = __builtin_amdgcn_alignbit(sr[x + 1] ^ sx[x + 1], sr[x] ^ sx[x], 4);
+            }
+            kf.w[KT::NW - 1] &= KT::TOPMASK;
+            a.w[KT::NW - 1] &= KT::TOPMASK;
+            const KT kr = revcomp_key<BPS, K>(kf);
+            uint32_t dr = notin;
+#pragma unroll
+            for (int x = 0; x < KT::NW; ++x) dr |= a.w[x] ^ kr.w[x];
+            same[q] = df == 0u;
+            rcm[q] = dr == 0u;
+            const uint32_t cont = (il & (VREC_MAX_LEN - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
+                                  (uint32_t)((int)((sx[0] & 15u) - 1u) >> 31);
+            head[q] = (df | cont) == 0u;
+            uint32_t xw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xw[j] = ES ? __builtin_amdgcn_alignbit(sx[EW + j + 1], sx[EW + j], ES) : sx[EW + j];
+            xw[3] |= 0x10000000u;                        // (31 symbols after the k-mer decide: at most 32 dots per run)
+            const unsigned long long lo64 = ((unsigned long long)xw[1] << 32) | xw[0], hi64 = ((unsigned long long)xw[3] << 32) | xw[2];
+            const int ext = lo64 ? (__builtin_ctzll(lo64) >> 2) : 16 + (__builtin_ctzll(hi64) >> 2);
+            len[q] = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e[q]));
         } else {
             const KT kf = extract_key<BPS, K>(rbuf, il);
             const KT a = extract_key<BPS, K>(tile, e[q]);
@@ -594,6 +643,9 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     if (rcm[1] && slot < cap) out[slot] = record(who[1], 1, 1u);
 }
 
+// runs on the 4-bit planes up to this window size (beyond it a candidate's two streams need more registers than there are)
+constexpr int X4_MERGE_MAX_K = 20;
+
 template <int BPS, int K, bool AEXC>
 __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
                                             const uint32_t* rbuf, const uint32_t* tile, const uint32_t* etile, int cb, int ts,
@@ -601,6 +653,7 @@ __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, cons
                                             unsigned long long* out)
 {
     if (BPS == 2 && merge) join_verify_t<BPS, K, AEXC ? 2 : 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    else if (BPS == 4 && K <= X4_MERGE_MAX_K && merge) join_verify_t<BPS, (K <= X4_MERGE_MAX_K ? K : 10), 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
     else join_verify_t<BPS, K, 0>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
 }
 
@@ -889,7 +942,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     const uint32_t* re = e1 + (size_t)chunk1;
                     const bool exc1 = (BPS == 2) && (ri_chunk >> 31) != 0u;
                     unsigned long long* out = hits + pr.hit_off;
-                    const bool merge = (BPS == 2) && !exc1;
+                    const bool merge = (BPS == 2) ? !exc1 : (K <= X4_MERGE_MAX_K && s2.n_invalid == 0);
                     // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
                     {
                         const int nw = min(rbuf_words<BPS>(), (int)((((size_t)(nk1 + K - 1 - cb)) * BPS + 31) >> 5) + 2);
