@@ -1230,8 +1230,12 @@ static int plan_lane(vapor_plan* p, hipStream_t* out)
         if (!c->lane[l]) HIPCHK(hipStreamCreateWithFlags(&c->lane[l], hipStreamNonBlocking));
         if (!c->fin[l]) {
             int lo = 0, hi = 0;                  // (numerically lowest = highest priority)
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPCHK(hipStreamCreateWithPriority(&c->fin[l], hipStreamNonBlocking, hi));
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&c->fin[l], hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                c->fin[l] = nullptr;
+                HIPCHK(hipStreamCreateWithFlags(&c->fin[l], hipStreamNonBlocking));   // no priorities here: an ordinary stream
+            }
         }
         p->lane = c->lane[l];
         p->fin = c->fin[l];
