@@ -1,7 +1,7 @@
 import os, sys, tempfile, time, cProfile, pstats
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from vapor_amd import cli, pipeline, seqio, synth
-n = 600
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 w = synth.make_world(seed=11, n_loci=n, svtypes=("DEL", "DEL", "INV", "INS"), span_range=(100, 4000), read_len=9500, n_reads=20)
 for c in w.reads:
     w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
@@ -15,3 +15,10 @@ t0 = time.perf_counter(); run("b"); dt = time.perf_counter() - t0
 print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt))
 cProfile.run('run("c")', "/tmp/pf.prof")
 pstats.Stats("/tmp/pf.prof").sort_stats("tottime").print_stats(18)
+if len(sys.argv) > 2 and sys.argv[2] == "--sweep":
+    for thr in (2, 4, 8, 12, 16, 24):
+        os.environ["VAPOR_PREFETCH_THREADS"] = str(thr)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter(); run("s"); best = min(best, time.perf_counter() - t0)
+        print("prefetch threads %2d: %.3f s -> %.0f loci/s" % (thr, best, n / best), file=sys.stderr)

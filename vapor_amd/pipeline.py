@@ -315,7 +315,7 @@ def run_sync(gen, engine=None, figure_fn: Optional[Callable] = None):
 
 
 def _prefetch_threads(n_gens: int) -> int:
-    """Threads that start the loci of a batch (VAPOR_PREFETCH_THREADS; default up to 8, 1 = off)."""
+    """Threads that start the loci of a batch (VAPOR_PREFETCH_THREADS; default up to 12, 1 = off)."""
     import os
     from . import seqio
     if n_gens < 16 or not getattr(seqio.get_backend(), "threads_ok", False) or os.environ.get("VAPOR_BAM_NATIVE", "1") == "0":
@@ -323,12 +323,27 @@ def _prefetch_threads(n_gens: int) -> int:
     want = os.environ.get("VAPOR_PREFETCH_THREADS")
     if want is not None:
         return max(1, int(want))
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))       # ranks sharing this host's cores (torchrun)
+    return max(1, min(12, _usable_cores() // ranks_here))
+
+
+def _usable_cores() -> int:
+    """Cores this process may use: its affinity mask, cut to the container's CPU quota where there is one."""
+    import os
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))       # ranks sharing this host's cores (torchrun)
-    return max(1, min(8, cores // (2 * ranks_here)))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1") and int(period) > 0:
+                cores = max(1, min(cores, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
 
 
 def run_batch(gens: Sequence, engine=None, figure_fn: Optional[Callable] = None) -> List[object]:
@@ -355,20 +370,37 @@ def run_batch(gens: Sequence, engine=None, figure_fn: Optional[Callable] = None)
             results[t] = e
             pending.pop(t, None)
 
-    # The first stretch of a locus generator is its read extraction (window from the FASTA, reads of the region from the
-    # BAM: BGZF inflation in the library's host helper, which releases the GIL).  With a backend whose handles are per
-    # thread the loci of a batch start on a few threads, so that one locus inflates while another's Python runs.
+    # A stretch of a locus generator holds its read extraction (window from the FASTA, reads of the region from the BAM:
+    # BGZF inflation in the library's host helper, which releases the GIL) - the first stretch for the deletion and
+    # insertion drivers, the one after the window refinements for the others (reads are fetched only when the windows
+    # pass, CLI:334-367 via SF:1512-1530).  With a backend whose handles are per thread the generators of a batch advance on
+    # a few threads, so that one locus inflates while another's Python runs.
     n_thr = _prefetch_threads(len(gens))
+    pool = None
     if n_thr > 1:
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=n_thr) as pool:
-            list(pool.map(lambda t: advance(t, first=True), range(len(gens))))
-    else:
-        for t in range(len(gens)):
-            advance(t, first=True)
-    while pending:
-        idx = sorted(pending)
-        ans = _answer(engine, [pending[t] for t in idx], figure_fn)
-        for t, a in zip(idx, ans):
-            advance(t, value=a)
+        pool = ThreadPoolExecutor(max_workers=n_thr)
+
+    def spread(work):
+        """`work`: argument tuples of advance(); in slices over the pool (a future per item costs as much as a short stretch)."""
+        if pool is None or len(work) < 16:
+            for a in work:
+                advance(*a)
+            return
+        step = max(1, len(work) // (n_thr * 8))
+
+        def some(k):
+            for a in work[k:k + step]:
+                advance(*a)
+        list(pool.map(some, range(0, len(work), step)))
+
+    try:
+        spread([(t, True) for t in range(len(gens))])
+        while pending:
+            idx = sorted(pending)
+            ans = _answer(engine, [pending[t] for t in idx], figure_fn)
+            spread([(t, False, a) for t, a in zip(idx, ans)])
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     return results
