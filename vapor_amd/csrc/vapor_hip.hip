@@ -19,6 +19,7 @@
 #include <string>
 #include <thread>
 #include <array>
+#include <atomic>
 #include <vector>
 
 using namespace vapor;
@@ -381,24 +382,6 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
                 for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
             }
         };
-        const int n_thr = (n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? 4 : 1;
-        if (n_thr == 1) {
-            stage_range(0, n_seqs);
-        } else {
-            // cut at equal shares of the bytes
-            std::vector<int32_t> cut(1, 0);
-            for (int t = 1; t < n_thr; ++t) {
-                const uint32_t want = (uint32_t)(n_asc * (size_t)t / (size_t)n_thr);
-                int32_t i = cut.back();
-                while (i < n_seqs && s->h[i].asc0 < want) ++i;
-                cut.push_back(i);
-            }
-            cut.push_back(n_seqs);
-            std::vector<std::thread> th;
-            for (int t = 1; t < n_thr; ++t) th.emplace_back(stage_range, cut[(size_t)t], cut[(size_t)t + 1]);
-            stage_range(cut[0], cut[1]);
-            for (auto& x : th) x.join();
-        }
         SS_CHK(dmalloc(ctx, (void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
         SS_CHK(dmalloc(ctx, (void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
         SS_CHK(dmalloc(ctx, (void**)&s->d_e1, pl * sizeof(uint32_t)));
@@ -407,8 +390,45 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         SS_CHK(hipMemsetAsync(s->d_e1, 0, pl * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemcpyAsync(s->d_seqs, s->h.data(), sizeof(SeqDesc) * s->h.size(), hipMemcpyHostToDevice, ctx->stream));
+        const int n_thr = (n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? 4 : 1;
+        if (n_thr == 1) {
+            stage_range(0, n_seqs);
+            if (n_asc) SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 36, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            // slices of equal shares of the bytes, staged by the threads in order; this thread sends a slice to the device
+            // as soon as it is staged, so that the link works while the cores still copy
+            constexpr int SLICES = 12;
+            std::vector<int32_t> cut(1, 0);
+            for (int t = 1; t < SLICES; ++t) {
+                const uint32_t want = (uint32_t)(n_asc * (size_t)t / (size_t)SLICES);
+                int32_t i = cut.back();
+                while (i < n_seqs && s->h[i].asc0 < want) ++i;
+                cut.push_back(i);
+            }
+            cut.push_back(n_seqs);
+            std::atomic<int> staged[SLICES];
+            for (auto& f : staged) f.store(0, std::memory_order_relaxed);
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; ++t)
+                th.emplace_back([&, t] {
+                    for (int k = t; k < SLICES; k += n_thr) {
+                        stage_range(cut[(size_t)k], cut[(size_t)k + 1]);
+                        staged[k].store(1, std::memory_order_release);
+                    }
+                });
+            hipError_t err = hipSuccess;
+            for (int k = 0; k < SLICES; ++k) {
+                while (!staged[k].load(std::memory_order_acquire)) std::this_thread::yield();
+                const size_t c0 = cut[(size_t)k] < n_seqs ? s->h[(size_t)cut[(size_t)k]].asc0 : n_asc;
+                const size_t c1 = cut[(size_t)k + 1] < n_seqs ? s->h[(size_t)cut[(size_t)k + 1]].asc0 : n_asc;
+                if (c1 > c0 && err == hipSuccess)
+                    err = hipMemcpyAsync(d_asc + c0 * 32, h_asc + c0 * 32, (c1 - c0) * 32, hipMemcpyHostToDevice, ctx->stream);
+            }
+            for (auto& x : th) x.join();
+            SS_CHK(err);
+            SS_CHK(hipMemcpyAsync(d_map, h_map, n_asc * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
         if (n_asc) {
-            SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 36, hipMemcpyHostToDevice, ctx->stream));
             unsigned grid = (unsigned)((n_asc + 255) / 256);
             hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_asc, s->d_seqs, n_seqs, d_map,
                                (uint32_t)n_asc, s->d_p2, s->d_e1, s->d_x4);
