@@ -234,6 +234,13 @@ const char* vapor_bam_last_error(void);
 int vapor_bam_chop(vapor_bam* bam, int32_t tid, int64_t start, int64_t end, int64_t flank, int32_t n_chunks,
                    const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
                    int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need);
+/*
+ * The block decoder of vapor_bam_chop by itself (host, no device): a raw DEFLATE stream (RFC 1951; the payload of a BGZF
+ * block) of in_n bytes into exactly out_n bytes.  VAPOR_E_ARG for anything that is not such a stream (truncated, damaged,
+ * another size); it reads and writes nothing outside the two buffers.  Replaces the inflate inside `samtools view`
+ * (SF:342 runs it as a process per locus).
+ */
+int vapor_inflate_raw(const uint8_t* in, int64_t in_n, uint8_t* out, int64_t out_n);
 
 #ifdef __cplusplus
 }

@@ -291,3 +291,83 @@ def test_native_chop_from_several_threads(tmp_path):
         threaded = list(pool.map(lambda q: b.chop_native("c", *q), qs))
     b.close()
     assert threaded == serial and sum(len(x) for x in serial) > 100
+
+
+def _native_inflate(comp: bytes, size: int):
+    """vapor_inflate_raw through the C ABI: the bytes, or None when the library refuses the stream."""
+    import ctypes
+    from vapor_amd import _lib
+    lib = _lib.load()
+    src = np.frombuffer(comp, dtype=np.uint8) if comp else np.zeros(1, dtype=np.uint8)
+    out = np.full(size + 16, 0xEE, dtype=np.uint8)
+    rc = lib.vapor_inflate_raw(src.ctypes.data, len(comp), out.ctypes.data, size)
+    assert bytes(out[size:]) == b"\xEE" * 16, "wrote behind the output"
+    return bytes(out[:size]) if rc == 0 else None
+
+
+def _zlib_inflate(comp: bytes, size: int):
+    d = zlib.decompressobj(-15)
+    try:
+        out = d.decompress(comp, size + 1)
+    except zlib.error:
+        return None
+    return out if d.eof and len(out) == size else None
+
+
+def _deflate(data: bytes, level: int, strategy: int) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def test_block_decoder_against_zlib():
+    """The library's own DEFLATE decoder (vapor_inflate.h, what vapor_bam_chop inflates BGZF blocks with) against zlib:
+    stored, fixed and dynamic blocks of random bytes, bases, packed-read-like and run-heavy data at every size class up
+    to several blocks; a wrong size is refused."""
+    rng = np.random.default_rng(5)
+    kinds = {
+        "bytes": lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes(),
+        "bases": lambda n: rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes(),
+        "quals": lambda n: np.where(rng.random(n) < 0.9, 73, rng.integers(33, 74, n)).astype(np.uint8).tobytes(),
+        "zeros": lambda n: bytes(n),
+        "repeats": lambda n: (rng.integers(0, 256, 97, dtype=np.uint8).tobytes() * (n // 97 + 1))[:n],
+        "period3": lambda n: (b"xyz" * (n // 3 + 1))[:n],
+    }
+    n_cases = 0
+    for name, make in kinds.items():
+        for size in (0, 1, 2, 9, 257, 258, 259, 4000, 65280, 200001):
+            data = make(size)
+            for level in (0, 1, 6, 9):
+                for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                    comp = _deflate(data, level, strategy)
+                    assert _native_inflate(comp, size) == data, (name, size, level, strategy)
+                    if size:
+                        assert _native_inflate(comp, size - 1) is None
+                        assert _native_inflate(comp, size + 1) is None
+                    n_cases += 1
+    assert n_cases == 6 * 10 * 4 * 4
+
+
+def test_block_decoder_refuses_what_zlib_refuses():
+    """Truncated streams and streams with a flipped bit: the decoder accepts exactly those zlib accepts, with the same
+    bytes, and never touches memory outside its buffers (guard bytes behind the output; the sanitizer build of
+    tools/inflate_check.cpp runs the same under ASan)."""
+    rng = np.random.default_rng(6)
+    refused = accepted = 0
+    for size in (50, 3000, 70000):
+        for maker in (lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes(),
+                      lambda n: rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), n).tobytes(),
+                      lambda n: (rng.integers(0, 256, 61, dtype=np.uint8).tobytes() * (n // 61 + 1))[:n]):
+            data = maker(size)
+            for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)):
+                comp = _deflate(data, level, strategy)
+                for t in range(40):
+                    bad = bytearray(comp)
+                    if t % 4 == 0:
+                        bad = bad[:int(rng.integers(0, len(bad)))]
+                    else:
+                        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+                    ours, theirs = _native_inflate(bytes(bad), size), _zlib_inflate(bytes(bad), size)
+                    assert ours == theirs, (size, level, strategy, t)
+                    refused += ours is None
+                    accepted += ours is not None
+    assert refused > 500

@@ -93,3 +93,4 @@ print("%d loci in %.3f s -> %.1f loci/s (best of 3, one process, in-memory world
 if "--profile" in args:
     cProfile.run("run()", "/tmp/pipe.prof")
     pstats.Stats("/tmp/pipe.prof").sort_stats("tottime").print_stats(24)
+    pstats.Stats("/tmp/pipe.prof").sort_stats("cumulative").print_stats(45)

@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libvapor_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "vapor_hip.hip"), os.path.join(HERE, "csrc", "vapor_bam.cpp")]
-DEPS = SOURCES + [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(ROOT, "include", "vapor_hip.h")]
+DEPS = SOURCES + [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(HERE, "csrc", "vapor_inflate.h"),
+                  os.path.join(ROOT, "include", "vapor_hip.h")]
 
 
 # The kernels issue their wave-level atomics from one lane already (`if (lane == 0) atomicAdd(...)`); LLVM's atomic

@@ -3,11 +3,12 @@
 //
 // The reference starts a samtools process per locus and parses its text; vapor_amd/bamio.py does the same work
 // in-process in Python (and stays the statement this file is tested against, tests/test_bamio.py); this is the native
-// form of its hot loop: the region's BGZF blocks are read with one pread, inflated by a few host threads (zlib),
+// form of its hot loop: the region's BGZF blocks are read with one pread, inflated by a few host threads (vapor_inflate.h),
 // the records of the wanted reference are walked in file order, each CIGAR is walked in its binary form up to the window
 // start (cigar2alignstart_by_pos, SF:309-337; the CG:B,I long-CIGAR convention included) and only the bases that are
 // kept are decoded.  The .bai lookup (bins, linear index) stays in Python: it is a few dictionary reads per locus.
 #include "vapor_hip.h"
+#include "vapor_inflate.h"
 
 #include <fcntl.h>
 #include <unistd.h>
@@ -32,6 +33,7 @@ struct vapor_bam {
     std::vector<int32_t> blk_csize;     // whole block size (header .. trailer)
     std::vector<int64_t> blk_ustart;    // where its inflated bytes start in `data`
     std::vector<int32_t> blk_usize;
+    std::vector<vapor_inflate::Decoder> dec;   // decoder tables, one per inflate thread
 };
 
 static thread_local std::string g_bam_err;
@@ -100,10 +102,13 @@ static int scan_blocks(vapor_bam* b)
     return n;
 }
 
-static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize)
+static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize, vapor_inflate::Decoder& dec)
 {
     if (isize == 0) return true;
     const int xlen = blk[10] | (blk[11] << 8);
+    if (bsize - xlen - 20 < 0) return false;
+    if (vapor_inflate::inflate_raw(blk + 12 + xlen, (size_t)(bsize - xlen - 20), out, (size_t)isize, dec)) return true;
+    // refused: zlib has the last word on whether the block is damaged
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -116,15 +121,27 @@ static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize
     return rc == Z_STREAM_END && zs.avail_out == 0;
 }
 
+extern "C" int vapor_inflate_raw(const uint8_t* in, int64_t in_n, uint8_t* out, int64_t out_n)
+{
+    if (in_n < 0 || out_n < 0 || (in_n && !in) || (out_n && !out)) return bfail(VAPOR_E_ARG, "vapor_inflate_raw: bad argument");
+    static thread_local vapor_inflate::Decoder* dec = nullptr;
+    if (!dec) dec = new vapor_inflate::Decoder();
+    uint8_t none = 0;
+    if (!vapor_inflate::inflate_raw(in ? in : &none, (size_t)in_n, out ? out : &none, (size_t)out_n, *dec))
+        return bfail(VAPOR_E_ARG, "vapor_inflate_raw: not a DEFLATE stream of that size");
+    return VAPOR_OK;
+}
+
 // inflates blocks [b0, b1) into data (their ustart already laid out), a few threads when there are several
 static bool inflate_range(vapor_bam* b, size_t b0, size_t b1)
 {
     const size_t n = b1 - b0;
     const int nt = (int)std::min<size_t>((size_t)b->n_threads, n);
+    if (b->dec.size() < (size_t)std::max(nt, 1)) b->dec.resize((size_t)std::max(nt, 1));
     std::vector<char> ok((size_t)std::max(nt, 1), 1);
     auto work = [&](int t) {
         for (size_t i = b0 + (size_t)t; i < b1; i += (size_t)nt)
-            if (!inflate_block(b->comp.data() + b->blk_cpos[i], b->blk_csize[i], b->data.data() + b->blk_ustart[i], b->blk_usize[i])) ok[(size_t)t] = 0;
+            if (!inflate_block(b->comp.data() + b->blk_cpos[i], b->blk_csize[i], b->data.data() + b->blk_ustart[i], b->blk_usize[i], b->dec[(size_t)t])) ok[(size_t)t] = 0;
     };
     if (nt <= 1) {
         work(0);
