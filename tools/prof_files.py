@@ -16,9 +16,10 @@ print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt)
 cProfile.run('run("c")', "/tmp/pf.prof")
 pstats.Stats("/tmp/pf.prof").sort_stats("tottime").print_stats(18)
 if len(sys.argv) > 2 and sys.argv[2] == "--sweep":
-    for thr in (2, 4, 8, 12, 16, 24):
+    for thr, inf in ((8, 1), (8, 2), (12, 1), (12, 2), (16, 1), (12, 4)):
         os.environ["VAPOR_PREFETCH_THREADS"] = str(thr)
+        os.environ["VAPOR_BAM_INFLATE_THREADS"] = str(inf)
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter(); run("s"); best = min(best, time.perf_counter() - t0)
-        print("prefetch threads %2d: %.3f s -> %.0f loci/s" % (thr, best, n / best), file=sys.stderr)
+        print("prefetch threads %2d x %d inflate: %.3f s -> %.0f loci/s" % (thr, inf, best, n / best), file=sys.stderr)

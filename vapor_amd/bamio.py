@@ -265,7 +265,8 @@ class BamFile:
             if lib.vapor_bam_open(self.path.encode(), ctypes.byref(h)) != 0:
                 raise OSError(lib.vapor_bam_last_error().decode())
             if threading.current_thread() is not threading.main_thread():
-                lib.vapor_bam_set_threads(h, 2)       # several readers at once: fewer inflate threads each
+                import os
+                lib.vapor_bam_set_threads(h, int(os.environ.get("VAPOR_BAM_INFLATE_THREADS", "2")))   # several readers at once: fewer inflate threads each
             tl.native = h
             tl.buf = {"seq": np.empty(1 << 20, dtype=np.uint8), "names": ctypes.create_string_buffer(1 << 16),
                       "meta": np.empty(4 * 256, dtype=np.int64), "need": np.zeros(3, dtype=np.int64)}

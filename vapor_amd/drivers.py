@@ -54,19 +54,22 @@ class Figure:
 
 def _collect(results, reads, scores: List[float], keep=None):
     """The per-read loop every driver repeats (e.g. SF:1909-1915): a read counts when neither scorer output is 0
-    (the executor hands such a read over as None, the others as 1 - b/a; the scorers never produce NaN, so
+    (`keep`: a flag per read, for the reads that were handed to the executor at all; the executor
+    hands such a read over as None, the others as 1 - b/a; the scorers never produce NaN, so
     vapor_dup_inv_VapoR's extra isnan test, SF:1629, changes nothing); returns the read with the best score so
     far (ties: the later read)."""
     best = ""
     it = iter(results)
-    for x in reads:
-        if keep is not None and not keep(x):
+    top = max(scores) if scores else None
+    for t, x in enumerate(reads):
+        if keep is not None and not keep[t]:
             continue
         s = next(it)
         if s is None:
             continue
         scores.append(s)
-        if scores[-1] == max(scores):
+        if top is None or s >= top:          # (`scores[-1] == max(scores)` of the reference, without the scan)
+            top = s
             best = x
     return best
 
@@ -204,9 +207,10 @@ def vapor_simple_ins(num_reads_cff, plt_li, bam_in, ref, ins_pos, ins_seq, out_f
             def few_n(x):                                   # SF:1878
                 return float(x[0].count("N") + x[0].count("n")) / float(len(x[0])) < 0.1
 
-            used = [x for x in reads if few_n(x)]
+            kept = [few_n(x) for x in reads]
+            used = [x for x, f in zip(reads, kept) if f]
             res = (yield Score("s1", ref_seq, alt_seq, used, k)) if used else []
-            best = _collect(res, reads, scores, keep=few_n)
+            best = _collect(res, reads, scores, keep=kept)
             if ins_seq_2.count("X") == len(ins_seq_2):
                 yield Figure(scores, best, k, ref_seq, ref_seq[2:flank], out_figure_name)
             else:

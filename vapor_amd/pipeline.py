@@ -160,10 +160,11 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
     reads in order.  The arrays are put together with numpy per request, not per read."""
     seqs: List[str] = []
     upper: List[bool] = []
-    seq1, seq2, off2, kk, flg = [], [], [], [], []           # pair columns, one array per request block
-    ra, aa, rb, ab, kind, locus, lref, lalt = [], [], [], [], [], [], [], []
-    first_read, n_pairs = [], 0
-    read_seq_first = []                                      # per request: index of its first read sequence
+    # per request: scalars only; the per-read and per-pair columns are expanded from them in one go below
+    rq_n, rq_k, rq_kind, rq_lref, rq_lalt, rq_blk_a, rq_blk_b = [], [], [], [], [], [], []
+    bl_rq, bl_allele, bl_flags = [], [], []                  # blocks of pairs: (request, first allele sequence, pair flags)
+    miss: List[int] = []
+    first_read, read_seq_first = [], []
     n_reads_tot = 0
     for t, r in enumerate(reqs):
         n = len(r.reads)
@@ -181,47 +182,58 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
             upper += [True, True]
         else:
             ui = ri
-        q0 = len(seqs)
-        read_seq_first.append(q0)
+        read_seq_first.append(len(seqs))
         seqs += [x[0] for x in r.reads]
         upper += [False] * n
-        q = np.arange(q0, q0 + n, dtype=np.int32)
-        miss = np.fromiter((int(x[1]) for x in r.reads), dtype=np.int32, count=n)
-
-        def block(allele0, fl):
-            nonlocal n_pairs
-            base = n_pairs
-            seq1.append(np.repeat(q, 2))
-            seq2.append(np.tile(np.array([allele0, allele0 + 1], dtype=np.int32), n))
-            off2.append(np.repeat(miss, 2))
-            kk.append(np.full(2 * n, int(r.k), dtype=np.int32))
-            flg.append(np.full(2 * n, fl, dtype=np.uint32))
-            n_pairs += 2 * n
-            return base + 2 * np.arange(n, dtype=np.int32)
-
-        if r.kind == "del":
-            if ui == ri:
-                pa = pb = block(ri, L.PF_C1 | L.PF_C2)       # upper-casing changes nothing: one fill serves both scorers
-            else:
-                pa = block(ui, L.PF_C1)
-                pb = block(ri, L.PF_C2)
+        miss += [int(x[1]) for x in r.reads]
+        k = len(rq_n)
+        if r.kind == "del" and ui != ri:
+            blk_a = len(bl_rq)
+            bl_rq += [k, k]; bl_allele += [ui, ri]; bl_flags += [L.PF_C1, L.PF_C2]
+            blk_b = blk_a + 1
         else:
-            pa = pb = block(ui if r.kind == "s1" else ri, _FLAGS[r.kind])
-        ra.append(pa); aa.append(pa + 1); rb.append(pb); ab.append(pb + 1)
-        kind.append(np.full(n, _KIND[r.kind], dtype=np.int32))
-        locus.append(np.full(n, t, dtype=np.int32))
-        lref.append(np.full(n, len(r.ref_seq), dtype=np.int32))
-        lalt.append(np.full(n, len(r.alt_seq), dtype=np.int32))
+            # (a deletion whose alleles are upper case already: one fill serves both scorers)
+            blk_a = blk_b = len(bl_rq)
+            bl_rq.append(k)
+            bl_allele.append(ri if r.kind in ("del", "s2", "s3") else ui)
+            bl_flags.append(L.PF_C1 | L.PF_C2 if r.kind == "del" else _FLAGS[r.kind])
+        rq_n.append(n); rq_k.append(int(r.k)); rq_kind.append(_KIND[r.kind]); rq_lref.append(len(r.ref_seq)); rq_lalt.append(len(r.alt_seq))
+        rq_blk_a.append(blk_a); rq_blk_b.append(blk_b)
         n_reads_tot += n
     if n_reads_tot == 0:
         return [[] for _ in reqs]
-    pairs = np.zeros(n_pairs, dtype=L.PAIR_DTYPE)
-    for name, col in (("seq1", seq1), ("seq2", seq2), ("off2", off2), ("k", kk), ("flags", flg)):
-        pairs[name] = np.concatenate(col)
+    i32 = np.int32
+    nz = [t for t, r in enumerate(reqs) if len(r.reads)]     # requests with reads, in order (rq_* are indexed by position here)
+    rq_n_a = np.asarray(rq_n, dtype=np.int64)
+    rq_first = np.concatenate(([0], np.cumsum(rq_n_a)[:-1]))             # first read of a request in the read table
+    rq_q0 = np.asarray([read_seq_first[t] for t in nz], dtype=np.int64)  # its first read sequence
+    miss_a = np.asarray(miss, dtype=i32)
+    # blocks -> pairs: block b holds, per read i of its request, the pairs (read, allele) and (read, allele + 1)
+    bl_rq_a = np.asarray(bl_rq, dtype=np.int64)
+    bl_n = rq_n_a[bl_rq_a]
+    bl_base = 2 * np.concatenate(([0], np.cumsum(bl_n)[:-1]))            # first pair of a block
+    br_blk = np.repeat(np.arange(len(bl_rq_a)), bl_n)                     # per (block, read): its block
+    br_i = np.arange(int(bl_n.sum())) - np.repeat(bl_base // 2, bl_n)     # ... and the read's index in the request
+    br_rq = bl_rq_a[br_blk]
+    pairs = np.zeros(2 * len(br_blk), dtype=L.PAIR_DTYPE)
+    pairs["seq1"] = np.repeat((rq_q0[br_rq] + br_i).astype(i32), 2)
+    al = np.repeat(np.asarray(bl_allele, dtype=i32)[br_blk], 2)
+    al[1::2] += 1
+    pairs["seq2"] = al
+    pairs["off2"] = np.repeat(miss_a[rq_first[br_rq] + br_i], 2)
+    pairs["k"] = np.repeat(np.asarray(rq_k, dtype=i32)[br_rq], 2)
+    pairs["flags"] = np.repeat(np.asarray(bl_flags, dtype=np.uint32)[br_blk], 2)
+    # read table: read i of request r takes its statistics from pairs base(block) + 2 i (+ 1 for the other allele)
+    rd_rq = np.repeat(np.arange(len(rq_n_a)), rq_n_a)
+    rd_i = np.arange(n_reads_tot) - rq_first[rd_rq]
+    pa = (bl_base[np.asarray(rq_blk_a, dtype=np.int64)][rd_rq] + 2 * rd_i).astype(i32)
+    pb = (bl_base[np.asarray(rq_blk_b, dtype=np.int64)][rd_rq] + 2 * rd_i).astype(i32)
     table = np.zeros(n_reads_tot, dtype=L.READ_DTYPE)
-    for name, col in (("ref_a", ra), ("alt_a", aa), ("ref_b", rb), ("alt_b", ab), ("kind", kind), ("locus", locus),
-                      ("len_ref", lref), ("len_alt", lalt)):
-        table[name] = np.concatenate(col)
+    table["ref_a"], table["alt_a"], table["ref_b"], table["alt_b"] = pa, pa + 1, pb, pb + 1
+    table["kind"] = np.asarray(rq_kind, dtype=i32)[rd_rq]
+    table["locus"] = np.asarray(nz, dtype=i32)[rd_rq]
+    table["len_ref"] = np.asarray(rq_lref, dtype=i32)[rd_rq]
+    table["len_alt"] = np.asarray(rq_lalt, dtype=i32)[rd_rq]
     ss = engine.seqset(seqs, upper)
     try:
         plan = engine.plan(ss, pairs)
@@ -237,22 +249,29 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
         lens = np.asarray(ss.lens)
     finally:
         ss.close()
+    # per request with reads: longest read, any read the library could not have hashed (one pass over all reads)
+    rd_q = rq_q0[rd_rq] + rd_i
+    rd_len = lens[rd_q]
+    max_read = np.maximum.reduceat(rd_len, rq_first)
+    rd_inv = bad_inv[rd_q] & (rd_len - np.asarray(rq_k, dtype=np.int64)[rd_rq] + 1 > 0)
+    any_inv = np.logical_or.reduceat(rd_inv, rq_first)
+    vals = sc.tolist()
+    if sc.size and bool(np.isnan(sc).any()):
+        vals = [None if x != x else x for x in vals]
     out: List[object] = []
+    j = 0
     for t, r in enumerate(reqs):
         n = len(r.reads)
         if n == 0:
             out.append([])
             continue
-        q0 = read_seq_first[t]
-        if k_unsupported(r.k) or max(len(r.ref_seq), len(r.alt_seq)) > L.MAX_SEQ_LEN or int(lens[q0:q0 + n].max()) > L.MAX_SEQ_LEN:
+        if k_unsupported(r.k) or max(len(r.ref_seq), len(r.alt_seq)) > L.MAX_SEQ_LEN or int(max_read[j]) > L.MAX_SEQ_LEN:
             out.append(ValueError("sequence longer than %d bases or unsupported window size" % L.MAX_SEQ_LEN))
-            continue
-        inv = bad_inv[q0:q0 + n] & (lens[q0:q0 + n] - int(r.k) + 1 > 0)
-        if inv.any():
+        elif any_inv[j]:
             out.append(KeyError("invert_base"))              # what SF:1421 raises on a base outside ATCGN/atcgn
-            continue
-        v = sc[first_read[t]:first_read[t] + n]
-        out.append([None if x != x else x for x in v.tolist()])
+        else:
+            out.append(vals[first_read[t]:first_read[t] + n])
+        j += 1
     return out
 
 
@@ -315,7 +334,7 @@ def run_sync(gen, engine=None, figure_fn: Optional[Callable] = None):
 
 
 def _prefetch_threads(n_gens: int) -> int:
-    """Threads that start the loci of a batch (VAPOR_PREFETCH_THREADS; default up to 12, 1 = off)."""
+    """Threads that start the loci of a batch (VAPOR_PREFETCH_THREADS; default up to 8, 1 = off)."""
     import os
     from . import seqio
     if n_gens < 16 or not getattr(seqio.get_backend(), "threads_ok", False) or os.environ.get("VAPOR_BAM_NATIVE", "1") == "0":
@@ -324,7 +343,7 @@ def _prefetch_threads(n_gens: int) -> int:
     if want is not None:
         return max(1, int(want))
     ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))       # ranks sharing this host's cores (torchrun)
-    return max(1, min(12, _usable_cores() // ranks_here))
+    return max(1, min(8, _usable_cores() // ranks_here))
 
 
 def _usable_cores() -> int:
