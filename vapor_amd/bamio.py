@@ -293,11 +293,16 @@ class BamFile:
             tl.buf = {"seq": np.empty(int(need[0]) * 2 + 1024, dtype=np.uint8),
                          "names": ctypes.create_string_buffer(int(need[1]) * 2 + 256),
                          "meta": np.empty(4 * (int(need[2]) * 2 + 16), dtype=np.int64), "need": need}
-        seq, meta, names = bf["seq"], bf["meta"], bf["names"].raw
+        if n.value == 0:
+            return []
+        # (one conversion of the numbers, one of the bases: this runs under the interpreter lock on every pool thread)
+        m = bf["meta"][:4 * n.value].tolist()
+        whole = bf["seq"][:max(m[4 * r] + m[4 * r + 1] for r in range(n.value))].tobytes().decode("ascii")
+        names = bf["names"].raw
         out = []
         for r in range(n.value):
-            o, ln, miss, no = (int(v) for v in meta[4 * r:4 * r + 4])
-            out.append([seq[o:o + ln].tobytes().decode("ascii"), miss, names[no:names.index(b"\0", no)].decode()])
+            o, ln, miss, no = m[4 * r:4 * r + 4]
+            out.append([whole[o:o + ln], miss, names[no:names.index(b"\0", no)].decode()])
         return out
 
     def close(self) -> None:
