@@ -518,3 +518,32 @@ def test_figure_specs_match_what_the_reference_plots(fake):
 def test_figure_requests_of_the_drivers(fake):
     import figure_cases
     figure_cases.check_driver_requests()
+
+
+def test_pool_size_follows_the_cpu_quota_and_the_ranks_on_the_host(monkeypatch):
+    """pipeline._prefetch_threads: VAPOR_PREFETCH_THREADS wins; otherwise the usable cores (affinity cut to the container's
+    CPU quota) divided by the ranks torchrun started on this host, at most eight; one thread for small batches and for
+    backends that are not thread-safe."""
+    from vapor_amd import pipeline
+
+    class Be:
+        threads_ok = True
+    seqio.set_backend(Be())
+    try:
+        monkeypatch.delenv("VAPOR_PREFETCH_THREADS", raising=False)
+        monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+        monkeypatch.setattr(pipeline, "_usable_cores", lambda: 16)
+        assert pipeline._prefetch_threads(1000) == 8
+        assert pipeline._prefetch_threads(10) == 1
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "5")
+        assert pipeline._prefetch_threads(1000) == 3
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
+        assert pipeline._prefetch_threads(1000) == 1
+        monkeypatch.setenv("VAPOR_PREFETCH_THREADS", "6")
+        assert pipeline._prefetch_threads(1000) == 6
+        Be.threads_ok = False
+        assert pipeline._prefetch_threads(1000) == 1
+    finally:
+        seqio.set_backend(None)
+    monkeypatch.undo()
+    assert 1 <= pipeline._usable_cores() <= (os.cpu_count() or 1)
