@@ -761,7 +761,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     const DTask task = tasks[blockIdx.x];          // first = index into task_pairs, n_reads = pairs in the range
     const uint32_t* plane = (BPS == 2) ? p2 : x4;
     constexpr int WPC = (BPS == 2) ? VP_P2_WORDS_PER_CHUNK : VP_X4_WORDS_PER_CHUNK;
-    uint32_t* myq = queue + wave * (JQCAP + 4);    // JQCAP slots + a dump slot for lanes that have nothing to store
+    uint32_t* myq = queue + wave * (JQCAP + 4);    // JQCAP slots + dump slots for lanes that have nothing to store (and the surplus of the last lanes)
     uint32_t* rbuf = rbufs + wave * rbuf_words<BPS>();
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
     const uint32_t qbase = (uint32_t)(uintptr_t)(lds_u32_t*)myq;            // LDS byte address of the wave's queue
@@ -1101,9 +1101,20 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                 const uint32_t pos = (uint32_t)qlen + incl[x] - c;
                                 const uint32_t item = (il << 16) | s0;
                                 const uint32_t full = qbase + pos * 4u;
+#ifdef VAPOR_AB_OLDFILL
                                 ((lds_u32_t*)(uintptr_t)(c > 0u ? full : qbase + (uint32_t)JQCAP * 4u))[0] = item;
                                 ((lds_u32_t*)(uintptr_t)(c > 1u ? full : qbase + (uint32_t)(JQCAP - 1) * 4u))[1] = item + 1u;
                                 ((lds_u32_t*)(uintptr_t)(c > 2u ? full : qbase + (uint32_t)(JQCAP - 2) * 4u))[2] = item + 2u;
+#else
+                                // One select for the three stores: a lane without a candidate writes the three dump slots, a lane
+                                // with one or two writes its surplus onto the slots of the lanes after it - whose own stores of a
+                                // LOWER index come later in program order (the wave's LDS instructions execute in order), so the
+                                // stores go out from index 2 down to 0 and every slot ends with its owner's value.
+                                volatile lds_u32_t* const qp = (volatile lds_u32_t*)(uintptr_t)(c > 0u ? full : qbase + (uint32_t)JQCAP * 4u);
+                                qp[2] = item + 2u;
+                                qp[1] = item + 1u;
+                                qp[0] = item;
+#endif
                                 for (uint32_t u = 3; __ballot(c > u); ++u)
                                     if (c > u) myq[pos + u] = item + u;
                             }
