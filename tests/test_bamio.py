@@ -268,7 +268,7 @@ def test_native_chop_equals_the_python_statement(tmp_path):
 
 
 def test_native_chop_from_several_threads(tmp_path):
-    """One BamFile read from eight threads at once (every thread gets its own library handle, the index is shared):
+    """One BamFile read from eight threads at once (every call in flight has a library handle of its own, the index is shared):
     the regions come back exactly as from one thread."""
     from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(77)
@@ -289,8 +289,15 @@ def test_native_chop_from_several_threads(tmp_path):
     serial = [b.chop_native("c", a, e, f) for a, e, f in qs]
     with ThreadPoolExecutor(max_workers=8) as pool:
         threaded = list(pool.map(lambda q: b.chop_native("c", *q), qs))
-    b.close()
     assert threaded == serial and sum(len(x) for x in serial) > 100
+    # a long run starts a pool of threads per batch: the handles (a file descriptor and inflate buffers each) are handed
+    # from call to call, not left behind with every pool
+    for _ in range(6):
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            assert list(pool.map(lambda q: b.chop_native("c", *q), qs)) == serial
+    assert 1 <= len(b._handles) <= 9 and len(b._free) == len(b._handles)
+    b.close()
+    assert not b._handles and not b._free
 
 
 def _native_inflate(comp: bytes, size: int):

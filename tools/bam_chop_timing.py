@@ -25,7 +25,7 @@ def run(fn):
 run(be.chop)
 lib = _lib.load()
 for nt in (1, 2, 4, 8):
-    lib.vapor_bam_set_threads(be._open(bam)._tls.native, nt)      # (this thread's handle, opened by the run above)
+    lib.vapor_bam_set_threads(be._open(bam)._free[-1]["native"], nt)      # (the handle the run above opened and will take again)
     print("native, %d inflate thread(s): %.3f ms per locus" % (nt, run(be.chop)), flush=True)
 print("python statement:            %.3f ms per locus" % run(be.chop_python))
 t0 = time.perf_counter()

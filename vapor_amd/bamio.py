@@ -202,9 +202,10 @@ class BamFile:
             self.refs.append((name, l_ref))
             self.tid[name] = t
         self.first_record = c.tell()
-        # vapor_bam handles of the HIP library's host helper, one per thread that reads (opened on first use; a handle owns
-        # its inflate buffers, the .bai index above is shared): pipeline.run_batch starts the loci of a batch on a few threads
-        self._tls = threading.local()
+        # vapor_bam handles of the HIP library's host helper: as many as calls were ever in flight at once (a handle owns
+        # its file descriptor and inflate buffers, the .bai index above is shared; `_free` holds the idle ones):
+        # pipeline.run_batch advances the loci of a batch on a few threads
+        self._free = []
         self._handles = []
         self._lock = threading.Lock()
         import os
@@ -259,27 +260,44 @@ class BamFile:
         tid = self.tid.get(chrom)
         if tid is None:
             return []
-        tl = self._tls
-        if getattr(tl, "native", None) is None:
-            h = ctypes.c_void_p()
-            if lib.vapor_bam_open(self.path.encode(), ctypes.byref(h)) != 0:
-                raise OSError(lib.vapor_bam_last_error().decode())
-            if threading.current_thread() is not threading.main_thread():
-                import os
-                lib.vapor_bam_set_threads(h, int(os.environ.get("VAPOR_BAM_INFLATE_THREADS", "2")))   # several readers at once: fewer inflate threads each
-            tl.native = h
-            tl.buf = {"seq": np.empty(1 << 20, dtype=np.uint8), "names": ctypes.create_string_buffer(1 << 16),
-                      "meta": np.empty(4 * 256, dtype=np.int64), "need": np.zeros(3, dtype=np.int64)}
-            with self._lock:
-                self._handles.append(h)
         ch = self.index.chunks(tid, max(int(start) - 1, 0), int(end))
         if not ch:
             return []
+        tl = self._take_handle(lib)
+        try:
+            return self._chop_with(lib, tl, tid, ch, start, end, flank_length)
+        finally:
+            with self._lock:
+                self._free.append(tl)
+
+    def _take_handle(self, lib):
+        """A native handle with its output buffers, for the duration of one call: from the free list, else a new one.
+        (Handles are not tied to threads: a pool of threads that lives for one batch would leave its handles - a file
+        descriptor and the inflate buffers each - behind for every batch of a long run.)"""
+        import ctypes
+        with self._lock:
+            if self._free:
+                return self._free.pop()
+        h = ctypes.c_void_p()
+        if lib.vapor_bam_open(self.path.encode(), ctypes.byref(h)) != 0:
+            raise OSError(lib.vapor_bam_last_error().decode())
+        if threading.current_thread() is not threading.main_thread():
+            import os
+            lib.vapor_bam_set_threads(h, int(os.environ.get("VAPOR_BAM_INFLATE_THREADS", "2")))   # several readers at once: fewer inflate threads each
+        tl = {"native": h, "buf": {"seq": np.empty(1 << 20, dtype=np.uint8), "names": ctypes.create_string_buffer(1 << 16),
+                                   "meta": np.empty(4 * 256, dtype=np.int64), "need": np.zeros(3, dtype=np.int64)}}
+        with self._lock:
+            self._handles.append(h)
+        return tl
+
+    def _chop_with(self, lib, tl, tid, ch, start, end, flank_length):
+        import ctypes
+        from . import _lib
         chunks = np.asarray(ch, dtype=np.uint64).reshape(-1)
         n = ctypes.c_int32(0)
         while True:
-            bf = tl.buf
-            rc = lib.vapor_bam_chop(tl.native, tid, int(start), int(end), int(flank_length), len(ch), chunks.ctypes.data,
+            bf = tl["buf"]
+            rc = lib.vapor_bam_chop(tl["native"], tid, int(start), int(end), int(flank_length), len(ch), chunks.ctypes.data,
                                     bf["seq"].ctypes.data, bf["seq"].size, ctypes.cast(bf["names"], ctypes.c_void_p), len(bf["names"]),
                                     bf["meta"].ctypes.data, bf["meta"].size // 4, ctypes.byref(n), bf["need"].ctypes.data)
             if rc == 0:
@@ -290,7 +308,7 @@ class BamFile:
                     raise IndexError("string index out of range")      # what '' [1] raises in SF:331
                 raise ValueError(msg)
             need = bf["need"]
-            tl.buf = {"seq": np.empty(int(need[0]) * 2 + 1024, dtype=np.uint8),
+            tl["buf"] = {"seq": np.empty(int(need[0]) * 2 + 1024, dtype=np.uint8),
                          "names": ctypes.create_string_buffer(int(need[1]) * 2 + 256),
                          "meta": np.empty(4 * (int(need[2]) * 2 + 16), dtype=np.int64), "need": need}
         if n.value == 0:
@@ -307,12 +325,11 @@ class BamFile:
 
     def close(self) -> None:
         with self._lock:
-            hs, self._handles = self._handles, []
+            hs, self._handles, self._free = self._handles, [], []
         if hs:
             from . import _lib
             for h in hs:
                 _lib.load().vapor_bam_close(h)
-        self._tls = threading.local()
 
     def __del__(self):
         try:
