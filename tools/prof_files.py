@@ -23,3 +23,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "--sweep":
         for _ in range(3):
             t0 = time.perf_counter(); run("s"); best = min(best, time.perf_counter() - t0)
         print("prefetch threads %2d x %d inflate: %.3f s -> %.0f loci/s" % (thr, inf, best, n / best), file=sys.stderr)
+if len(sys.argv) > 2 and sys.argv[2] == "--soak":
+    import resource
+    for i in range(12):
+        t0 = time.perf_counter(); run("k"); dt = time.perf_counter() - t0
+        print("soak run %2d: %.3f s, %d open descriptors, max RSS %.0f MB" % (i, dt, len(os.listdir("/proc/self/fd")),
+              resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024), file=sys.stderr)
