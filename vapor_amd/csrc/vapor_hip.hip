@@ -84,6 +84,9 @@ struct vapor_ctx {
     uint8_t* h_stage = nullptr;
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
+    // the genotype table of vapor_plan_set_reads, kept on the device while callers keep passing the same one
+    std::vector<double> h_gt;
+    double* d_gt = nullptr;
     int reads_per_task = MAX_READS_PER_TASK;   // upper bound on pairs per join task
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
@@ -199,6 +202,7 @@ struct vapor_plan {
     DRead* d_reads = nullptr;
     int32_t* d_locus_first = nullptr;
     double* d_gt = nullptr;
+    bool own_gt = false;              // false: the context's cached table
     double* d_read_scores = nullptr;
     double* d_loci = nullptr;
     unsigned int* d_overflow = nullptr;   // [0] pairs whose slot overflowed, [1] length of d_big_list
@@ -280,6 +284,7 @@ extern "C" int vapor_destroy(vapor_ctx* c)
         if (l) (void)hipStreamDestroy(l);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_gt) (void)hipFree(c->d_gt);
     delete c;
     return VAPOR_OK;
 }
@@ -478,8 +483,9 @@ static void plan_free_device(vapor_plan* p)
     dfree(p->ctx, p->d_nhits); p->d_nhits = nullptr;
     dfree(p->ctx, p->d_stats); p->d_stats = nullptr;
     dfree(p->ctx, p->d_reads); p->d_reads = nullptr;
-    dfree(p->ctx, p->d_locus_first); p->d_locus_first = nullptr;
-    dfree(p->ctx, p->d_gt); p->d_gt = nullptr;
+    p->d_locus_first = nullptr;           // (inside d_reads' block)
+    if (p->own_gt) dfree(p->ctx, p->d_gt);
+    p->d_gt = nullptr;
     dfree(p->ctx, p->d_read_scores); p->d_read_scores = nullptr;
     dfree(p->ctx, p->d_loci); p->d_loci = nullptr;
 }
@@ -588,13 +594,16 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     // Sort by (mode, k, allele): one launch per (mode, k); inside a launch the sorted pair list is
     // cut into contiguous, cost-balanced ranges (tasks).  A workgroup rebuilds its allele hash table
     // only where the allele changes inside its range.
-    std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        const DPair &a = p->hp[x], &b = p->hp[y];
-        if (mode[x] != mode[y]) return mode[x] < mode[y];
-        if (a.k != b.k) return a.k < b.k;
-        if (a.seq2 != b.seq2) return a.seq2 < b.seq2;
-        return x < y;
-    });
+    // (the three fields packed into one word per pair, the index behind it: the comparisons touch nothing else)
+    {
+        std::vector<std::pair<uint64_t, int32_t>> keyed(order.size());
+        for (size_t t = 0; t < order.size(); ++t) {
+            const int32_t x = order[t];
+            keyed[t] = {((uint64_t)mode[(size_t)x] << 48) | ((uint64_t)(uint32_t)p->hp[(size_t)x].k << 32) | (uint32_t)p->hp[(size_t)x].seq2, x};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t t = 0; t < order.size(); ++t) order[t] = keyed[t].second;
+    }
     p->task_pairs = order;
     auto tiles_of = [&](int32_t seq2, int k, int m) {
         const int ta = m != 4 ? tile_pos<JoinCfg, 2>() : tile_pos<JoinCfg, 4>();
@@ -618,13 +627,16 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             biggest = std::max(biggest, probe[t - q] + build[t - q]);
         }
         const int64_t want = std::max<int64_t>(1, std::min<int64_t>((int64_t)n, ctx->join_tasks));
-        auto new_allele = [&](size_t t) { return p->hp[order[q + t]].seq2 != p->hp[order[q + t - 1]].seq2; };
+        // (what a pair adds to a range it does not start: its probe, and a table build when it brings a new allele)
+        std::vector<int64_t> inside(n);
+        for (size_t t = 0; t < n; ++t)
+            inside[t] = probe[t] + ((t > 0 && p->hp[order[q + t]].seq2 != p->hp[order[q + t - 1]].seq2) ? build[t] : 0);
         // number of ranges a bound needs (cuts[] = first pair of every range when asked for)
         auto pack = [&](int64_t bound, std::vector<size_t>* cuts) {
             int64_t ranges = 0, acc = 0;
             size_t t0 = 0;
             for (size_t t = 0; t < n; ++t) {
-                const int64_t add = probe[t] + ((t == t0 || new_allele(t)) ? build[t] : 0);
+                const int64_t add = t == t0 ? probe[t] + build[t] : inside[t];
                 const bool full = (int)(t - t0) >= ctx->reads_per_task;
                 if (t > t0 && (acc + add > bound || full)) {
                     ++ranges;
@@ -639,7 +651,12 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             if (cuts) cuts->push_back(t0);
             return ranges;
         };
-        int64_t lo = biggest, hi = total;
+        // the smallest bound that needs at most `want` ranges: no partition can do with less than the costs inside
+        // ranges shared out evenly, a doubling search finds a bound that is enough, bisection the smallest between
+        int64_t in_sum = 0;
+        for (size_t t = 0; t < n; ++t) in_sum += inside[t];
+        int64_t lo = std::max(biggest, in_sum / want), hi = lo;
+        while (hi < total && pack(hi, nullptr) > want) { lo = hi + 1; hi = std::min(total, hi * 2); }
         while (lo < hi) {
             const int64_t mid = lo + (hi - lo) / 2;
             if (pack(mid, nullptr) <= want) hi = mid; else lo = mid + 1;
@@ -1094,16 +1111,37 @@ extern "C" int vapor_plan_set_reads(vapor_plan* p, int64_t n_reads, const vapor_
         first[(size_t)x.locus + 1]++;
     }
     for (int64_t l = 0; l < n_loci; ++l) first[l + 1] += first[l];
-    dfree(p->ctx, p->d_reads); dfree(p->ctx, p->d_locus_first); dfree(p->ctx, p->d_gt); dfree(p->ctx, p->d_read_scores); dfree(p->ctx, p->d_loci);
-    p->d_reads = nullptr; p->d_locus_first = nullptr; p->d_gt = nullptr; p->d_read_scores = nullptr; p->d_loci = nullptr;
-    HIPCHK(dmalloc(p->ctx, (void**)&p->d_reads, sizeof(DRead) * std::max<int64_t>(n_reads, 1)));
-    HIPCHK(dmalloc(p->ctx, (void**)&p->d_locus_first, sizeof(int32_t) * first.size()));
-    HIPCHK(dmalloc(p->ctx, (void**)&p->d_gt, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N));
+    dfree(p->ctx, p->d_reads); dfree(p->ctx, p->d_read_scores); dfree(p->ctx, p->d_loci);
+    if (p->own_gt) dfree(p->ctx, p->d_gt);
+    p->d_reads = nullptr; p->d_locus_first = nullptr; p->d_gt = nullptr; p->own_gt = false; p->d_read_scores = nullptr; p->d_loci = nullptr;
+    // the read table and the locus offsets travel as one block (one blocking copy out of caller memory instead of two)
+    const size_t reads_bytes = (sizeof(DRead) * (size_t)std::max<int64_t>(n_reads, 1) + 15) & ~(size_t)15;
+    const size_t first_bytes = sizeof(int32_t) * first.size();
+    std::vector<uint8_t> blockv(reads_bytes + first_bytes, 0);
+    if (n_reads) memcpy(blockv.data(), reads, sizeof(DRead) * (size_t)n_reads);
+    memcpy(blockv.data() + reads_bytes, first.data(), first_bytes);
+    HIPCHK(dmalloc(p->ctx, (void**)&p->d_reads, blockv.size()));
+    p->d_locus_first = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(p->d_reads) + reads_bytes);
     HIPCHK(dmalloc(p->ctx, (void**)&p->d_read_scores, sizeof(double) * std::max<int64_t>(n_reads, 1)));
     HIPCHK(dmalloc(p->ctx, (void**)&p->d_loci, sizeof(double) * 8 * std::max<int64_t>(n_loci, 1)));
-    if (n_reads) HIPCHK(hipMemcpy(p->d_reads, reads, sizeof(DRead) * n_reads, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->d_locus_first, first.data(), sizeof(int32_t) * first.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->d_gt, gt_table, sizeof(double) * 2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_reads, blockv.data(), blockv.size(), hipMemcpyHostToDevice));
+    // the genotype table is the same for every plan of a run: uploaded once per context, again only for a different one
+    {
+        vapor_ctx* c = p->ctx;
+        const size_t gt_n = (size_t)2 * VAPOR_GT_TABLE_N * VAPOR_GT_TABLE_N;
+        if (!c->d_gt) {
+            HIPCHK(hipMalloc((void**)&c->d_gt, sizeof(double) * gt_n));
+            HIPCHK(hipMemcpy(c->d_gt, gt_table, sizeof(double) * gt_n, hipMemcpyHostToDevice));
+            c->h_gt.assign(gt_table, gt_table + gt_n);
+        }
+        if (memcmp(c->h_gt.data(), gt_table, sizeof(double) * gt_n) == 0) {
+            p->d_gt = c->d_gt;
+        } else {
+            HIPCHK(dmalloc(c, (void**)&p->d_gt, sizeof(double) * gt_n));
+            p->own_gt = true;
+            HIPCHK(hipMemcpy(p->d_gt, gt_table, sizeof(double) * gt_n, hipMemcpyHostToDevice));
+        }
+    }
     p->n_reads = n_reads;
     p->n_loci = n_loci;
     return VAPOR_OK;
