@@ -547,3 +547,39 @@ def test_pool_size_follows_the_cpu_quota_and_the_ranks_on_the_host(monkeypatch):
         seqio.set_backend(None)
     monkeypatch.undo()
     assert 1 <= pipeline._usable_cores() <= (os.cpu_count() or 1)
+
+
+@pytest.mark.parametrize("procs", ["0", "2"])
+def test_figures_of_a_batch_are_drawn_by_worker_processes(fake, tmp_path, monkeypatch, procs):
+    """The drivers' Figure requests of a batch go through figures.make_figures: one device pass for all their dot plots,
+    the drawing in spawned worker processes (VAPOR_FIGURE_PROCS=2) or here (0); when run_batch returns every PNG the
+    reference would have written is on disk, and the batched specifications are the single ones."""
+    import figure_cases
+    from vapor_amd import drivers, figures
+    monkeypatch.setenv("VAPOR_FIGURE_PROCS", procs)
+    figures.shutdown()
+    cases = figure_cases.FIG["cases"]
+    reqs = [drivers.Figure(c["scores"], c["best_read"], c["k"], c["ref_seq"], c["alt_seq"],
+                           str(tmp_path / ("f%d.png" % n))) for n, c in enumerate(cases)]
+    many = figures.figure_specs(reqs)
+    for r, m in zip(reqs, many):
+        one = figures.figure_spec(r)
+        assert (one is None) == (m is None)
+        if one is not None:
+            assert one["name"] == m["name"] and all(np.array_equal(a["hits"], b["hits"]) and a["xticks"] == b["xticks"]
+                                                    for a, b in zip(one["subplots"], m["subplots"]))
+    try:
+        figures.make_event_figure_1.batch(reqs)
+        figures.make_event_figure_1.wait()
+        drawn = sorted(f for f in os.listdir(tmp_path) if f.endswith(".png"))
+        assert len(drawn) == sum(c["drawn"] is not None for c in cases) >= 6
+        assert all(os.path.getsize(tmp_path / f) > 2000 for f in drawn)
+        assert (figures._pool is not None) == (procs == "2")
+        # what a drawing raises (here: a directory that does not exist) comes back to the caller, from a worker too
+        bad = drivers.Figure(cases[0]["scores"], cases[0]["best_read"], cases[0]["k"], cases[0]["ref_seq"], cases[0]["alt_seq"],
+                             str(tmp_path / "no_such_dir" / "x.png"))
+        with pytest.raises((OSError, RuntimeError)):
+            figures.make_event_figure_1.batch([bad])
+            figures.make_event_figure_1.wait()
+    finally:
+        figures.shutdown()

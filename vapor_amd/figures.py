@@ -39,39 +39,54 @@ def clamp_name(name: str) -> str:
     return name
 
 
-def figure_spec(req, engine=None) -> Optional[dict]:
-    """None when the reference draws nothing (no best read, or one of the four plots is empty); else
-    {"name": file name, "subplots": [{"pos", "title", "hits" (n, 2) int32 [x = j, y = i], "xticks", "xticklabels"}]}."""
-    best = req.best_read
-    if best == '' or best == []:
-        return None
-    from . import pipeline
-    eng = engine or pipeline.get_engine()
-    ss = eng.seqset([req.ref_seq, req.alt_seq, best[0]])
-    try:
-        k, miss = int(req.k), int(best[1])
-        st, hits = eng.dotplots(ss, eng.make_pairs([(0, 0, 0, k, 0), (1, 1, 0, k, 0), (2, 0, miss, k, 0), (2, 1, miss, k, 0)]))
-    finally:
-        ss.close()
-    for row in st:
-        pipeline._raise_for_status(row)
-    if any(len(h) == 0 for h in hits):
-        return None
+def _subplots_of(hits) -> List[dict]:
     subs: List[dict] = []
     for h, title, pos in zip(hits, TITLES, POSITIONS):
         h = np.asarray(h, dtype=np.int32).reshape(-1, 2)
         h = h[np.lexsort((h[:, 1], h[:, 0]))]            # dotdata's order: by j, then i
         ticks = x_ticks(int(h[:, 0].max()))
         subs.append({"pos": pos, "title": title, "hits": h, "xticks": ticks, "xticklabels": [str(i) for i in ticks]})
-    return {"name": clamp_name(req.name), "subplots": subs}
+    return subs
 
 
-def make_event_figure_1(req) -> None:
-    """`req` is a drivers.Figure.  Nothing is drawn without a best read or when any of the four
-    plots is empty, as in the reference."""
-    spec = figure_spec(req)
-    if spec is None:
-        return
+def figure_specs(reqs, engine=None) -> List[Optional[dict]]:
+    """figure_spec for many requests with one sequence set and one device pass for all their dot plots."""
+    from . import pipeline
+    todo = [t for t, r in enumerate(reqs) if not (r.best_read == '' or r.best_read == [])]
+    out: List[Optional[dict]] = [None] * len(reqs)
+    if not todo:
+        return out
+    eng = engine or pipeline.get_engine()
+    seqs, rows = [], []
+    for t in todo:
+        r = reqs[t]
+        b = len(seqs)
+        k, miss = int(r.k), int(r.best_read[1])
+        seqs += [r.ref_seq, r.alt_seq, r.best_read[0]]
+        rows += [(b, b, 0, k, 0), (b + 1, b + 1, 0, k, 0), (b + 2, b, miss, k, 0), (b + 2, b + 1, miss, k, 0)]
+    ss = eng.seqset(seqs)
+    try:
+        st, hits = eng.dotplots(ss, eng.make_pairs(rows))
+    finally:
+        ss.close()
+    for n, t in enumerate(todo):
+        for row in st[4 * n:4 * n + 4]:
+            pipeline._raise_for_status(row)
+        mine = hits[4 * n:4 * n + 4]
+        if any(len(h) == 0 for h in mine):
+            continue
+        out[t] = {"name": clamp_name(reqs[t].name), "subplots": _subplots_of(mine)}
+    return out
+
+
+def figure_spec(req, engine=None) -> Optional[dict]:
+    """None when the reference draws nothing (no best read, or one of the four plots is empty); else
+    {"name": file name, "subplots": [{"pos", "title", "hits" (n, 2) int32 [x = j, y = i], "xticks", "xticklabels"}]}."""
+    return figure_specs([req], engine)[0]
+
+
+def render(spec: dict) -> None:
+    """What make_event_figure_1 hands to matplotlib (SF:1072-1089), for one specification."""
     import matplotlib
     matplotlib.use('Agg')
     import matplotlib.pyplot as plt
@@ -82,5 +97,148 @@ def make_event_figure_1(req) -> None:
         plt.xticks(sp["xticks"], sp["xticklabels"])
         plt.title(sp["title"])
         plt.grid(False)
-    plt.savefig(spec["name"])
+    fig.savefig(spec["name"])        # (the method itself: pyplot.savefig draws the whole figure a second time after the file is written)
     plt.close(fig)
+
+
+def make_event_figure_1(req) -> None:
+    """`req` is a drivers.Figure.  Nothing is drawn without a best read or when any of the four
+    plots is empty, as in the reference."""
+    spec = figure_spec(req)
+    if spec is not None:
+        render(spec)
+
+
+# ------------------------------------------------------------------------------------------
+# Many figures: the reference draws one PNG per locus inside its locus loop (a third of its time per locus, SURVEY 8f-2);
+# here the dot plots of a batch's figures are one device pass and the drawing - matplotlib, ~90 ms a figure - goes to a
+# few worker processes (`figure_worker.py`: fresh interpreters that never touch the GPU), so that it runs beside the scoring of the other
+# loci.  pipeline._answer calls `make_event_figure_1.batch`, pipeline.run_batch `make_event_figure_1.wait` before it
+# returns: when a batch is done its PNGs are on disk.
+# ------------------------------------------------------------------------------------------
+_pool = None
+_pending: list = []
+_CHUNK = 64                                   # figures per device pass (their dots pass through host memory)
+
+
+def _workers() -> int:
+    import os
+    want = os.environ.get("VAPOR_FIGURE_PROCS")
+    if want is not None:
+        return max(0, int(want))
+    from . import pipeline
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return max(0, min(16, pipeline._usable_cores() // ranks_here - 1))
+
+
+class _Workers:
+    """`n` drawing processes (python -m vapor_amd.figure_worker), each fed by one thread of a thread pool: a task writes
+    a pickled specification to its thread's process and waits for the one-byte answer.  Child processes of our own
+    rather than a multiprocessing pool: that one would import the caller's main module again in every worker."""
+
+    def __init__(self, n: int):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=n)
+        self.tls = threading.local()
+        self.lock = threading.Lock()
+        self.procs: list = []
+
+    def _proc(self):
+        import os
+        import subprocess
+        import sys
+        p = getattr(self.tls, "p", None)
+        if p is None or p.poll() is not None:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), MPLBACKEND="Agg")
+            p = subprocess.Popen([sys.executable, "-m", "vapor_amd.figure_worker"], stdin=subprocess.PIPE,
+                                 stdout=subprocess.PIPE, env=env)
+            self.tls.p = p
+            with self.lock:
+                self.procs.append(p)
+        return p
+
+    def _task(self, payload: bytes) -> None:
+        import struct
+        p = self._proc()
+        p.stdin.write(struct.pack("<q", len(payload)))
+        p.stdin.write(payload)
+        p.stdin.flush()
+        tag = p.stdout.read(1)
+        if tag == b"\x00":
+            return
+        if tag == b"\x01":
+            n = struct.unpack("<q", p.stdout.read(8))[0]
+            raise RuntimeError("figure worker: " + p.stdout.read(n).decode(errors="replace"))
+        raise RuntimeError("figure worker ended (exit code %s)" % p.poll())
+
+    def submit(self, spec: dict):
+        import pickle
+        return self.pool.submit(self._task, pickle.dumps(spec, protocol=4))
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)
+        with self.lock:
+            procs, self.procs = self.procs, []
+        for p in procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+        for p in procs:
+            p.wait()
+
+
+def _get_pool():
+    global _pool
+    if _pool is None:
+        n = _workers()
+        if n < 2:
+            return None
+        import atexit
+        _pool = _Workers(n)
+        atexit.register(shutdown)
+    return _pool
+
+
+def make_figures(reqs) -> None:
+    """make_event_figure_1 for many requests: batched dot plots, drawing handed to the worker processes (or done
+    here when there are none: VAPOR_FIGURE_PROCS=0, a single core)."""
+    pool = _get_pool()
+    for a in range(0, len(reqs), _CHUNK):
+        for spec in figure_specs(reqs[a:a + _CHUNK]):
+            if spec is None:
+                continue
+            if pool is None:
+                render(spec)
+            else:
+                _pending.append(pool.submit(spec))
+
+
+def wait() -> None:
+    """Returns when every figure handed out so far is on disk; raises what a drawing raised."""
+    global _pending
+    todo, _pending = _pending, []
+    first = None
+    for r in todo:
+        try:
+            r.result()
+        except Exception as e:          # noqa: BLE001 - the first one is raised once all are in
+            first = first or e
+    if first is not None:
+        raise first
+
+
+def shutdown() -> None:
+    global _pool
+    if _pool is not None:
+        try:
+            wait()
+        finally:
+            _pool.close()
+            _pool = None
+
+
+make_event_figure_1.batch = make_figures
+make_event_figure_1.wait = wait

@@ -315,9 +315,14 @@ def _answer(engine, reqs: Sequence[object], figure_fn) -> List[object]:
     if si:
         for t, v in zip(si, score_requests(engine, [reqs[t] for t in si])):
             res[t] = v
-    for t, r in enumerate(reqs):
-        if isinstance(r, Figure) and figure_fn is not None:
-            figure_fn(r)
+    if figure_fn is not None:
+        figs = [r for r in reqs if isinstance(r, Figure)]
+        batch = getattr(figure_fn, "batch", None)      # (figures.make_event_figure_1: one device pass, drawing in worker processes)
+        if figs and batch is not None:
+            batch(figs)
+        else:
+            for r in figs:
+                figure_fn(r)
     return res
 
 
@@ -331,6 +336,10 @@ def run_sync(gen, engine=None, figure_fn: Optional[Callable] = None):
             req = gen.throw(ans) if isinstance(ans, BaseException) else gen.send(ans)
     except StopIteration as e:
         return e.value
+    finally:
+        wait = getattr(figure_fn, "wait", None)
+        if wait is not None:
+            wait()
 
 
 def _prefetch_threads(n_gens: int) -> int:
@@ -422,4 +431,7 @@ def run_batch(gens: Sequence, engine=None, figure_fn: Optional[Callable] = None)
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
+        wait = getattr(figure_fn, "wait", None)
+        if wait is not None:
+            wait()                                   # the batch's figures are on disk when it returns
     return results
