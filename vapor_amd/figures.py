@@ -43,7 +43,9 @@ def _subplots_of(hits) -> List[dict]:
     subs: List[dict] = []
     for h, title, pos in zip(hits, TITLES, POSITIONS):
         h = np.asarray(h, dtype=np.int32).reshape(-1, 2)
-        h = h[np.lexsort((h[:, 1], h[:, 0]))]            # dotdata's order: by j, then i
+        key = (h[:, 0].astype(np.int64) << 32) | h[:, 1].astype(np.int64)
+        if key.size > 1 and not bool(np.all(key[1:] >= key[:-1])):     # (the engine hands them over sorted already)
+            h = h[np.argsort(key, kind="stable")]        # dotdata's order: by j, then i
         ticks = x_ticks(int(h[:, 0].max()))
         subs.append({"pos": pos, "title": title, "hits": h, "xticks": ticks, "xticklabels": [str(i) for i in ticks]})
     return subs
