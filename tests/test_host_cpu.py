@@ -574,7 +574,8 @@ def test_figures_of_a_batch_are_drawn_by_worker_processes(fake, tmp_path, monkey
         drawn = sorted(f for f in os.listdir(tmp_path) if f.endswith(".png"))
         assert len(drawn) == sum(c["drawn"] is not None for c in cases) >= 6
         assert all(os.path.getsize(tmp_path / f) > 2000 for f in drawn)
-        assert (figures._pool is not None) == (procs == "2")
+        from vapor_amd import hostpool
+        assert (hostpool._pool is not None) == (procs == "2")
         # what a drawing raises (here: a directory that does not exist) comes back to the caller, from a worker too
         bad = drivers.Figure(cases[0]["scores"], cases[0]["best_read"], cases[0]["k"], cases[0]["ref_seq"], cases[0]["alt_seq"],
                              str(tmp_path / "no_such_dir" / "x.png"))
@@ -583,3 +584,28 @@ def test_figures_of_a_batch_are_drawn_by_worker_processes(fake, tmp_path, monkey
             figures.make_event_figure_1.wait()
     finally:
         figures.shutdown()
+
+
+def test_repeat_clustering_in_host_workers_equals_the_callers_own(fake, monkeypatch):
+    """refine_windows hands the X-means clustering of the windows in the (0.1, 0.5) band to the host worker processes
+    when there are eight or more: with a seed (the reference runs it unseeded) the answers are those of the calling
+    process, slot for slot."""
+    from vapor_amd import hostpool
+    rng = np.random.default_rng(12)
+    seqs = []
+    for _ in range(10):
+        a, b, c = (synth.random_dna(rng, int(n)) for n in (rng.integers(150, 260), rng.integers(260, 340), rng.integers(150, 260)))
+        seqs.append(a + b + b + c)                      # a tandem duplication: its copy's dots lie off the diagonal
+    seqs.append(synth.random_dna(rng, 500))             # and one window that is not in the band
+    monkeypatch.setenv("VAPOR_QC_SEED", "7")
+    hostpool.shutdown()
+    monkeypatch.setenv("VAPOR_HOST_PROCS", "0")
+    own = pipeline.refine_windows(fake, seqs)
+    assert sum(1 for r in own if isinstance(r, list) and r[1] != "Error" and r[1][1] != [0]) >= 8
+    monkeypatch.setenv("VAPOR_HOST_PROCS", "2")
+    try:
+        pooled = pipeline.refine_windows(fake, seqs)
+        assert hostpool._pool is not None and len(hostpool._pool.procs) >= 1
+    finally:
+        hostpool.shutdown()
+    assert repr(pooled) == repr(own)

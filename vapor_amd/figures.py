@@ -114,100 +114,19 @@ def make_event_figure_1(req) -> None:
 # ------------------------------------------------------------------------------------------
 # Many figures: the reference draws one PNG per locus inside its locus loop (a third of its time per locus);
 # here the dot plots of a batch's figures are one device pass and the drawing - matplotlib, ~90 ms a figure - goes to a
-# few worker processes (`figure_worker.py`: fresh interpreters that never touch the GPU), so that it runs beside the scoring of the other
+# few worker processes (`hostpool.py`: fresh interpreters that never touch the GPU), so that it runs beside the scoring of the other
 # loci.  pipeline._answer calls `make_event_figure_1.batch`, pipeline.run_batch `make_event_figure_1.wait` before it
 # returns: when a batch is done its PNGs are on disk.
 # ------------------------------------------------------------------------------------------
-_pool = None
 _pending: list = []
 _CHUNK = 64                                   # figures per device pass (their dots pass through host memory)
 
 
-def _workers() -> int:
-    import os
-    want = os.environ.get("VAPOR_FIGURE_PROCS")
-    if want is not None:
-        return max(0, int(want))
-    from . import pipeline
-    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    return max(0, min(16, pipeline._usable_cores() // ranks_here - 1))
-
-
-class _Workers:
-    """`n` drawing processes (python -m vapor_amd.figure_worker), each fed by one thread of a thread pool: a task writes
-    a pickled specification to its thread's process and waits for the one-byte answer.  Child processes of our own
-    rather than a multiprocessing pool: that one would import the caller's main module again in every worker."""
-
-    def __init__(self, n: int):
-        import threading
-        from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(max_workers=n)
-        self.tls = threading.local()
-        self.lock = threading.Lock()
-        self.procs: list = []
-
-    def _proc(self):
-        import os
-        import subprocess
-        import sys
-        p = getattr(self.tls, "p", None)
-        if p is None or p.poll() is not None:
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), MPLBACKEND="Agg")
-            p = subprocess.Popen([sys.executable, "-m", "vapor_amd.figure_worker"], stdin=subprocess.PIPE,
-                                 stdout=subprocess.PIPE, env=env)
-            self.tls.p = p
-            with self.lock:
-                self.procs.append(p)
-        return p
-
-    def _task(self, payload: bytes) -> None:
-        import struct
-        p = self._proc()
-        p.stdin.write(struct.pack("<q", len(payload)))
-        p.stdin.write(payload)
-        p.stdin.flush()
-        tag = p.stdout.read(1)
-        if tag == b"\x00":
-            return
-        if tag == b"\x01":
-            n = struct.unpack("<q", p.stdout.read(8))[0]
-            raise RuntimeError("figure worker: " + p.stdout.read(n).decode(errors="replace"))
-        raise RuntimeError("figure worker ended (exit code %s)" % p.poll())
-
-    def submit(self, spec: dict):
-        import pickle
-        return self.pool.submit(self._task, pickle.dumps(spec, protocol=4))
-
-    def close(self) -> None:
-        self.pool.shutdown(wait=True)
-        with self.lock:
-            procs, self.procs = self.procs, []
-        for p in procs:
-            try:
-                p.stdin.close()
-            except OSError:
-                pass
-        for p in procs:
-            p.wait()
-
-
-def _get_pool():
-    global _pool
-    if _pool is None:
-        n = _workers()
-        if n < 2:
-            return None
-        import atexit
-        _pool = _Workers(n)
-        atexit.register(shutdown)
-    return _pool
-
-
 def make_figures(reqs) -> None:
-    """make_event_figure_1 for many requests: batched dot plots, drawing handed to the worker processes (or done
-    here when there are none: VAPOR_FIGURE_PROCS=0, a single core)."""
-    pool = _get_pool()
+    """make_event_figure_1 for many requests: batched dot plots, drawing handed to the worker processes of
+    vapor_amd.hostpool (or done here when there are none: VAPOR_HOST_PROCS=0, a single core)."""
+    from . import hostpool
+    pool = hostpool.get()
     for a in range(0, len(reqs), _CHUNK):
         for spec in figure_specs(reqs[a:a + _CHUNK]):
             if spec is None:
@@ -215,7 +134,7 @@ def make_figures(reqs) -> None:
             if pool is None:
                 render(spec)
             else:
-                _pending.append(pool.submit(spec))
+                _pending.append(pool.submit("vapor_amd.figures", "render", spec))
 
 
 def wait() -> None:
@@ -233,13 +152,11 @@ def wait() -> None:
 
 
 def shutdown() -> None:
-    global _pool
-    if _pool is not None:
-        try:
-            wait()
-        finally:
-            _pool.close()
-            _pool = None
+    from . import hostpool
+    try:
+        wait()
+    finally:
+        hostpool.shutdown()
 
 
 make_event_figure_1.batch = make_figures

@@ -115,6 +115,19 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
                 pts[int(w)] = h[np.lexsort((h[:, 1], h[:, 0]))]
         plan.close()
         ss.close()
+        # the clustering of the windows in the band (sklearn / scipy, ~1 ms each, unseeded as in the reference) goes to the
+        # host worker processes when there are enough of them to pay for the pickling
+        sizes_of: Dict[int, object] = {}
+        if len(pts) >= 8:
+            from . import hostpool
+            hp = hostpool.get()
+            if hp is not None:
+                futs = {w: hp.submit("vapor_amd.repeat_qc", "cluster_sizes", p[:, 0].tolist(), p[:, 1].tolist()) for w, p in pts.items()}
+                for w, f in futs.items():
+                    try:
+                        sizes_of[w] = f.result()
+                    except Exception as e:      # noqa: BLE001 - e.g. the clustering libraries' own errors
+                        sizes_of[w] = e
         nxt = []
         for w, (t, s2) in enumerate(work):
             if code[w] != 0:
@@ -129,7 +142,10 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
                 continue
             if band[w]:
                 try:
-                    qc = [float(diag[w]), repeat_qc.cluster_sizes(pts[w][:, 0].tolist(), pts[w][:, 1].tolist())]
+                    got = sizes_of[w] if w in sizes_of else repeat_qc.cluster_sizes(pts[w][:, 0].tolist(), pts[w][:, 1].tolist())
+                    if isinstance(got, BaseException):
+                        raise got
+                    qc = [float(diag[w]), got]
                 except Exception as e:          # noqa: BLE001 - e.g. the clustering libraries' own errors
                     out[t] = e
                     continue
