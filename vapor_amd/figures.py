@@ -134,21 +134,36 @@ def make_figures(reqs) -> None:
             if pool is None:
                 render(spec)
             else:
-                _pending.append(pool.submit("vapor_amd.figures", "render", spec))
+                # (a few figures per worker in flight: their dots wait in memory, half a megabyte a figure)
+                while len(_pending) >= 4 * pool.n:
+                    _settle(_pending.pop(0))
+                _pending.append((pool.submit("vapor_amd.figures", "render", spec), spec))
+
+
+_first_error: list = []
+
+
+def _settle(item) -> None:
+    from . import hostpool
+    r, spec = item
+    try:
+        try:
+            r.result()
+        except hostpool.WorkerLost:
+            render(spec)                # (the worker is gone: drawn here)
+    except Exception as e:              # noqa: BLE001 - the first one is raised by wait() once all are in
+        if not _first_error:
+            _first_error.append(e)
 
 
 def wait() -> None:
     """Returns when every figure handed out so far is on disk; raises what a drawing raised."""
     global _pending
     todo, _pending = _pending, []
-    first = None
-    for r in todo:
-        try:
-            r.result()
-        except Exception as e:          # noqa: BLE001 - the first one is raised once all are in
-            first = first or e
-    if first is not None:
-        raise first
+    for item in todo:
+        _settle(item)
+    if _first_error:
+        raise _first_error.pop()
 
 
 def shutdown() -> None:

@@ -30,6 +30,10 @@ def n_workers() -> int:
     return max(0, min(16, pipeline._usable_cores() // ranks_here - 1))
 
 
+class WorkerLost(RuntimeError):
+    """The worker process could not be started or ended before it answered (the caller then does the work itself)."""
+
+
 class Workers:
     def __init__(self, n: int):
         self.n = n
@@ -52,13 +56,16 @@ class Workers:
         return p
 
     def _task(self, payload: bytes):
-        p = self._proc()
-        p.stdin.write(struct.pack("<q", len(payload)))
-        p.stdin.write(payload)
-        p.stdin.flush()
-        tag = p.stdout.read(1)
+        try:
+            p = self._proc()
+            p.stdin.write(struct.pack("<q", len(payload)))
+            p.stdin.write(payload)
+            p.stdin.flush()
+            tag = p.stdout.read(1)
+        except OSError as e:
+            raise WorkerLost("host worker: %s" % e) from e
         if tag not in (b"\x00", b"\x01"):
-            raise RuntimeError("host worker ended (exit code %s)" % p.poll())
+            raise WorkerLost("host worker ended (exit code %s)" % p.poll())
         n = struct.unpack("<q", p.stdout.read(8))[0]
         body = pickle.loads(p.stdout.read(n))
         if tag == b"\x00":

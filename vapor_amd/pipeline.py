@@ -126,6 +126,8 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
                 for w, f in futs.items():
                     try:
                         sizes_of[w] = f.result()
+                    except hostpool.WorkerLost:
+                        pass                    # (clustered below, by this process)
                     except Exception as e:      # noqa: BLE001 - e.g. the clustering libraries' own errors
                         sizes_of[w] = e
         nxt = []
