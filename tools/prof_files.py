@@ -9,7 +9,7 @@ tmp = tempfile.mkdtemp()
 fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
 bed = os.path.join(tmp, "in.bed"); open(bed, "w").write(synth.bed_text(w))
 def run(tag):
-    return cli.main(["bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam, "--output-path", tmp + "/f", "--output-file", tmp + "/o%s.vapor" % tag, "--no-figures"])
+    return cli.main(["bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam, "--output-path", tmp + "/f", "--output-file", tmp + "/o%s.vapor" % tag] + ([] if os.environ.get("VAPOR_PROF_FIGURES") else ["--no-figures"]))
 run("a")
 t0 = time.perf_counter(); run("b"); dt = time.perf_counter() - t0
 print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt))
