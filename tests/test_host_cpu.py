@@ -609,3 +609,28 @@ def test_repeat_clustering_in_host_workers_equals_the_callers_own(fake, monkeypa
     finally:
         hostpool.shutdown()
     assert repr(pooled) == repr(own)
+
+
+def test_kept_figure_writes_the_same_bytes_as_a_fresh_one(fake, tmp_path):
+    """figures.render keeps its matplotlib figure between calls; figures.render_fresh makes the reference's calls one by
+    one on a new figure: the PNG files are equal byte for byte, whatever was drawn before (larger, smaller, other ticks)."""
+    import figure_cases
+    from vapor_amd import drivers, figures
+    cases = figure_cases.FIG["cases"]
+    reqs = [drivers.Figure(c["scores"], c["best_read"], c["k"], c["ref_seq"], c["alt_seq"], "x.png") for c in cases]
+    specs = [s for s in figures.figure_specs(reqs) if s is not None]
+    rng = np.random.default_rng(9)
+    for n in (40, 30000, 700):                             # and synthetic ones of very different extents
+        d = np.arange(n, dtype=np.int32)
+        h = np.stack([d, d], 1)
+        h = np.concatenate([h, rng.integers(0, n, (n // 20 + 3, 2)).astype(np.int32)])
+        h = h[np.lexsort((h[:, 1], h[:, 0]))]
+        t = figures.x_ticks(int(h[:, 0].max()))
+        specs.append({"name": "x.png", "subplots": [{"pos": p, "title": ti, "hits": h, "xticks": t, "xticklabels": [str(i) for i in t]}
+                                                    for p, ti in zip(figures.POSITIONS, figures.TITLES)]})
+    assert len(specs) >= 9
+    for n, spec in enumerate(specs + specs[::-1]):
+        a, b = dict(spec, name=str(tmp_path / ("kept%d.png" % n))), dict(spec, name=str(tmp_path / ("fresh%d.png" % n)))
+        figures.render(a)
+        figures.render_fresh(b)
+        assert open(a["name"], "rb").read() == open(b["name"], "rb").read(), n
