@@ -122,7 +122,7 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
             from . import hostpool
             hp = hostpool.get()
             if hp is not None:
-                futs = {w: hp.submit("vapor_amd.repeat_qc", "cluster_sizes", p[:, 0].tolist(), p[:, 1].tolist()) for w, p in pts.items()}
+                futs = {w: hp.submit("vapor_amd.repeat_qc", "cluster_sizes_of_points", p) for w, p in pts.items()}
                 for w, f in futs.items():
                     try:
                         sizes_of[w] = f.result()

@@ -38,7 +38,10 @@ def _one_thread():
 
 def _log10(x):
     """calcu_log10, SF:155-159."""
-    return 0 if x == 0 else np.log10(x)
+    if x == 0:
+        return 0
+    with np.errstate(divide="ignore"):          # (a zero variance term gives -inf, as in the reference; not worth a warning per process)
+        return np.log10(x)
 
 
 def _bic(km, X) -> float:
@@ -121,6 +124,11 @@ def cluster_sizes(lower_j: Sequence[int], lower_i: Sequence[int]) -> List[float]
     for cx, cy in x_means(list(lower_j), list(lower_i)):
         out.append(np.sqrt((max(cx) - min(cx)) * (max(cy) - min(cy))))
     return out
+
+
+def cluster_sizes_of_points(points: np.ndarray) -> List[float]:
+    """cluster_sizes for an (n, 2) array [j, i] (what a host worker is sent: the lists are made on its side)."""
+    return cluster_sizes(points[:, 0].tolist(), points[:, 1].tolist())
 
 
 def qual_check_from_counts(n_hits: int, n_diag: int, n_lower: int, lower_points=None):
