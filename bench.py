@@ -44,6 +44,16 @@ def _load_json(name):
     return None
 
 
+def kernel_source_id() -> str:
+    """sha256 (16 hex digits) over the library's sources: what a committed counter summary must have been measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("vapor_amd/csrc/vapor_kernels.h", "vapor_amd/csrc/vapor_hip.hip", "include/vapor_hip.h", "vapor_amd/build.py"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 class Resident:
     """A batch resident in HBM with `n_plans` plans over it; pass i runs on plan i % n_plans."""
 
@@ -110,16 +120,26 @@ def main() -> None:
     ap.add_argument("--sub", default="cfg3", help="workload of the sub-record ('' = none)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process has not touched the GPU (torch is not even imported yet);
+        # it starts N fresh rank processes and relays their output and status
+        raise SystemExit(spawn_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (or plain `python bench.py --gpus N`, "
+                         "which starts them itself)" % (args.gpus, world))
 
     import torch
+    n_dev = torch.cuda.device_count()           # (counting devices does not initialise the GPU)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    # VAPOR_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on one GPU (RCCL wants a GPU per rank)
-    backend = os.environ.get("VAPOR_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count()
+    # RCCL wants a GPU per rank.  With fewer GPUs than ranks (a rehearsal of the N > 1 path on one card) the ranks share
+    # the GPUs and the all-gather goes through gloo; VAPOR_BENCH_BACKEND forces either.
+    backend = os.environ.get("VAPOR_BENCH_BACKEND", "nccl" if world <= n_dev else "gloo")
+    local = local % n_dev
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -212,15 +232,24 @@ def main() -> None:
     dom = "join_kernel" if res.alone["join_ms"] >= res.alone["clean_ms"] else "clean_kernel"
     dom_ms = avg["join_ms"] if dom == "join_kernel" else avg["clean_ms"]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # counter passes of this same workload and build, committed under profiles/ (byte and instruction counts depend on
-    # the batch and the code, not on the run): fabric-side bytes per launch and what the counters say binds
+    # Counter passes (rocprofv3 --pmc: fabric-side bytes per launch, what the counters say binds) cannot be taken inside
+    # this run; the committed summaries under profiles/ are quoted ONLY when they were measured on this workload with
+    # this very kernel source (sha of vapor_amd/csrc + include), and their provenance is printed beside them.
+    src_id = kernel_source_id()
     traffic = util = None
-    tj = _load_json("r02_%s_traffic.json" % args.workload) or _load_json("r01_%s_traffic.json" % args.workload)
+    traffic_source = binds_source = None
+    tj = _load_json("r03_%s_traffic.json" % args.workload)
     if tj and dom in tj:
-        traffic = int(tj[dom]["bytes"])
-    uj = _load_json("r02_%s_util.json" % args.workload)
+        traffic_source = {"file": "profiles/r03_%s_traffic.json" % args.workload, "measured_on_source": tj.get("source_id"),
+                          "this_source": src_id, "live": False}
+        if tj.get("source_id") == src_id:
+            traffic = int(tj[dom]["bytes"])
+    uj = _load_json("r03_%s_util.json" % args.workload)
     if uj and dom in uj:
-        util = uj[dom]
+        binds_source = {"file": "profiles/r03_%s_util.json" % args.workload, "measured_on_source": uj.get("source_id"),
+                        "this_source": src_id, "live": False}
+        if uj.get("source_id") == src_id:
+            util = uj[dom]
 
     extras = {}
     cpu = None
@@ -228,7 +257,7 @@ def main() -> None:
         if not args.no_extras:
             extras["inclusive"] = inclusive_rate(eng, w, wl)
             if args.sub and args.sub != args.workload:
-                extras["sub"] = sub_record(eng, wl, args.sub, torch)
+                extras["sub"] = sub_record(eng, wl, args.sub, torch, cpu_seconds=0.0 if args.no_cpu else min(args.cpu_seconds, 10.0))
         if not args.no_cpu:
             cpu = cpu_baseline(w, st, n_pairs, args.cpu_seconds)
 
@@ -237,7 +266,10 @@ def main() -> None:
             "metric": "SV loci validated/sec",
             "value": round(loci_s, 3),
             "unit": "loci/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus,
+            "ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "backend": (backend if dist is not None else None),
+            "gpus_visible": n_dev,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -261,14 +293,13 @@ def main() -> None:
                           "device_total": round(avg["total_ms"], 4), "join_launches": launches,
                           "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)}},
             "upload_pack_s": round(res.upload_s, 4),
-            # `bound`: the roof the kernel sits under.  The counter passes (profiles/r02_cfg2_util.json) give the occupancy of
-            # the vector ALUs directly - (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / SQ_BUSY_CU_CYCLES, gfx950 issues two simple
-            # vector instructions of different waves in one quad-cycle (profiles/r02_valu_ops.txt) - 0.78 for the join, the LDS
-            # array half busy, the fabric at 2 % of HBM peak.  achieved / peak / frac are still priced against the HBM roof
-            # the task names, with SURVEY 8d's algorithmic bytes; traffic_* use the bytes the kernel really moves; binds.*
-            # hold the utilisations.
-            "roofline": {"bound": "valu_issue", "priced_against": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # `achieved` / `peak` / `frac`: SURVEY 8d's algorithmic bytes per launch over the dominant kernel's live
+            # HIP-event duration, against the HBM roof the task names.  `bound` says which roof the kernel really sits
+            # under and is printed only with counter evidence for this workload, kernel and source (`binds`); the kernels
+            # are vector-issue-bound, the fabric moves a few per cent of HBM peak.
+            "roofline": {"bound": ("valu_issue" if util else "hbm"), "priced_against": "hbm", "kernel": dom, "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          # `achieved` / `frac` price the kernel's interval inside the timed region, where the other plan's
                          # clean and finish kernels share the CUs with it; alone (the blocking run before the region) it is
@@ -277,14 +308,45 @@ def main() -> None:
                          "record_bytes_per_launch": 8 * n_rec,
                          "traffic_gbs": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic and dom_ms > 0 else None,
                          "traffic_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and dom_ms > 0 else None,
-                         "binds": util},
+                         "binds": util, "binds_source": binds_source},
             "cpu_baseline": cpu,
         }
         out.update(extras)
+        if "inclusive" in extras:
+            # the same batch when every pass also pays upload + packing, the window self plots, planning and a blocking pass
+            out["inclusive_value"] = extras["inclusive"]["value"]
+        sub = extras.get("sub")
+        if sub and sub.get("cpu_baseline") and sub["cpu_baseline"].get("reference"):
+            # north_star's target is stated on 1 000 loci x 40x (configs[2] = cfg3): GPU over the reference's Cython path
+            ref = sub["cpu_baseline"]["reference"]
+            est = ref["estimated_reference_cython_loci_per_s_here"]
+            out["target_200x"] = {"config": "cfg3", "gpu_loci_per_s": sub["value"], "cpu_port_loci_per_s": sub["cpu_baseline"]["value"],
+                                  "port_over_reference_cython": ref["port_over_reference_cython"],
+                                  "estimated_reference_cython_loci_per_s": est,
+                                  "gpu_over_reference": round(sub["value"] / est, 1) if est > 0 else None,
+                                  "gpu_over_port": round(sub["value"] / sub["cpu_baseline"]["value"], 1),
+                                  "met": bool(est > 0 and sub["value"] / est >= 200.0)}
         print(json.dumps(out))
     res.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n: int) -> int:
+    """Starts `n` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and
+    returns their exit status.  Called before anything in this process has touched the GPU; the ranks are children, never
+    an exec of this process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def inclusive_rate(eng, w, wl, reps: int = 6):
@@ -323,7 +385,7 @@ def inclusive_rate(eng, w, wl, reps: int = 6):
                         "Median of %d batches, one at a time" % (len(allele_idx), reps)}
 
 
-def sub_record(eng, wl, name, torch, passes: int = 12):
+def sub_record(eng, wl, name, torch, passes: int = 12, cpu_seconds: float = 0.0):
     """The resident measurement on another BASELINE shape, same build, same run: two plans in flight like the headline
     (the clean and finish kernels of one pass overlap the other plan's join), and one plan alone for comparison."""
     spec = wl.WORKLOADS[name]
@@ -351,7 +413,7 @@ def sub_record(eng, wl, name, torch, passes: int = 12):
 
     dt1, tm1 = timed(plans[:1])
     dt2, tm2 = timed(plans)
-    plans[0].run()
+    st = plans[0].run().copy()
     alg, cells = plans[0].algorithmic()
     out = {"workload": "%s: %d loci x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s; resident in HBM"
                        % (name, w.n_loci, spec["reads_per_locus"], spec["read_len"], spec["allele_len"], "/".join(sorted(set(w.svtypes)))),
@@ -364,10 +426,22 @@ def sub_record(eng, wl, name, torch, passes: int = 12):
     for p in plans:
         p.close()
     ss.close()
+    if cpu_seconds > 0:
+        # the CPU port beside it on a bounded sample of THIS shape, and the reference : port ratio measured on this shape
+        out["cpu_baseline"] = cpu_baseline(w, st, len(w.pairs), cpu_seconds, ratio_file="r03_cpu_ratio_%s.json" % name)
     return out
 
 
-def cpu_baseline(w, st, n_pairs, seconds):
+def host_cores() -> dict:
+    """The box's core count and the share of it this process may use (north_star: 'core count stated')."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"logical": os.cpu_count(), "usable_by_this_process": usable}
+
+
+def cpu_baseline(w, st, n_pairs, seconds, ratio_file="r03_cpu_ratio_cfg2.json"):
     """The CPU port timed through the same C ABI: oracle/_build/libvapor_cpu.so (oracle/cpu_twin.cpp on vapor_oracle.c)
     exports include/vapor_hip.h's symbols; a bounded sample of the batch's pairs is run through vapor_plan_run there,
     chunk by chunk, one thread, and every record is compared with the GPU's."""
@@ -406,12 +480,12 @@ def cpu_baseline(w, st, n_pairs, seconds):
         done += len(pr)
     tw.vapor_destroy(ctx)
     pairs_per_locus = n_pairs / w.n_loci
-    cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "kind": "port",
+    cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "host_cores": host_cores(), "kind": "port",
            "sample": "first %d of %d (read, allele) dot plots of the same batch through libvapor_cpu.so - the CPU oracle behind "
                      "the same C ABI (oracle/cpu_twin.cpp + vapor_oracle.c: fill, C1/C2 clean, counts, directed statistics; "
                      "gcc -O2, 1 thread, %.1f s); every record checked equal to the GPU's" % (done, n_pairs, ct),
            "cells_per_s": round(c_cells / ct, 1)}
-    rj = _load_json("r02_cpu_ratio.json")
+    rj = _load_json(ratio_file)
     if rj:
         # the reference itself cannot travel to the GPU box: its rate relative to this port was measured in the
         # development container on the same shape (tools/cpu_ratio.py)
@@ -419,7 +493,7 @@ def cpu_baseline(w, st, n_pairs, seconds):
                             "port_over_reference_python": round(rj["port_over_reference_python"], 1),
                             "reference_cython_loci_per_s_there": round(rj["reference_cython_loci_per_s"], 4),
                             "estimated_reference_cython_loci_per_s_here": round(cpu["value"] / rj["port_over_reference_cython"], 4),
-                            "provenance": "profiles/r02_cpu_ratio.json: " + rj["note"] + "; " + rj["shape"]}
+                            "provenance": "profiles/" + ratio_file + ": " + rj["note"] + "; " + rj["shape"]}
     return cpu
 
 

@@ -20,7 +20,12 @@
 extern "C" {
 #endif
 
-#define VAPOR_ABI_VERSION 1
+#define VAPOR_ABI_VERSION 2
+/* A developer build of the library (-DVAPOR_DEV_BUILD: timing stamps, A/B variants, non-default tuning constants)
+ * reports VAPOR_ABI_VERSION + VAPOR_ABI_DEV_OFFSET and lists what it carries in vapor_build_flags(); the product
+ * build reports VAPOR_ABI_VERSION and "".  A loader that accepts only VAPOR_ABI_VERSION can never run an
+ * experimental library by accident. */
+#define VAPOR_ABI_DEV_OFFSET 1000000
 
 /* status codes */
 #define VAPOR_OK 0
@@ -84,6 +89,7 @@ typedef struct vapor_pair {
 
 /* ---- context --------------------------------------------------------------------------- */
 int vapor_abi_version(void);
+const char* vapor_build_flags(void);
 const char* vapor_last_error(void);
 int vapor_init(int device_ordinal, vapor_ctx** ctx);
 int vapor_destroy(vapor_ctx* ctx);

@@ -59,6 +59,7 @@ static bool in_alphabet(unsigned char c)        // invert_base's alphabet after 
 }
 
 extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION; }
+extern "C" const char* vapor_build_flags(void) { return ""; }
 extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 extern "C" int vapor_init(int device_ordinal, vapor_ctx** ctx)
 {

@@ -7,6 +7,8 @@
   * the linear-index rule: a region query never starts before the window's recorded offset and finds every overlap.
 CPU only; no third-party BAM exists in this environment."""
 import gzip
+import os
+import shutil
 import struct
 import zlib
 
@@ -72,7 +74,7 @@ def _member(data, level):
 
 
 def _encode_bam(path, refs, reads):
-    """reads: (qname, tid, pos0, [(len, op)...], seq, aux bytes); tid -1 = unmapped.  One BGZF block per record."""
+    """reads: (qname, tid, pos0, [(len, op)...], seq, aux bytes); tid -1 = unmapped.  One BGZF block per record (several for a record above 64 KB)."""
     text = b"@HD\tVN:1.6\tSO:coordinate\n"
     head = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
     for name, ln in refs:
@@ -93,7 +95,9 @@ def _encode_bam(path, refs, reads):
         rec = struct.pack("<iiBBHHHiiii", tid, pos, len(qname) + 1, 30, b, len(cig), 4 if tid < 0 else 0, len(seq), -1, -1, 0)
         rec += qname.encode() + b"\0" + b"".join(struct.pack("<I", c) for c in cig) + bytes(sq) + b"\x20" * len(seq) + aux
         v0 = len(out) << 16
-        out += _member(struct.pack("<i", len(rec)) + rec, 9)
+        body = struct.pack("<i", len(rec)) + rec
+        for q in range(0, len(body), 65280):                   # a BGZF block holds at most 64 KB of data (SAM 4.1)
+            out += _member(body[q:q + 65280], 9)
         v1 = len(out) << 16
         if tid >= 0:
             index[tid].setdefault(b, []).append((v0, v1))
@@ -378,3 +382,164 @@ def test_block_decoder_refuses_what_zlib_refuses():
                     refused += ours is None
                     accepted += ours is not None
     assert refused > 500
+
+
+# ---------------------------------------------------------------------------------------------
+# damaged files: every size field is checked before use and the block CRC32 is verified; a file that
+# breaks a rule is a Python exception from both readers - never a crash, never silently different reads
+# ---------------------------------------------------------------------------------------------
+def _blocks(raw: bytes):
+    """(offset, bsize, xlen) of every BGZF block of a file image."""
+    out, p = [], 0
+    while p + 18 <= len(raw):
+        xlen = struct.unpack_from("<H", raw, p + 10)[0]
+        bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+        out.append((p, bsize, xlen))
+        p += bsize
+    return out
+
+
+def _small_bam(tmp_path, name="dmg.bam", block_size=3000):
+    rng = np.random.default_rng(5)
+    contig = synth.random_dna(rng, 30000)
+    recs = []
+    for i in range(150):
+        pos = int(rng.integers(0, 20000)); n = int(rng.integers(3000, 7000))
+        read, cg = synth.mutate(rng, contig[pos:pos + n])
+        recs.append(("d%d" % i, 0, pos, cg, read))
+    path = str(tmp_path / name)
+    bamio.write_bam(path, [("c", 30000)], recs, block_size=block_size)
+    return path
+
+
+def _both_raise(path, query=("c", 4000, 5500, 200)):
+    """Both readers refuse the file with an ordinary exception (the native one through vapor_bam_last_error)."""
+    be = seqio.InProcessBam()
+    got = []
+    for fn in (lambda: be._open(path).chop_native(*query), lambda: be.chop_python(path, *query)):
+        try:
+            fn()
+            got.append(None)
+        except (ValueError, IndexError, OSError, struct.error, zlib.error, EOFError) as e:
+            got.append(e)
+    return got
+
+
+def _data_block_index(raw, path):
+    """A block well inside the region the query reads (not the header block, not the EOF marker)."""
+    bl = _blocks(raw)
+    assert len(bl) > 12
+    return bl, 6
+
+
+def test_good_file_is_read_and_its_crcs_hold(tmp_path):
+    path = _small_bam(tmp_path)
+    nat, py = _chop_both(path, [("c", 4000, 5500, 200)])
+    assert nat == py and len(nat[0]) > 3
+    raw = open(path, "rb").read()
+    for off, bsize, xlen in _blocks(raw):
+        data = zlib.decompress(raw[off + 12 + xlen:off + bsize - 8], -15)
+        crc, isize = struct.unpack_from("<II", raw, off + bsize - 8)
+        assert isize == len(data) and crc == zlib.crc32(data) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("field", ["isize_huge", "isize_small", "bsize_tiny", "crc", "payload_bit"])
+def test_damaged_bgzf_block_is_an_exception_not_a_crash(tmp_path, field):
+    path = _small_bam(tmp_path)
+    raw = bytearray(open(path, "rb").read())
+    bl, k = _data_block_index(raw, path)
+    off, bsize, xlen = bl[k]
+    if field == "isize_huge":
+        struct.pack_into("<I", raw, off + bsize - 4, 0xFFFFFFFF)          # reached the inflaters as a buffer size in round 2
+    elif field == "isize_small":
+        struct.pack_into("<I", raw, off + bsize - 4, 17)
+    elif field == "bsize_tiny":
+        struct.pack_into("<H", raw, off + 16, 9)                          # BSIZE below header + trailer
+    elif field == "crc":
+        raw[off + bsize - 8] ^= 0x40
+    else:
+        raw[off + 12 + xlen + (bsize - xlen - 20) // 2] ^= 0x04           # a bit of the DEFLATE payload
+    bad = str(tmp_path / ("bad_%s.bam" % field))
+    open(bad, "wb").write(bytes(raw))
+    shutil.copy(path + ".bai", bad + ".bai")
+    errs = _both_raise(bad)
+    assert all(e is not None for e in errs), (field, errs)
+
+
+@pytest.mark.parametrize("field", ["l_seq_neg", "l_seq_huge", "n_cigar_huge", "block_size_huge", "block_size_small"])
+def test_damaged_bam_record_is_an_exception_not_a_crash(tmp_path, field):
+    """The record fields are inside compressed blocks: rewrite one record of an uncompressed copy and write the file again
+    with valid blocks and CRCs, so that only the record rule is broken."""
+    rng = np.random.default_rng(6)
+    contig = synth.random_dna(rng, 30000)
+    recs = []
+    for i in range(40):
+        pos = 3000 + 10 * i
+        read, cg = synth.mutate(rng, contig[pos:pos + 4000])
+        recs.append(("e%d" % i, 0, pos, cg, read))
+    path = str(tmp_path / "rec.bam")
+    bamio.write_bam(path, [("c", 30000)], recs, block_size=60000)
+    raw = open(path, "rb").read()
+    bl = _blocks(raw)
+    # inflate everything, patch record number 5, deflate again block by block (same block boundaries: offsets of the index hold
+    # as long as every block keeps its compressed size - so the blocks are stored, not deflated, and padded by the extra field)
+    datas = [zlib.decompress(raw[o + 12 + x:o + b - 8], -15) for o, b, x in bl]
+    whole = bytearray(b"".join(datas))
+    # header: magic, l_text, text, n_ref, refs
+    p = 4
+    l_text = struct.unpack_from("<i", whole, p)[0]; p += 4 + l_text
+    n_ref = struct.unpack_from("<i", whole, p)[0]; p += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", whole, p)[0]; p += 4 + l_name + 4
+    for _ in range(5):
+        p += 4 + struct.unpack_from("<i", whole, p)[0]
+    if field == "l_seq_neg":
+        struct.pack_into("<i", whole, p + 4 + 16, -5)
+    elif field == "l_seq_huge":
+        struct.pack_into("<i", whole, p + 4 + 16, 0x7FFFFFF0)
+    elif field == "n_cigar_huge":
+        struct.pack_into("<H", whole, p + 4 + 12, 0xFFFF)
+    elif field == "block_size_huge":
+        struct.pack_into("<i", whole, p, 0x7FFFFFF0)
+    else:
+        struct.pack_into("<i", whole, p, 8)
+    bad = str(tmp_path / ("badrec_%s.bam" % field))
+    with open(bad, "wb") as f:
+        q = 0
+        for d in datas:
+            f.write(bamio._bgzf_block(bytes(whole[q:q + len(d)])))
+            q += len(d)
+    # a fresh index for the rewritten file is not possible with a broken record: query through explicit chunks instead
+    lib = __import__("vapor_amd._lib", fromlist=["x"]).load()
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.vapor_bam_open(bad.encode(), ctypes.byref(h)) == 0
+    first = len(bamio._bgzf_block(datas[0])) if len(datas) > 1 else 0
+    size = os.path.getsize(bad)
+    chunks = np.array([(first << 16) if len(datas) > 1 else 0, size << 16], dtype=np.uint64)
+    seq = np.empty(1 << 20, dtype=np.uint8); names = ctypes.create_string_buffer(1 << 16)
+    meta = np.empty(4 * 256, dtype=np.int64); need = np.zeros(3, dtype=np.int64); n = ctypes.c_int32(0)
+    rc = lib.vapor_bam_chop(h, 0, 3500, 5000, 200, 1, chunks.ctypes.data, seq.ctypes.data, seq.size,
+                            ctypes.cast(names, ctypes.c_void_p), len(names), meta.ctypes.data, 256, ctypes.byref(n), need.ctypes.data)
+    msg = lib.vapor_bam_last_error().decode()
+    lib.vapor_bam_close(h)
+    assert rc == -4 and "vapor_bam_chop" in msg, (field, rc, msg)
+
+
+def test_truncated_file_is_an_exception_not_a_crash(tmp_path):
+    path = _small_bam(tmp_path)
+    raw = open(path, "rb").read()
+    bl = _blocks(raw)
+    cut = bl[7][0] + bl[7][1] // 2                                         # in the middle of a block the query needs
+    bad = str(tmp_path / "trunc.bam")
+    open(bad, "wb").write(raw[:cut])
+    shutil.copy(path + ".bai", bad + ".bai")
+    errs = _both_raise(bad, ("c", 9000, 10500, 200))
+    # the native reader stops at the end of the file like `samtools view` on a file without EOF marker when the cut falls
+    # between records, and raises when it falls inside one; it must never crash, and never return other reads than the
+    # intact file gives for the part that is there
+    be = seqio.InProcessBam()
+    if errs[0] is None:
+        got = be._open(bad).chop_native("c", 9000, 10500, 200)
+        whole = be._open(path).chop_native("c", 9000, 10500, 200)
+        assert all(r in whole for r in got)

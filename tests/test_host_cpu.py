@@ -634,3 +634,29 @@ def test_kept_figure_writes_the_same_bytes_as_a_fresh_one(fake, tmp_path):
         figures.render(a)
         figures.render_fresh(b)
         assert open(a["name"], "rb").read() == open(b["name"], "rb").read(), n
+
+
+
+def test_worker_that_dies_inside_its_reply_is_a_lost_worker():
+    """a worker that ends after the tag byte left a short header (struct.error) or a truncated pickle, which
+    callers stored as the locus' result; it is WorkerLost now (the callers' fallback), the process is dropped, the next task
+    gets a new one, and close() does not wait for ever."""
+    from vapor_amd import hostpool
+    w = hostpool.Workers(1)
+    try:
+        assert w.submit("operator", "add", 2, 3).result(timeout=60) == 5
+        # the worker writes a tag byte and three bytes of the length to its reply stream, then ends
+        with pytest.raises(hostpool.WorkerLost):
+            w.submit("builtins", "exec", "import os\nos.write(1, b'\\x00\\x01\\x02\\x03')\nos._exit(3)").result(timeout=60)
+        # ... a whole header that promises more than comes
+        with pytest.raises(hostpool.WorkerLost):
+            w.submit("builtins", "exec", "import os, struct\nos.write(1, b'\\x00' + struct.pack('<q', 500) + b'abc')\nos._exit(3)").result(timeout=60)
+        # ... and a body that is no pickle
+        with pytest.raises(hostpool.WorkerLost):
+            w.submit("builtins", "exec", "import os, struct\nos.write(1, b'\\x00' + struct.pack('<q', 3) + b'abc')\nos._exit(3)").result(timeout=60)
+        assert w.submit("operator", "mul", 4, 5).result(timeout=60) == 20
+        assert len(w.procs) == 4
+    finally:
+        procs = list(w.procs)
+        w.close()
+    assert all(p.poll() is not None for p in procs)

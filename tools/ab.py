@@ -19,7 +19,7 @@ if "--build" in sys.argv:
     from vapor_amd import build as B
     for spec in sys.argv[sys.argv.index("--build") + 1:]:
         name, _, flags = spec.partition(":")
-        cmd = [B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + B.EXTRA_FLAGS + [
+        cmd = [B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + B.EXTRA_FLAGS + (["-DVAPOR_DEV_BUILD"] if flags else []) + [
                "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vapor_amd", "csrc"),
                "-Wno-unused-function", "-o", so(name)] + [f for f in flags.split(",") if f] + B.SOURCES + ["-lz"]
         subprocess.check_call(cmd)

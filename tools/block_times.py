@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 SO = os.path.join(ROOT, "tools", "libvapor_hip_blocks.so")
 if "--build" in sys.argv:
     from vapor_amd import build as B
-    subprocess.check_call([B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + B.EXTRA_FLAGS + [ "-DVAPOR_BLOCK_TIMING",
+    subprocess.check_call([B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + B.EXTRA_FLAGS + ["-DVAPOR_DEV_BUILD", "-DVAPOR_BLOCK_TIMING",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vapor_amd", "csrc"),
                            "-Wno-unused-function", "-o", SO] + B.SOURCES + ["-lz"])
     print(SO); sys.exit(0)

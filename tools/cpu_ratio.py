@@ -1,8 +1,9 @@
-"""Reference CPU path vs this repository's C port of it, on the same (read, allele) pairs of the cfg2 shape
-(10 kb reads x 20 kb windows).  DEVELOPMENT CONTAINER ONLY: imports the reference from /root/reference (as
-oracle/gen_golden.py does) and, with --cython, a scratch Cython build of it under /tmp (never inside the repository).
-Writes profiles/r02_cpu_ratio.json, which bench.py quotes next to its own C-port timing (the reference cannot travel
-to the GPU box).  usage: python tools/cpu_ratio.py [--cython] [n_reads]"""
+"""Reference CPU path vs this repository's C port of it, on the same (read, allele) pairs of a bench shape
+(cfg2: 10 kb reads x 20 kb windows, DEL/TANDUP; cfg3: 15 kb reads x 20 kb windows, DEL/DEL/TANDUP/INV/INS).
+DEVELOPMENT CONTAINER ONLY: imports the reference from /root/reference (as oracle/gen_golden.py does) and, with
+--cython, a scratch Cython build of it under /tmp (never inside the repository).
+Writes profiles/r03_cpu_ratio_<cfg>.json, which bench.py quotes next to its own C-port timing (the reference cannot
+travel to the GPU box).  usage: python tools/cpu_ratio.py [--cython] [--cfg cfg3] [n_reads]"""
 import json
 import os
 import subprocess
@@ -21,7 +22,9 @@ gen_golden = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(gen_golden)
 
 n_reads = int([a for a in sys.argv[1:] if a.isdigit()][0]) if [a for a in sys.argv[1:] if a.isdigit()] else 6
-w = wl.make_workload("cfg2", seed=1000, **dict(wl.WORKLOADS["cfg2"], n_loci=2))
+CFG = sys.argv[sys.argv.index("--cfg") + 1] if "--cfg" in sys.argv else "cfg2"
+TYPES = wl.WORKLOADS[CFG]["svtypes"]
+w = wl.make_workload(CFG, seed=1000, **dict(wl.WORKLOADS[CFG], n_loci=len(TYPES)))
 orc.build()
 mods = {"python": gen_golden.load_reference()}
 if "--cython" in sys.argv:
@@ -43,28 +46,33 @@ if "--cython" in sys.argv:
 
 # locus 0 is a DEL (abs_dis_m1b + within_10Perc_m1b per read, SF:1718-1726), locus 1 a TANDUP
 # (directed_dis_m1b_redefine_diagnal, SF:1761), as the cfg2 batch scores them
-rpl = wl.WORKLOADS["cfg2"]["reads_per_locus"]
+rpl = wl.WORKLOADS[CFG]["reads_per_locus"]
+n_reads = min(n_reads, rpl)
 loci = []
-for li in range(2):
+for li in range(len(TYPES)):
     base = li * (2 + rpl)
     loci.append((w.svtypes[li], w.seqs[base], w.seqs[base + 1], [[w.seqs[base + 2 + r], 0, "r%d" % r] for r in range(n_reads)]))
-out = {"shape": "cfg2: %d reads of %d bp per locus x ref/alt windows of ~%d bp, k = 10; one DEL locus (abs_dis_m1b + "
-                "within_10Perc_m1b per read) and one TANDUP locus (directed_dis_m1b_redefine_diagnal per read)"
-                % (n_reads, len(loci[0][3][0][0]), len(loci[0][1])), "host": "development container, 1 core"}
+out = {"shape": "%s: %d reads of %d bp per locus x ref/alt windows of ~%d bp, k = 10; one locus per entry of the shape's type "
+                "cycle %s (DEL: abs_dis_m1b + within_10Perc_m1b per read; TANDUP: directed_dis_m1b_redefine_diagnal; INV / INS: "
+                "abs_dis_m1b)" % (CFG, n_reads, len(loci[0][3][0][0]), len(loci[0][1]), "/".join(TYPES)),
+       "host": "development container, 1 core", "reads_per_locus_of_the_shape": rpl}
 res = {}
 for name, m in mods.items():
     r = []
-    per_type = {}
+    per_locus = []
     for t, ref, alt, reads in loci:
         t0 = time.perf_counter()
         if t == "DEL":
             r.append([(m.calcu_vapor_single_read_score_abs_dis_m1b(ref, alt, x, 10), m.calcu_vapor_single_read_score_within_10Perc_m1b(ref, alt, x, 10)) for x in reads])
-        else:
+        elif t == "TANDUP":
             r.append([(m.calcu_vapor_single_read_score_directed_dis_m1b_redefine_diagnal(ref, alt, x, 10),) for x in reads])
-        per_type[t] = (time.perf_counter() - t0) / n_reads
+        else:
+            r.append([(m.calcu_vapor_single_read_score_abs_dis_m1b(ref, alt, x, 10),) for x in reads])
+        per_locus.append((t, (time.perf_counter() - t0) / n_reads))
+        print(name, t, per_locus[-1][1], flush=True)
     res[name] = r
-    out["reference_%s_s_per_read" % name] = per_type
-    mean = sum(per_type.values()) / len(per_type)
+    out["reference_%s_s_per_read" % name] = [[t, v] for t, v in per_locus]
+    mean = sum(v for _t, v in per_locus) / len(per_locus)          # the type cycle weights the types as the shape does
     out["reference_%s_loci_per_s" % name] = 1.0 / (mean * rpl)
 # the port as bench.py times it: one statistics record (fill + C1/C2 clean + counts) per (read, window) pair
 t0 = time.perf_counter()
@@ -72,7 +80,7 @@ for t, ref, alt, reads in loci:
     for x in reads:
         orc.pair_stats(10, x[0], ref)
         orc.pair_stats(10, x[0], alt)
-dt = (time.perf_counter() - t0) / (2 * n_reads)
+dt = (time.perf_counter() - t0) / (len(loci) * n_reads)
 out["port_s_per_read"] = dt
 out["port_loci_per_s"] = 1.0 / (dt * rpl)
 for name in mods:
@@ -82,6 +90,6 @@ if "cython" in res:
 out["note"] = ("reference = /root/reference/vapor_vali/Simple_function.pyx, imported as plain Python and (cython) compiled "
                "unchanged with Cython in a scratch directory; port = oracle/vapor_oracle.c through oracle.pair_stats, "
                "one record per (read, window) pair as in bench.py's cpu_baseline leg, gcc -O2, one thread; both per locus of "
-               "20 reads, mean of the DEL and the TANDUP locus")
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_cpu_ratio.json"), "w"), indent=1)
+               "%d reads, mean over the loci of the type cycle" % rpl)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r03_cpu_ratio_%s.json" % CFG), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -14,7 +14,7 @@ SO = os.path.join(ROOT, "tools", "libvapor_hip_phases.so")
 
 if "--build" in sys.argv:
     from vapor_amd import build as B
-    cmd = [B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + B.EXTRA_FLAGS + [ "-DVAPOR_PHASE_TIMING",
+    cmd = [B.hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + B.EXTRA_FLAGS + ["-DVAPOR_DEV_BUILD", "-DVAPOR_PHASE_TIMING",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "vapor_amd", "csrc"),
            "-Wno-unused-function", "-o", SO] + B.SOURCES + ["-lz"]
     subprocess.check_call(cmd)

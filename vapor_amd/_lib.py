@@ -28,9 +28,11 @@ HF_C1_KEPT, HF_C2_DIAG, HF_C2_ANTI = 1, 2, 4
 SEQ_UPPER = 1
 E_HIP, E_OVERFLOW, E_KEYERROR, E_ARG, E_NOMEM = -1, -2, -3, -4, -5
 MAX_SEQ_LEN = 65535
+ABI_VERSION = 2
+ABI_DEV_OFFSET = 1000000
 
 EXPORTS = [
-    "vapor_abi_version", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
+    "vapor_abi_version", "vapor_build_flags", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
     "vapor_seqset_create", "vapor_seqset_create_ptrs", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_record_counts", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
@@ -81,7 +83,16 @@ def load() -> ctypes.CDLL:
         raise RuntimeError("%s is missing - the HIP extension has not been built "
                            "(run `python -m vapor_amd.build`); there is no CPU fallback" % lib_path)
     _share_torch_hip_runtime()
-    _lib = bind(ctypes.CDLL(lib_path))
+    lib = bind(ctypes.CDLL(lib_path))
+    ver, flags = lib.vapor_abi_version(), lib.vapor_build_flags().decode()
+    dev_ok = bool(os.environ.get("VAPOR_HIP_LIB"))        # developer tools name their library explicitly
+    if ver != ABI_VERSION and not (dev_ok and ver == ABI_VERSION + ABI_DEV_OFFSET):
+        raise RuntimeError("%s reports ABI version %d, build flags %r: this package binds version %d of the product build "
+                           "(a developer build loads only through VAPOR_HIP_LIB); rebuild with `python -m vapor_amd.build --force`"
+                           % (lib_path, ver, flags, ABI_VERSION))
+    if flags and not dev_ok:
+        raise RuntimeError("%s carries developer switches (%s)" % (lib_path, flags))
+    _lib = lib
     return _lib
 
 
@@ -95,6 +106,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     f64p = ctypes.POINTER(ctypes.c_double)
     L.vapor_abi_version.restype = ctypes.c_int
     L.vapor_last_error.restype = ctypes.c_char_p
+    L.vapor_build_flags.restype = ctypes.c_char_p
     L.vapor_init.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.vapor_destroy.argtypes = [vp]
     L.vapor_set_param.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
@@ -129,7 +141,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_plan_set_reads.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, f64p]
     L.vapor_plan_run_loci.argtypes = [vp, vp, f64p, f64p]
     for name in EXPORTS:
-        if name not in ("vapor_last_error", "vapor_bam_last_error"):
+        if name not in ("vapor_last_error", "vapor_bam_last_error", "vapor_build_flags"):
             getattr(L, name).restype = ctypes.c_int
     return L
 

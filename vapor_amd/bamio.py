@@ -66,9 +66,22 @@ class BgzfReader:
             p += 4 + slen
         if bsize is None:
             raise ValueError("BGZF block without BC field")
+        if bsize < xlen + 20:
+            raise ValueError("BGZF block at offset %d is shorter than its own header and trailer" % coff)
         cdata = self.f.read(bsize - 12 - xlen - 8)
-        self.f.read(8)
-        data = zlib.decompress(cdata, -15)
+        trailer = self.f.read(8)
+        if len(trailer) < 8:
+            raise ValueError("truncated BGZF block at offset %d" % coff)
+        crc, isize = struct.unpack("<II", trailer)
+        if isize > 65536:
+            raise ValueError("BGZF block at offset %d claims %d bytes (at most 65536)" % (coff, isize))
+        try:
+            data = zlib.decompress(cdata, -15)
+        except zlib.error as e:
+            raise ValueError("BGZF block at offset %d does not inflate: %s" % (coff, e)) from None
+        # the block's own CRC32 and size, as htslib checks them: a damaged block must not become reads
+        if len(data) != isize or (zlib.crc32(data) & 0xFFFFFFFF) != crc:
+            raise ValueError("BGZF block at offset %d fails its CRC32 / size check" % coff)
         if len(self._cache) > 64:
             self._cache.clear()
         self._cache[coff] = (data, bsize)

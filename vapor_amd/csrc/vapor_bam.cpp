@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,13 +90,17 @@ static int scan_blocks(vapor_bam* b)
             if (e[0] == 66 && e[1] == 67 && slen == 2) bsize = (e[4] | (e[5] << 8)) + 1;
             q += 4 + slen;
         }
-        if (bsize < 0) return -1;
+        // (a block is its 12-byte header, the extra field, the payload, CRC32 and ISIZE: anything shorter is not one, and its
+        // trailer would be read from before the block)
+        if (bsize < 0 || bsize < xlen + 20) return -1;
         if (p + (size_t)bsize > b->comp.size()) break;
         const uint8_t* t = h + bsize - 4;
+        const uint32_t isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > 65536u) return -1;                       // BGZF: at most 64 KB of data per block
         b->blk_coff.push_back(b->comp_base + (int64_t)p);
         b->blk_cpos.push_back((int64_t)p);
         b->blk_csize.push_back(bsize);
-        b->blk_usize.push_back((int32_t)(t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24)));
+        b->blk_usize.push_back((int32_t)isize);
         p += (size_t)bsize;
         ++n;
     }
@@ -102,12 +108,21 @@ static int scan_blocks(vapor_bam* b)
     return n;
 }
 
+// the block's own CRC32 (the four bytes before ISIZE) against the inflated bytes, as htslib checks it: a decoder bug or a
+// damaged block that still inflates to ISIZE bytes must not become reads
+static bool crc_ok(const uint8_t* blk, int bsize, const uint8_t* out, int isize)
+{
+    const uint8_t* t = blk + bsize - 8;
+    const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)isize) == want;
+}
+
 static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize, vapor_inflate::Decoder& dec)
 {
-    if (isize == 0) return true;
     const int xlen = blk[10] | (blk[11] << 8);
-    if (bsize - xlen - 20 < 0) return false;
-    if (vapor_inflate::inflate_raw(blk + 12 + xlen, (size_t)(bsize - xlen - 20), out, (size_t)isize, dec)) return true;
+    if (bsize - xlen - 20 < 0 || isize < 0 || isize > 65536) return false;
+    if (isize == 0) return crc_ok(blk, bsize, out, 0);
+    if (vapor_inflate::inflate_raw(blk + 12 + xlen, (size_t)(bsize - xlen - 20), out, (size_t)isize, dec)) return crc_ok(blk, bsize, out, isize);
     // refused: zlib has the last word on whether the block is damaged
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -118,7 +133,7 @@ static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize
     zs.avail_out = (uInt)isize;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
-    return rc == Z_STREAM_END && zs.avail_out == 0;
+    return rc == Z_STREAM_END && zs.avail_out == 0 && crc_ok(blk, bsize, out, isize);
 }
 
 extern "C" int vapor_inflate_raw(const uint8_t* in, int64_t in_n, uint8_t* out, int64_t out_n)
@@ -177,14 +192,16 @@ static bool read_more(vapor_bam* b, size_t bytes)
 
 // makes sure `data` holds at least `upto` inflated bytes (a record may run past the chunk's own blocks); false at the end
 // of the file or on bytes that are not BGZF
+static thread_local bool g_bam_damaged = false;          // ensure() failed on damaged bytes, not at the end of the file
 static bool ensure(vapor_bam* b, int64_t upto)
 {
+    g_bam_damaged = false;
     while ((int64_t)b->data.size() < upto) {
         if (!read_more(b, (size_t)1 << 18)) return false;
         const size_t b0 = b->blk_coff.size();
-        if (scan_blocks(b) < 0) return false;
+        if (scan_blocks(b) < 0) { g_bam_damaged = true; return false; }
         if (b->blk_coff.size() == b0) continue;              // not even one whole block yet: read on
-        if (!take_blocks(b, b0)) return false;
+        if (!take_blocks(b, b0)) { g_bam_damaged = true; return false; }
     }
     return true;
 }
@@ -202,29 +219,36 @@ static const uint8_t* find_cg(const uint8_t* p, const uint8_t* end, int32_t* cou
         case 'A': case 'c': case 'C': sz = 1; break;
         case 's': case 'S': sz = 2; break;
         case 'i': case 'I': case 'f': sz = 4; break;
-        case 'Z': case 'H': { while (p < end && *p) ++p; ++p; continue; }
+        case 'Z': case 'H': { while (p < end && *p) ++p; if (p >= end) return nullptr; ++p; continue; }
         case 'B': {
             if (p + 5 > end) return nullptr;
             const uint8_t sub = p[0];
             const int32_t cnt = rd32(p + 1);
             p += 5;
             const int es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            // (the array must lie inside the record)
+            if (cnt < 0 || (int64_t)cnt * es > (int64_t)(end - p)) return nullptr;
             if (t0 == 'C' && t1 == 'G' && sub == 'I') { *count = cnt; return p; }
             p += (size_t)cnt * (size_t)es;
             continue;
         }
         default: return nullptr;
         }
+        if (sz > end - p) return nullptr;
         p += sz;
     }
     return nullptr;
 }
 
-extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t end, int64_t flank, int32_t n_chunks,
-                              const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
-                              int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need)
+// Every size field of the file is checked before it is used (a damaged ISIZE reached the inflaters as a
+// buffer size); a file that breaks a rule is VAPOR_E_ARG with a message, never a read or write outside `comp` / `data`.
+static int bam_chop_impl(vapor_bam* b, int32_t tid, int64_t start, int64_t end, int64_t flank, int32_t n_chunks,
+                         const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
+                         int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need)
 {
     if (!b || !n_reads || (n_chunks && !chunks)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: null argument");
+    if (seq_cap < 0 || names_cap < 0 || max_reads < 0 || (max_reads && (!meta || !seq_out || !names_out)))
+        return bfail(VAPOR_E_ARG, "vapor_bam_chop: bad output buffers");
     static const char* NT16 = "=ACMGRSVTWYHKDBN";
     const int64_t beg = std::max<int64_t>(start - 1, 0), stop = end;     // 0-based half-open region
     int64_t seq_used = 0, names_used = 0;
@@ -236,6 +260,9 @@ extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t 
         b->comp.clear(); b->data.clear(); b->scan_pos = 0;
         b->blk_coff.clear(); b->blk_cpos.clear(); b->blk_csize.clear(); b->blk_ustart.clear(); b->blk_usize.clear();
         b->comp_base = (int64_t)(cs >> 16);
+        // (index chunks come from a file as well: an end before the start, or gigabytes for one locus, is a damaged .bai)
+        if (ce < cs || (ce >> 16) - (cs >> 16) > ((uint64_t)1 << 31))
+            return bfail(VAPOR_E_ARG, "vapor_bam_chop: implausible index chunk for " + b->path);
         // through the block that holds the chunk's end (none of it when the chunk ends on a block boundary)
         const size_t span = (size_t)((int64_t)(ce >> 16) - b->comp_base) + ((ce & 0xFFFFu) ? ((size_t)1 << 16) + 64 : 0);
         if (span == 0 || !read_more(b, span)) continue;
@@ -256,15 +283,24 @@ extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t 
                 voff = ((uint64_t)b->blk_coff[blk] << 16) | (uint64_t)(pos_u - b->blk_ustart[blk]);
             }
             if (voff >= ce) break;
-            if (!ensure(b, pos_u + 4)) break;
+            if (!ensure(b, pos_u + 4)) {
+                // the end of the file inside a chunk is the end of its records; bytes that are not BGZF, or a block that
+                // does not inflate to its CRC, are an error
+                if (!g_bam_damaged) break;
+                return bfail(VAPOR_E_ARG, "vapor_bam_chop: damaged BGZF block in " + b->path);
+            }
             const int32_t bs = rd32(b->data.data() + pos_u);
-            if (bs < 32 || !ensure(b, pos_u + 4 + bs)) break;
+            if (bs < 32 || bs > (1 << 29)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: implausible record size in " + b->path);
+            if (!ensure(b, pos_u + 4 + bs)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: truncated record (or damaged block) in " + b->path);
             const uint8_t* r = b->data.data() + pos_u + 4;
             pos_u += 4 + bs;
             const int32_t ref_id = rd32(r), pos = rd32(r + 4);
             const int l_name = r[8];
             const int n_cig = r[12] | (r[13] << 8);
             const int32_t l_seq = rd32(r + 16);
+            // name, CIGAR, packed bases and qualities must lie inside the record
+            if (l_seq < 0 || 32 + (int64_t)l_name + 4 * (int64_t)n_cig + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq > (int64_t)bs)
+                return bfail(VAPOR_E_ARG, "vapor_bam_chop: record fields exceed the record in " + b->path);
             if (ref_id != tid || pos >= stop) {
                 if (ref_id > tid || (ref_id == tid && pos >= stop)) break;
                 continue;
@@ -339,4 +375,18 @@ extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t 
     if (need) { need[0] = seq_used; need[1] = names_used; need[2] = nr; }
     if (overflow) return bfail(VAPOR_E_OVERFLOW, "vapor_bam_chop: output buffers too small");
     return VAPOR_OK;
+}
+
+extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t end, int64_t flank, int32_t n_chunks,
+                              const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
+                              int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need)
+{
+    // no exception crosses the C boundary (a std::bad_alloc / length_error from a buffer resize would end the process)
+    try {
+        return bam_chop_impl(b, tid, start, end, flank, n_chunks, chunks, seq_out, seq_cap, names_out, names_cap, meta, max_reads, n_reads, need);
+    } catch (const std::bad_alloc&) {
+        return bfail(VAPOR_E_NOMEM, "vapor_bam_chop: out of memory");
+    } catch (const std::exception& e) {
+        return bfail(VAPOR_E_ARG, std::string("vapor_bam_chop: ") + e.what());
+    }
 }

@@ -214,25 +214,33 @@ struct vapor_plan {
 };
 
 // ------------------------------------------------------------------------------------------
+// A developer build (-DVAPOR_DEV_BUILD: timing stamps, tools/ab.py variants, non-default tuning constants) says so in
+// both: the product loader accepts VAPOR_ABI_VERSION only, and vapor_build_flags() lists what the build carries.
+#ifdef VAPOR_DEV_BUILD
+extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION + VAPOR_ABI_DEV_OFFSET; }
+#define VP_STR2(x) #x
+#define VP_STR(x) VP_STR2(x)
+extern "C" const char* vapor_build_flags(void)
+{
+    return "dev"
+#ifdef VAPOR_PHASE_TIMING
+           ",phase_timing"
+#endif
+#ifdef VAPOR_BLOCK_TIMING
+           ",block_timing"
+#endif
+#ifdef VAPOR_AB
+           ",ab=" VP_STR(VAPOR_AB)
+#endif
+           ",jq_fast_slack=" VP_STR(VAPOR_JQ_FAST_SLACK) ",clean_threads=" VP_STR(VAPOR_CLEAN_THREADS) ",build_cost_x8=" VP_STR(VAPOR_BUILD_COST_X8);
+}
+#else
 extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION; }
+extern "C" const char* vapor_build_flags(void) { return ""; }
+#endif
 extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 
-#ifdef VAPOR_AB_DYN_LDS
-#define JOIN_DYN_LDS(BPS) (join_lds_bytes<JoinCfg, BPS>())
-#else
 #define JOIN_DYN_LDS(BPS) 0            // the join's LDS is a static array of the kernel
-#endif
-
-template <int BPS, int K>
-static hipError_t set_join_attr()
-{
-    if constexpr (BPS == 2) (void)&join_kernel<JoinCfg, BPS, K, true>;
-#ifndef VAPOR_AB_DYN_LDS
-    return hipSuccess;
-#endif
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&join_kernel<JoinCfg, BPS, K, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)join_lds_bytes<JoinCfg, BPS>());
-}
 
 extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
 {
@@ -253,10 +261,6 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VAPOR_E_HIP, hipGetErrorString(e)); }
-    hipError_t a[8] = {set_join_attr<2, 10>(), set_join_attr<2, 20>(), set_join_attr<2, 30>(), set_join_attr<2, 40>(),
-                       set_join_attr<4, 10>(), set_join_attr<4, 20>(), set_join_attr<4, 30>(), set_join_attr<4, 40>()};
-    for (hipError_t x : a)
-        if (x != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(VAPOR_E_HIP, std::string("hipFuncSetAttribute(join): ") + hipGetErrorString(x)); }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&clean_kernel<CLEAN_PER_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);

@@ -19,6 +19,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Developer switches (phase / workgroup timing builds, tools/ab.py variants, non-default tuning constants) exist only in
+// a build made with -DVAPOR_DEV_BUILD, which reports itself through vapor_build_flags() and a different
+// vapor_abi_version(): the product loader (vapor_amd/_lib.py) refuses such a library.  A stray -D of one of them without
+// the guard does not compile.
+#if !defined(VAPOR_DEV_BUILD) && (defined(VAPOR_PHASE_TIMING) || defined(VAPOR_BLOCK_TIMING) || defined(VAPOR_JQ_FAST_SLACK) || \
+                                  defined(VAPOR_CLEAN_THREADS) || defined(VAPOR_BUILD_COST_X8) || defined(VAPOR_AB))
+#error "developer switch without -DVAPOR_DEV_BUILD: a product library cannot be an experimental one"
+#endif
+
 namespace vapor {
 
 // ------------------------------------------------------------------------------------------
@@ -260,13 +269,8 @@ constexpr int JCHUNK = 1024;                      // read positions per wave pas
 // in 32768 buckets).  Smaller tables would not raise residency: at ~117 VGPRs four waves per SIMD is the
 // register limit as well.
 struct JoinBig { static constexpr int THREADS = 1024, WPS = 4, TA2 = 24576, TA4 = 16384, NB_LOG2 = 15, FILT_LOG2 = 17, QCAP = 256; };
-// Experiment geometry (tools/ab.py -DVAPOR_JOIN_CFG=JoinHalf): two workgroups per CU, six waves per SIMD, half a
-// table each - a 20 kb allele then takes two tiles and every read is probed twice.
-struct JoinHalf { static constexpr int THREADS = 768, WPS = 6, TA2 = 10240, TA4 = 8192, NB_LOG2 = 14, FILT_LOG2 = 16, QCAP = 224; };
-#ifndef VAPOR_JOIN_CFG
-#define VAPOR_JOIN_CFG JoinBig
-#endif
-using JoinCfg = VAPOR_JOIN_CFG;
+// (two workgroups per CU with half a table each were tried and lost: DESIGN.md section 4)
+using JoinCfg = JoinBig;
 
 template <typename C, int BPS> __host__ __device__ constexpr int tile_pos() { return BPS == 2 ? C::TA2 : C::TA4; }
 template <typename C, int BPS> __host__ __device__ constexpr int tile_words() { return ((tile_pos<C, BPS>() + 64) * BPS) / 32 + 8; }
@@ -460,9 +464,6 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     constexpr bool merge = MERGE != 0;
     using KT = KeyT<BPS, K>;
     const int lane = threadIdx.x & 63;
-#ifdef VAPOR_ABL_NOVERIFY
-    return;
-#endif
     // Both candidates of a lane go through the same straight-line code (a lane without a second candidate
     // re-reads item 0 and masks the result): with a branch per candidate the LDS reads of the second would only
     // start when the first is done.
@@ -727,13 +728,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     constexpr int JQCAP = C::QCAP;
     constexpr int JOIN_THREADS = C::THREADS, JOIN_WAVES = C::THREADS / 64;
     constexpr int JNB_LOG2 = C::NB_LOG2, JNB = 1 << C::NB_LOG2;
-#ifdef VAPOR_AB_DYN_LDS
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-#else
     // statically sized: the compiler then knows every table's LDS address and folds it into the offset field of
     // the ds_ instructions instead of adding a base per access
     __shared__ __attribute__((aligned(16))) uint32_t lds[join_lds_bytes<C, BPS>() / sizeof(uint32_t) + 1];
-#endif
     // (filter first: both tables of the position loop then lie within the 64 KB an LDS instruction's offset field
     // reaches and are addressed without adding a base.  Moving the tile, the strips and the queues below 64 KB as well
     // gains nothing: their reads are ds_read2_b32, whose offsets reach 1 KB)
@@ -1009,19 +1006,11 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             // (bitwise, not `&&`: with a short-circuit the compiler sinks the filter read into the branch on
                             // `valid` and waits for it there, one LDS round trip per position instead of one per four)
                             const uint32_t s0 = start16[h], s1v = start16[h + 1], fw = filt[fb >> 5];
-#ifdef VAPOR_AB_OLDTAKE
-                            const uint32_t take = (vmask >> t) & (fw >> (fb & 31u)) & 1u;
-                            sc[t4] = (s0 | ((s1v - s0) << 16)) & (0u - take);
-#else
                             // (bit 0 spread over the word by one v_bfe_i32; written as `0 - (x & 1)` the compiler turns
                             // it into and + compare + select, two of which cannot share an issue slot; the same happens to the builtin)
                             uint32_t take;
                             asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(take) : "v"((vm4 >> t4) & (fw >> (fb & 31u))));
                             sc[t4] = (s0 | ((s1v - s0) << 16)) & take;
-#endif
-#ifdef VAPOR_ABL_NOCAND
-                            sc[t4] &= 0xFFFFu;
-#endif
                         }
                         pc.mark(2, pw);                    // keys + bucket bounds issued
                         // ---- four wave prefix sums of the bucket sizes, interleaved -------------------------
@@ -1101,11 +1090,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                 const uint32_t pos = (uint32_t)qlen + incl[x] - c;
                                 const uint32_t item = (il << 16) | s0;
                                 const uint32_t full = qbase + pos * 4u;
-#ifdef VAPOR_AB_OLDFILL
-                                ((lds_u32_t*)(uintptr_t)(c > 0u ? full : qbase + (uint32_t)JQCAP * 4u))[0] = item;
-                                ((lds_u32_t*)(uintptr_t)(c > 1u ? full : qbase + (uint32_t)(JQCAP - 1) * 4u))[1] = item + 1u;
-                                ((lds_u32_t*)(uintptr_t)(c > 2u ? full : qbase + (uint32_t)(JQCAP - 2) * 4u))[2] = item + 2u;
-#else
                                 // One select for the three stores: a lane without a candidate writes the three dump slots, a lane
                                 // with one or two writes its surplus onto the slots of the lanes after it - whose own stores of a
                                 // LOWER index come later in program order (the wave's LDS instructions execute in order), so the
@@ -1114,7 +1098,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                 qp[2] = item + 2u;
                                 qp[1] = item + 1u;
                                 qp[0] = item;
-#endif
                                 for (uint32_t u = 3; __ballot(c > u); ++u)
                                     if (c > u) myq[pos + u] = item + u;
                             }
@@ -1626,19 +1609,13 @@ __device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots
         cluster_axis<true, NARROW, false, false, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
         cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     } else if (c1) {
-#ifndef VAPOR_ABL_NOAXIS1
         cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
-#endif
-#ifndef VAPOR_ABL_NOAXIS2
         cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
-#endif
     } else if (c2) {
         cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
         cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
     }
-#ifndef VAPOR_ABL_NODIR
     if (s3) directed_stats<NARROW>(recs, hflags, n, gcnt, sh, pc);
-#endif
     if (tid == 0) {
         st[0] = n_dots; st[1] = sh->min_j; st[2] = sh->max_j; st[3] = sh->c1_kept; st[4] = (long long)sh->c1_sum_abs;
         st[5] = sh->c2_kept; st[6] = sh->c2_count10; st[7] = sh->n_diag; st[8] = sh->n_lower; st[9] = sh->c2_kept_diag;

@@ -66,11 +66,33 @@ class Workers:
             raise WorkerLost("host worker: %s" % e) from e
         if tag not in (b"\x00", b"\x01"):
             raise WorkerLost("host worker ended (exit code %s)" % p.poll())
-        n = struct.unpack("<q", p.stdout.read(8))[0]
-        body = pickle.loads(p.stdout.read(n))
+        # a worker that dies after the tag leaves a short header or body, or an envelope that does not unpickle: that is a
+        # lost worker as well (the caller falls back to doing the work itself), and the process is not used again
+        try:
+            hdr = p.stdout.read(8)
+            if len(hdr) != 8:
+                raise EOFError("short header")
+            n = struct.unpack("<q", hdr)[0]
+            if n < 0 or n > (1 << 34):
+                raise EOFError("implausible length %d" % n)
+            raw = p.stdout.read(n)
+            if len(raw) != n:
+                raise EOFError("short body")
+            body = pickle.loads(raw)
+        except (OSError, EOFError, pickle.UnpicklingError, AttributeError, ImportError, IndexError, struct.error) as e:
+            self._drop(p)
+            raise WorkerLost("host worker answered with a damaged envelope: %s" % e) from e
         if tag == b"\x00":
             return body
         raise body if isinstance(body, BaseException) else RuntimeError("host worker: %s" % (body,))
+
+    def _drop(self, p) -> None:
+        """Ends a process whose stream can no longer be trusted; the thread starts a new one on its next task."""
+        self.tls.p = None
+        try:
+            p.kill()
+        except OSError:
+            pass
 
     def submit(self, module: str, function: str, *args) -> Future:
         return self.pool.submit(self._task, pickle.dumps((module, function, args), protocol=4))
@@ -84,8 +106,16 @@ class Workers:
                 p.stdin.close()
             except OSError:
                 pass
+        # (called from an atexit handler: a worker that does not end on a closed stdin must not hang the interpreter's exit)
         for p in procs:
-            p.wait()
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    pass
 
 
 def get() -> Optional[Workers]:
