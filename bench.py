@@ -434,11 +434,13 @@ def sub_record(eng, wl, name, torch, passes: int = 12, cpu_seconds: float = 0.0)
 
 def host_cores() -> dict:
     """The box's core count and the share of it this process may use (north_star: 'core count stated')."""
+    from vapor_amd import pipeline
     try:
-        usable = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        usable = os.cpu_count()
-    return {"logical": os.cpu_count(), "usable_by_this_process": usable}
+        affinity = os.cpu_count()
+    # (the affinity mask cut to the container's CPU quota: what the box really gives this job)
+    return {"logical": os.cpu_count(), "affinity": affinity, "usable_by_this_process": pipeline._usable_cores()}
 
 
 def cpu_baseline(w, st, n_pairs, seconds, ratio_file="r03_cpu_ratio_cfg2.json"):

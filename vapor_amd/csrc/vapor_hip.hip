@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -594,7 +595,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         if (s1.len - a.k + 1 > 0 && s2.len - a.k + 1 > 0) order.push_back((int32_t)i);
     }
     p->range_words_cap = rw;
-    p->hcap_want = (int)std::min<int64_t>(hwant, 16384);
+    p->hcap_want = (int)std::min<int64_t>(hwant, CLEAN_HCAP_MAX);
     // Sort by (mode, k, allele): one launch per (mode, k); inside a launch the sorted pair list is
     // cut into contiguous, cost-balanced ranges (tasks).  A workgroup rebuilds its allele hash table
     // only where the allele changes inside its range.
@@ -752,23 +753,43 @@ static int clean_groups_lds(int rw, int hcap)
     return 2 * std::max((g + 1) / 2, rw * 32 / 100 + 8);
 }
 
-static size_t clean_lds_bytes(int rw, int hcap)
+// clean_pair's layout: bitmap and ranks of one axis, or of both (`dual`: cluster_dual works on the two axes of C1 at
+// once), one region of 16-bit group counters, then the staged records, 8 bytes each with their flag byte inside
+static size_t clean_lds_bytes(int rw, int hcap, bool dual)
 {
-    return sizeof(uint32_t) * ((size_t)rw + ((size_t)rw + 1) / 2 + (size_t)clean_groups_lds(rw, hcap) / 2) + 64 + (size_t)hcap * 9 + 8;
+    const size_t bw = (size_t)rw + ((size_t)rw + 1) / 2;
+    const size_t rec_word = ((dual ? 2 : 1) * bw + ((size_t)clean_groups_lds(rw, hcap) + 1) / 2 + 1) & ~(size_t)1;
+    return sizeof(uint32_t) * rec_word + 64 + (size_t)hcap * 8 + 8;
 }
 
 // The kernel waits for memory and barriers more than it computes, so residency matters: take the largest number
 // of workgroups per CU (32 waves at most) whose share of the 160 KB still stages ~90 % of the expected records.
-static int clean_hcap(int range_words_cap, int want)
+struct CleanGeom { int hcap, per_cu; bool dual; };
+static CleanGeom clean_geom_for(int range_words_cap, int want, bool dual)
 {
-    int best = 0;
+    CleanGeom g{0, 1, dual};
+#ifdef VAPOR_DEV_BUILD
+    if (const char* e = getenv("VAPOR_DEV_HCAP")) { g.hcap = atoi(e) & ~3; return g; }      // experiment: records staged per pair
+#endif
     for (int per_cu = 2048 / CLEAN_THREADS; per_cu >= 1; --per_cu) {
         const size_t share = (size_t)(160 * 1024) / per_cu - 512;
-        int cap = std::min(want, 65532) & ~3;
-        while (cap > 0 && clean_lds_bytes(range_words_cap, cap) + 512 > share) cap -= 4;
-        if (cap >= want * 9 / 10 || per_cu == 1) { best = cap; break; }
+        int cap = std::min(want, CLEAN_HCAP_MAX) & ~3;
+        while (cap > 0 && clean_lds_bytes(range_words_cap, cap, dual) + 512 > share) cap -= 4;
+        if (cap >= want * 9 / 10 || per_cu == 1) { g.hcap = std::max(cap, 0); g.per_cu = per_cu; break; }
     }
-    return std::max(best, 0);
+    return g;
+}
+// Both axes of C1 in one sweep (cluster_dual) need a second bitmap and rank array per workgroup.  Measured (tools/clean_sweep.py,
+// profiles/r03_clean_variants.txt): the sweep wins where the extra LDS costs no residency (30 kb x 40 kb pairs, two workgroups
+// per CU either way: clean 1.87 -> 1.70 ms) and loses where it does (10 kb x 20 kb: 7 -> 6 per CU, 0.075 vs 0.078 ms; 15 kb x
+// 20 kb: 5 -> 4, 1.32 vs 1.42 ms) - so it is used exactly when it is free.
+static CleanGeom clean_geom(int range_words_cap, int want)
+{
+    const CleanGeom seq = clean_geom_for(range_words_cap, want, false), dual = clean_geom_for(range_words_cap, want, true);
+#ifdef VAPOR_DEV_BUILD
+    if (const char* e = getenv("VAPOR_DEV_CLEAN_DUAL")) return atoi(e) ? dual : seq;
+#endif
+    return dual.per_cu >= seq.per_cu ? dual : seq;      // (either stages at least nine tenths of the expected records)
 }
 
 static int async_fold(vapor_plan* p);
@@ -803,12 +824,16 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
     // (the clean kernels overwrite the statistics the previous step's finish kernel reads on its own stream)
     if (before_clean) HIPCHK(hipStreamWaitEvent(st, before_clean, 0));
     if (p->n_pairs > 0) {
-        int hcap = clean_hcap(p->range_words_cap, p->hcap_want);
-        size_t lds = clean_lds_bytes(p->range_words_cap, hcap);
+        const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
+        const int hcap = cg.hcap;
+        size_t lds = clean_lds_bytes(p->range_words_cap, hcap, cg.dual);
+#ifdef VAPOR_DEV_BUILD
+        if (const char* e = getenv("VAPOR_DEV_CLEAN_PAD")) lds += (size_t)atoi(e);   // experiment: fewer workgroups per CU
+#endif
         launch_clean(p->range_words_cap, (unsigned)p->n_pairs, lds, st,
                      (const DPair*)p->d_pairs, (const int32_t*)nullptr, (const unsigned long long*)p->d_nhits,
                      (const unsigned long long*)p->d_hits, p->d_hflags, p->d_stats, p->range_words_cap,
-                     clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1);
+                     clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1, cg.dual ? 1 : 0);
         HIPCHK(hipGetLastError());
         // (clean_big_kernel needs a CU with free LDS like any other clean workgroup: behind another plan's join it sits
         // on the stream until that join is over even with nothing to do, and holds back the finish kernel and the
@@ -1074,10 +1099,11 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         chk(hipMemcpyAsync(d_hits, packed.data(), sizeof(unsigned long long) * packed.size(), hipMemcpyHostToDevice, st), "copy");
     }
     if (rc == VAPOR_OK) {
-        int hcap = clean_hcap(rw, 4096);
-        launch_clean(rw, (unsigned)n_lists, clean_lds_bytes(rw, hcap), st, (const DPair*)d_dp, (const int32_t*)nullptr,
+        const CleanGeom cg = clean_geom(rw, 4096);
+        const int hcap = cg.hcap;
+        launch_clean(rw, (unsigned)n_lists, clean_lds_bytes(rw, hcap, cg.dual), st, (const DPair*)d_dp, (const int32_t*)nullptr,
                      (const unsigned long long*)d_nh, (const unsigned long long*)d_hits, d_fl, d_st, rw,
-                     clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1);
+                     clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1, cg.dual ? 1 : 0);
         chk(hipGetLastError(), "clean launch");
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);

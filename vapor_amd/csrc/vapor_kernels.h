@@ -1195,12 +1195,117 @@ struct RecV {
     int i0, j0, len;
     bool rc;
 };
+// clean_kernel works on a private LDS copy of a pair's records whose upper word is laid out for it (LFMT):
+//   bits 32..36 len - 1   bit 37 strand   bits 38..50 / 51..63 the record's group on the i - j / i + j axis (filled by the
+// group-size pass, read by the flag pass: a pair staged in LDS has at most CLEAN_HCAP_MAX = 8192 records and every group
+// holds at least one, so 13 bits do); a single-axis pass uses bits 38.. for its one group.  The lower word is i0 | j0 << 16
+// in both formats.
+constexpr int CLEAN_HCAP_MAX = 8192;
+template <bool LFMT>
 __device__ __forceinline__ RecV rec_decode(unsigned long long r)
 {
     RecV v;
-    v.i0 = VREC_I(r); v.j0 = VREC_J(r); v.len = VREC_LEN(r); v.rc = VREC_RC(r);
+    v.i0 = VREC_I(r); v.j0 = VREC_J(r);
+    if (LFMT) { v.len = (int)((r >> 32) & 31ull) + 1; v.rc = (bool)((r >> 37) & 1ull); }
+    else { v.len = VREC_LEN(r); v.rc = VREC_RC(r); }
     return v;
 }
+__device__ __forceinline__ unsigned long long rec_to_lds(unsigned long long r)
+{
+    return (r & 0xFFFFFFFFull) | ((unsigned long long)((uint32_t)(VREC_LEN(r) - 1) | ((uint32_t)VREC_RC(r) << 5)) << 32);
+}
+// The flag byte of record h.  Global path (clean_big_kernel): a byte beside the record.  LDS path: bits 38..45 of the
+// staged record itself (no flag array: a byte per record less in LDS, and one read gives record and flags), the group
+// number of a single-axis pass above it (bits 46..); cluster_dual parks its two group numbers in bits 38..63 while the
+// flags are still all zero and its flag pass overwrites them.
+struct GFlags {
+    uint8_t* p;
+    __device__ __forceinline__ uint32_t of(int h, unsigned long long) const { return p[h]; }
+    __device__ __forceinline__ void set(int h, unsigned long long, uint32_t f) const { p[h] = (uint8_t)f; }
+};
+struct LFlags {
+    unsigned long long* r;
+    __device__ __forceinline__ uint32_t of(int, unsigned long long raw) const { return (uint32_t)(raw >> 38) & 0xFFu; }
+    __device__ __forceinline__ void set(int h, unsigned long long raw, uint32_t f) const
+    {
+        reinterpret_cast<uint32_t*>(r)[2 * h + 1] = ((uint32_t)(raw >> 32) & 63u) | ((f & 0xFFu) << 6);
+    }
+};
+
+// Group starts of an occupancy bitmap, for the consecutive words [w0, w1) of one thread: a value starts a group when it is
+// occupied and none of the 9 values below it is.  "Occupied among the 9 below" = OR of the bitmap shifted up by 1..9 with
+// the previous word's top bits coming in; by doubling - x | x<<1 covers shifts {0,1}, | <<2 {0..3}, | <<4 {0..7}; then
+// (that << 1) covers {1..8} and (the first << 8) {8,9} - it is nine funnel operations per word instead of eighteen, the
+// previous word's partial results being those the thread has just computed (their low bits differ from the carried-in
+// truth, their top bits - all a funnel shift takes - do not).
+template <int PER_MAX>
+__device__ __forceinline__ uint32_t group_starts(const uint32_t* bm, int w0, int w1, uint32_t (&st)[PER_MAX])
+{
+    uint32_t p = w0 ? bm[w0 - 1] : 0u;
+    uint32_t a1p = p | (p << 1), a2p = a1p | (a1p << 2), a3p = a2p | (a2p << 4);
+    uint32_t n = 0;
+#pragma unroll
+    for (int q = 0; q < PER_MAX; ++q) {
+        const int w = w0 + q;
+        uint32_t s = 0;
+        if (w < w1) {
+            const uint32_t cur = bm[w];
+            const uint32_t a1 = cur | __builtin_amdgcn_alignbit(cur, p, 31);
+            const uint32_t a2 = a1 | __builtin_amdgcn_alignbit(a1, a1p, 30);
+            const uint32_t a3 = a2 | __builtin_amdgcn_alignbit(a2, a2p, 28);
+            const uint32_t below = __builtin_amdgcn_alignbit(a3, a3p, 31) | __builtin_amdgcn_alignbit(a1, a1p, 24);
+            s = cur & ~below;
+            p = cur; a1p = a1; a2p = a2; a3p = a3;
+        }
+        st[q] = s;
+        n += __popc(s);
+    }
+    return n;
+}
+
+// the reductions over a pair's finished flags (kept counts, sum |j-i|, count10, range of i-j over the C1-kept dots), done by
+// the flag pass of the pair's last clustering step; returns the public VAPOR_HF_* bits of the record
+struct FinalAcc {
+    int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
+    long long sabs = 0;
+    __device__ __forceinline__ uint32_t add(uint32_t f, const RecV& r)
+    {
+        uint32_t pub = f & (HF_C2D | HF_C2A);
+        const bool c1k = (f & (WF_D1 | WF_A1)) != 0u, c2k = pub != 0u;
+        if (c1k) pub |= HF_C1;
+        const int d0 = r.i0 - r.j0;
+        if (!r.rc) {
+            // i - j is the same for all dots of the record
+            const int ad = d0 < 0 ? -d0 : d0;
+            if (c1k) { k1 += r.len; sabs += (long long)r.len * ad; dlo = min(dlo, d0); dhi = max(dhi, d0); }
+            if (c2k) {
+                // dots with j > 0 and 25*|j-i| < 4*j, j = j0 .. j0+len-1:  j >= floor(25*ad/4) + 1
+                const int jmin = max(1, (25 * ad) / 4 + 1);
+                k2 += r.len;
+                c10 += max(0, r.j0 + r.len - max(r.j0, jmin));
+            }
+        } else if (c1k || c2k) {
+            for (int t = 0; t < r.len; ++t) {
+                const int j = r.j0 - t, i = r.i0 + t, ad = j > i ? j - i : i - j;
+                if (c1k) { ++k1; sabs += ad; }
+                if (c2k) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
+            }
+            if (c1k) { dlo = min(dlo, d0); dhi = max(dhi, d0 + 2 * (r.len - 1)); }
+        }
+        kd += (f & HF_C2D) ? r.len : 0;
+        return pub;
+    }
+    __device__ __forceinline__ void commit(CleanShared* sh)
+    {
+        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
+        sabs = wave_sum_i64(sabs); dlo = wave_min_i32(dlo); dhi = wave_max_i32(dhi);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&sh->c1_kept, k1); atomicAdd(&sh->c2_kept, k2); atomicAdd(&sh->c2_count10, c10);
+            atomicAdd(&sh->c2_kept_diag, kd); atomicAdd(&sh->c1_sum_abs, (unsigned long long)sabs);
+            atomicMin(&sh->kd_lo, dlo); atomicMax(&sh->kd_hi, dhi);
+        }
+    }
+};
 
 // marks the values v0, v0 + 2, ... (len of them; a single value when !strided) in an occupancy bitmap.
 // Most values are marked already: look before the atomic (a stale look only costs a redundant atomic).
@@ -1255,8 +1360,9 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
         __syncthreads();
         // 1. occupancy bitmap
         for (int h = tid; h < n; h += CLEAN_THREADS) {
-            if (need_clear && (hflags[h] & need_clear)) continue;
-            const RecV r = rec_decode(recs[h]);
+            const unsigned long long raw = recs[h];
+            if (need_clear && (hflags.of(h, raw) & need_clear)) continue;
+            const RecV r = rec_decode<NARROW>(raw);
             mark_values(bm, (uint32_t)first_value(r), r.len, AXIS_A ? !r.rc : r.rc);
         }
     }
@@ -1265,26 +1371,10 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
     // 2. group starts and their ranks
     const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
     const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
-    uint32_t local = 0;
     // (PER_MAX: bitmap words per thread the kernel was instantiated for - 4, 8 or 16; the host picks the smallest that
     // covers the batch's value range, so that a 30 kb range does not walk twelve empty predicated iterations)
     uint32_t stv[PER_MAX];
-#pragma unroll
-    for (int q = 0; q < PER_MAX; ++q) {
-        const int w = w0 + q;
-        uint32_t st = 0;
-        if (w < w1) {
-            // occupied, and none of the 9 values below occupied: OR of the word shifted up by 1..9 with the
-            // previous word's top bits coming in (funnel shifts)
-            const uint32_t cur = bm[w], prev = w ? bm[w - 1] : 0u;
-            uint32_t below = 0;
-#pragma unroll
-            for (int s = 1; s <= 9; ++s) below |= __builtin_amdgcn_alignbit(cur, prev, 32 - s);
-            st = cur & ~below;
-        }
-        stv[q] = st;
-        local += __popc(st);
-    }
+    const uint32_t local = group_starts<PER_MAX>(bm, w0, w1, stv);
     uint32_t ng;
     uint32_t run = block_exclusive_scan(local, sh, &ng);      // (its barrier also ends all reads of bm)
 #pragma unroll
@@ -1301,14 +1391,15 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
     pc.mark(phase0 + 1, tid == 0);
     // 3. group sizes
     for (int h = tid; h < n; h += CLEAN_THREADS) {
-        if (need_clear && (hflags[h] & need_clear)) continue;
-        const RecV r = rec_decode(recs[h]);
+        const unsigned long long raw = recs[h];
+        if (need_clear && (hflags.of(h, raw) & need_clear)) continue;
+        const RecV r = rec_decode<NARROW>(raw);
         const uint32_t g = group_of(first_value(r));
         if (NARROW) {
             atomicAdd(&gcnt[g >> 1], (uint32_t)r.len << ((g & 1u) * 16));
-            // (the LDS copy of a record has 15 spare bits above the strand bit: the flag pass takes the group from there
+            // (the LDS copy of a record keeps its group above its flags: the flag pass takes it from there
             // instead of ranking the value again - two LDS reads and a popcount per record)
-            reinterpret_cast<uint16_t*>(const_cast<unsigned long long*>(&recs[h]))[3] = (uint16_t)((g << 1) | (r.rc ? 1u : 0u));
+            reinterpret_cast<uint32_t*>(const_cast<unsigned long long*>(&recs[h]))[1] = ((uint32_t)(raw >> 32) & 0x3FFFu) | (g << 14);
         } else {
             atomicAdd(&gcnt[g], (uint32_t)r.len);
         }
@@ -1324,58 +1415,122 @@ __device__ __forceinline__ void cluster_axis(HP recs, FP hflags, int n, int vbia
     const uint32_t mx = sh->max_group;
     pc.mark(phase0 + 2, tid == 0);
     // 4. flags (and, for the last step of a pair, the reductions over the finished flags)
-    int k1 = 0, k2 = 0, c10 = 0, kd = 0, dlo = 0x7FFFFFFF, dhi = -0x7FFFFFFF;
-    long long sabs = 0;
+    FinalAcc acc;
     for (int h = tid; h < n; h += CLEAN_THREADS) {
-        uint32_t f = hflags[h];
+        const unsigned long long raw = recs[h];
+        uint32_t f = hflags.of(h, raw);
         const bool sel = !(need_clear && (f & need_clear));
         if (!(sel || FINAL)) continue;
-        const unsigned long long raw = recs[h];
-        const RecV r = rec_decode(raw);
+        const RecV r = rec_decode<NARROW>(raw);
         if (sel) {
-            const uint32_t c = gsize(NARROW ? (uint32_t)(raw >> 49) : group_of(first_value(r)));
+            const uint32_t c = gsize(NARROW ? (uint32_t)(raw >> 46) : group_of(first_value(r)));
             if (set_gt10 && c > 10u) f |= set_gt10;
             if (set_rule && ((mx > 50u) ? (c > 50u) : (c == mx))) f |= set_rule;
         }
-        if (FINAL) {
-            uint32_t pub = f & (HF_C2D | HF_C2A);
-            const bool c1k = (f & (WF_D1 | WF_A1)) != 0u, c2k = pub != 0u;
-            if (c1k) pub |= HF_C1;
-            const int d0 = r.i0 - r.j0;
-            if (!r.rc) {
-                // i - j is the same for all dots of the record
-                const int ad = d0 < 0 ? -d0 : d0;
-                if (c1k) { k1 += r.len; sabs += (long long)r.len * ad; dlo = min(dlo, d0); dhi = max(dhi, d0); }
-                if (c2k) {
-                    // dots with j > 0 and 25*|j-i| < 4*j, j = j0 .. j0+len-1:  j >= floor(25*ad/4) + 1
-                    const int jmin = max(1, (25 * ad) / 4 + 1);
-                    k2 += r.len;
-                    c10 += max(0, r.j0 + r.len - max(r.j0, jmin));
-                }
-            } else if (c1k || c2k) {
-                for (int t = 0; t < r.len; ++t) {
-                    const int j = r.j0 - t, i = r.i0 + t, ad = j > i ? j - i : i - j;
-                    if (c1k) { ++k1; sabs += ad; }
-                    if (c2k) { ++k2; c10 += (j > 0 && 25 * ad < 4 * j); }
-                }
-                if (c1k) { dlo = min(dlo, d0); dhi = max(dhi, d0 + 2 * (r.len - 1)); }
-            }
-            kd += (f & HF_C2D) ? r.len : 0;
-            f = pub;
-        }
-        hflags[h] = (uint8_t)f;
+        if (FINAL) f = acc.add(f, r);
+        hflags.set(h, raw, f);
     }
-    if (FINAL) {
-        k1 = wave_sum_i32(k1); k2 = wave_sum_i32(k2); c10 = wave_sum_i32(c10); kd = wave_sum_i32(kd);
-        sabs = wave_sum_i64(sabs); dlo = wave_min_i32(dlo); dhi = wave_max_i32(dhi);
-        if ((tid & 63) == 0) {
-            atomicAdd(&sh->c1_kept, k1); atomicAdd(&sh->c2_kept, k2); atomicAdd(&sh->c2_count10, c10);
-            atomicAdd(&sh->c2_kept_diag, kd); atomicAdd(&sh->c1_sum_abs, (unsigned long long)sabs);
-            atomicMin(&sh->kd_lo, dlo); atomicMax(&sh->kd_hi, dhi);
-        }
-    }
+    if (FINAL) acc.commit(sh);
     __syncthreads();
     pc.mark(phase0 + 3, tid == 0);
+}
+
+// Both axes of C1 (clean_dotdata_diagnal_and_anti_diagnal, SF:432-448: groups of more than 10 on i - j OR on i + j keep a
+// dot) in ONE sweep over the staged records of a pair - and with them the diagonal step of C2 when the pair wants it
+// (rule_d = HF_C2D: dis_cluster's rule on the same i - j groups).  The two clusterings are independent, so every phase of
+// cluster_axis is done once for both: one pass marks both occupancy bitmaps (the staging pass), one block scan ranks both
+// sets of group starts (two 16-bit fields of one word: a pair staged in LDS has at most 8192 groups per axis), one pass
+// over the records adds both group sizes and parks both group numbers in the record's upper word, one pass sets the
+// flags.  Half the barriers and record decodes of two cluster_axis calls.  LDS copy only (LFMT records).
+// The two axes share one region of 16-bit group counters (gcnt, room for gcap of them): the i + j counters follow the
+// i - j ones.  A pair with more groups than that on the two axes together (nearly every record a group of its own on both)
+// returns false with nothing but the bitmaps changed, and the caller clusters its axes one after the other.
+template <bool FINAL, int PER_MAX, typename FP>
+__device__ __forceinline__ bool cluster_dual(unsigned long long* recs, FP hflags, int n, int vbias, int range_words,
+                                             uint32_t* bmD, uint16_t* wrankD, uint32_t* bmA, uint16_t* wrankA,
+                                             uint32_t* gcnt, int gcap, CleanShared* sh, uint32_t rule_d, CleanClock& pc)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) sh->max_group = 0;
+    // (both bitmaps were filled while the records were staged; the caller's barrier ended that pass)
+    const int per = (range_words + CLEAN_THREADS - 1) / CLEAN_THREADS;
+    const int w0 = min(tid * per, range_words), w1 = min(w0 + per, range_words);
+    uint32_t ngD, ngA;
+    if constexpr (PER_MAX > 8) {
+        // (the largest value ranges: sixteen words per thread and axis - both sets of starts at once would not fit the 64
+        // registers of a thread, so the two axes are ranked one after the other; the record passes below stay shared)
+        auto rank_axis = [&](uint32_t* bm, uint16_t* wrank, uint32_t& ng) {
+            uint32_t st[PER_MAX];
+            const uint32_t local = group_starts<PER_MAX>(bm, w0, w1, st);
+            uint32_t run = block_exclusive_scan(local, sh, &ng);
+#pragma unroll
+            for (int q = 0; q < PER_MAX; ++q) {
+                const int w = w0 + q;
+                if (w < w1) { bm[w] = st[q]; wrank[w] = (uint16_t)run; run += __popc(st[q]); }
+            }
+        };
+        rank_axis(bmD, wrankD, ngD);
+        __syncthreads();                           // (block_exclusive_scan's shared totals are read by every thread)
+        rank_axis(bmA, wrankA, ngA);
+    } else {
+        uint32_t stD[PER_MAX], stA[PER_MAX];
+        const uint32_t local = group_starts<PER_MAX>(bmD, w0, w1, stD) | (group_starts<PER_MAX>(bmA, w0, w1, stA) << 16);
+        uint32_t tot;
+        uint32_t run = block_exclusive_scan(local, sh, &tot);      // (its barrier also ends all reads of the bitmaps)
+        ngD = tot & 0xFFFFu; ngA = tot >> 16;
+#pragma unroll
+        for (int q = 0; q < PER_MAX; ++q) {
+            const int w = w0 + q;
+            if (w < w1) {
+                bmD[w] = stD[q]; bmA[w] = stA[q];
+                wrankD[w] = (uint16_t)run; wrankA[w] = (uint16_t)(run >> 16);
+                run += __popc(stD[q]) | (__popc(stA[q]) << 16);
+            }
+        }
+    }
+    if ((int)(ngD + ngA) + 2 > gcap) { __syncthreads(); return false; }      // (uniform: block totals)
+    uint32_t* const gcntD = gcnt;
+    uint32_t* const gcntA = gcnt + (ngD + 1) / 2;
+    for (uint32_t g = tid; g < (ngD + 1) / 2 + (ngA + 1) / 2; g += CLEAN_THREADS) gcnt[g] = 0;
+    __syncthreads();
+    pc.mark(17, tid == 0);
+    // group sizes on both axes
+    for (int h = tid; h < n; h += CLEAN_THREADS) {
+        const unsigned long long raw = recs[h];
+        const RecV r = rec_decode<true>(raw);
+        const int vd = r.i0 - r.j0 + vbias, va = r.i0 + r.j0;
+        const uint32_t gd = (uint32_t)wrankD[vd >> 5] + __popc(bmD[vd >> 5] & (0xFFFFFFFFu >> (31 - (vd & 31)))) - 1u;
+        const uint32_t ga = (uint32_t)wrankA[va >> 5] + __popc(bmA[va >> 5] & (0xFFFFFFFFu >> (31 - (va & 31)))) - 1u;
+        atomicAdd(&gcntD[gd >> 1], (uint32_t)r.len << ((gd & 1u) * 16));
+        atomicAdd(&gcntA[ga >> 1], (uint32_t)r.len << ((ga & 1u) * 16));
+        reinterpret_cast<uint32_t*>(&recs[h])[1] = ((uint32_t)(raw >> 32) & 63u) | (gd << 6) | (ga << 19);
+    }
+    __syncthreads();
+    if (rule_d) {
+        uint32_t m = 0;
+        for (uint32_t g = tid; g < ngD; g += CLEAN_THREADS) m = max(m, (gcntD[g >> 1] >> ((g & 1u) * 16)) & 0xFFFFu);
+        m = (uint32_t)wave_max_i32((int)m);
+        if ((tid & 63) == 0) atomicMax(&sh->max_group, m);
+        __syncthreads();
+    }
+    const uint32_t mx = sh->max_group;
+    pc.mark(18, tid == 0);
+    FinalAcc acc;
+    for (int h = tid; h < n; h += CLEAN_THREADS) {
+        const unsigned long long raw = recs[h];
+        const uint32_t gd = (uint32_t)(raw >> 38) & 0x1FFFu, ga = (uint32_t)(raw >> 51);
+        const uint32_t cd = (gcntD[gd >> 1] >> ((gd & 1u) * 16)) & 0xFFFFu, ca = (gcntA[ga >> 1] >> ((ga & 1u) * 16)) & 0xFFFFu;
+        uint32_t f = 0;                                // (the flags of a pair are all clear before its first clustering step)
+        if (cd > 10u) f |= WF_D1;
+        if (ca > 10u) f |= WF_A1;
+        if (rule_d && ((mx > 50u) ? (cd > 50u) : (cd == mx))) f |= rule_d;
+        if (FINAL) f = acc.add(f, rec_decode<true>(raw));
+        hflags.set(h, raw, f);
+    }
+    if (FINAL) acc.commit(sh);
+    __syncthreads();
+    pc.mark(19, tid == 0);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1435,17 +1590,18 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
     const R4Div d1(lo1, range1);
     // level 1: sizes of the eleven lists
     for (int h = tid; h < n; h += CLEAN_THREADS) {
-        const uint32_t f = hflags[h];
+        const unsigned long long raw = recs[h];
+        const uint32_t f = hflags.of(h, raw);
         if (!(f & HF_C1)) continue;
-        const RecV r = rec_decode(recs[h]);
+        const RecV r = rec_decode<CACHE>(raw);
         const int d0 = r.i0 - r.j0;
         if (!r.rc) {
             const int b = d1.bin(d0);
             atomicAdd(&sh->cnt1[b], r.len);
-            if (CACHE) hflags[h] = (uint8_t)(f | ((uint32_t)b << 4));
+            if (CACHE) hflags.set(h, raw, f | ((uint32_t)b << 4));
         } else {
             for (int t = 0; t < r.len; ++t) atomicAdd(&sh->cnt1[d1.bin(d0 + 2 * t)], 1);
-            if (CACHE) hflags[h] = (uint8_t)(f | 0xF0u);
+            if (CACHE) hflags.set(h, raw, f | 0xF0u);
         }
     }
     __syncthreads();
@@ -1461,10 +1617,11 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
         {
             int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
             for (int h = tid; h < n; h += CLEAN_THREADS) {
-                const uint32_t f = hflags[h];
+                const unsigned long long raw = recs[h];
+                const uint32_t f = hflags.of(h, raw);
                 if (!(f & HF_C1)) continue;
                 if (CACHE && (f >> 4) != 15u && (int)(f >> 4) != w) continue;
-                const RecV r = rec_decode(recs[h]);
+                const RecV r = rec_decode<CACHE>(raw);
                 const int d0 = r.i0 - r.j0;
                 if (!r.rc) {
                     if (CACHE || d1.bin(d0) == w) { lo = min(lo, d0); hi = max(hi, d0); }
@@ -1482,10 +1639,11 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
         const int lo2 = sh->bin_lo, range2 = sh->bin_hi - sh->bin_lo;
         const R4Div d2(lo2, range2);
         for (int h = tid; h < n; h += CLEAN_THREADS) {
-            const uint32_t f = hflags[h];
+            const unsigned long long raw = recs[h];
+            const uint32_t f = hflags.of(h, raw);
             if (!(f & HF_C1)) continue;
             if (CACHE && (f >> 4) != 15u && (int)(f >> 4) != w) continue;
-            const RecV r = rec_decode(recs[h]);
+            const RecV r = rec_decode<CACHE>(raw);
             const int d0 = r.i0 - r.j0;
             if (!r.rc) {
                 if (CACHE || d1.bin(d0) == w) atomicAdd(&sh->cnt2[d2.bin(d0)], r.len);
@@ -1520,10 +1678,11 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
         for (int q = tid; q < width; q += CLEAN_THREADS) counters[q] = 0;
         __syncthreads();
         for (int h = tid; h < n; h += CLEAN_THREADS) {
-            const uint32_t f = hflags[h];
+            const unsigned long long raw = recs[h];
+            const uint32_t f = hflags.of(h, raw);
             if (!(f & HF_C1)) continue;
             if (CACHE && (f >> 4) != 15u && (int)(f >> 4) != w) continue;
-            const RecV r = rec_decode(recs[h]);
+            const RecV r = rec_decode<CACHE>(raw);
             const int d0 = r.i0 - r.j0;
             if (!r.rc) {
                 if (d0 >= vlo && d0 <= vhi && (CACHE || d1.bin(d0) == w) && d2.bin(d0) == b)
@@ -1566,8 +1725,9 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
         int cn = 0;
         long long cs = 0;
         for (int h = tid; h < n; h += CLEAN_THREADS) {
-            if (!(hflags[h] & HF_C1)) continue;
-            const RecV r = rec_decode(recs[h]);
+            const unsigned long long raw = recs[h];
+            if (!(hflags.of(h, raw) & HF_C1)) continue;
+            const RecV r = rec_decode<CACHE>(raw);
             if (!r.rc) {
                 // X - Y = df is the same for all dots, X = X0 + 2*t:  |X| < 10*|df|  <=>  -B < X < B
                 const int X0 = 2 * r.j0 + c2x, df = X0 - 2 * r.i0, B = 10 * (df < 0 ? -df : df);
@@ -1598,13 +1758,39 @@ __device__ __forceinline__ void directed_stats(HP recs, FP hflags, int n, uint32
 // everything after the records are in place (LDS copy or global), for one pair
 template <bool NARROW, int PER_MAX, typename HP, typename FP>
 __device__ __forceinline__ void clean_body(HP recs, FP hflags, int n, int n_dots, const DPair& pr, int len2, int range_words,
-                                           uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, CleanShared* sh, long long* st, CleanClock& pc)
+                                           uint32_t* bm, uint16_t* wrank, uint32_t* gcnt, uint32_t* bm2, uint16_t* wrank2,
+                                           int gcap, bool dual_layout, CleanShared* sh, long long* st, CleanClock& pc)
 {
     const int tid = threadIdx.x;
     const bool c1 = pr.flags & 1u, c2 = pr.flags & 2u, s3 = (pr.flags & 4u) && c1;
     // i - j over all dots (its bitmap was filled while the records were staged): C1's diagonal groups (>10)
     // and C2's diagonal step; then i + j over all dots (C1) and / or over the dots the diagonal step left (C2)
-    if (c1 && c2) {
+    bool done = false;
+    if constexpr (NARROW) {
+      if (dual_layout) {
+        done = true;
+        // (staged in LDS with room for both axes' bitmaps, which the staging pass has filled for a C1 pair; cluster_dual
+        // declines a pair with more groups than its counters hold, whose axes are then clustered one after the other,
+        // bitmaps marked again)
+        if (c1 && c2) {
+            if (!cluster_dual<false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, bm2, wrank2, gcnt, gcap, sh, HF_C2D, pc)) {
+                cluster_axis<false, NARROW, false, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
+                cluster_axis<true, NARROW, false, false, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
+            }
+            cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc, 20);
+        } else if (c1) {
+            if (!cluster_dual<true, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, bm2, wrank2, gcnt, gcap, sh, 0u, pc)) {
+                cluster_axis<false, NARROW, false, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, 0u, pc, 16);
+                cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc, 20);
+            }
+        } else if (c2) {
+            cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, 0u, HF_C2D, pc);
+            cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
+        }
+      }
+    }
+    if (done) {
+    } else if (c1 && c2) {
         cluster_axis<false, NARROW, true, false, PER_MAX>(recs, hflags, n, len2, range_words, bm, wrank, gcnt, sh, 0u, WF_D1, HF_C2D, pc);
         cluster_axis<true, NARROW, false, false, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, 0u, WF_A1, 0u, pc);
         cluster_axis<true, NARROW, false, true, PER_MAX>(recs, hflags, n, 0, range_words, bm, wrank, gcnt, sh, HF_C2D, 0u, HF_C2A, pc);
@@ -1630,7 +1816,7 @@ template <bool IN_LDS, int PER_MAX>
 __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh, const DPair& pr, int n, int n_dots, int len2,
                                            int range_words, const unsigned long long* __restrict__ recs_all,
                                            uint8_t* __restrict__ hflags_all, long long* __restrict__ stats,
-                                           int range_words_cap, int groups_cap, int hcap)
+                                           int range_words_cap, int groups_cap, int hcap, bool dual_layout)
 {
     const int tid = threadIdx.x;
     long long* st = stats + (size_t)p * 16;
@@ -1646,12 +1832,16 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
         const int h = q * CLEAN_THREADS + tid;
         x[q] = h < n ? grecs[h] : 0ull;
     }
+    // clean_kernel (IN_LDS): bitmap and ranks of i - j | bitmap and ranks of i + j (cluster_dual) | group counters | records;
+    // clean_big_kernel: bitmap | ranks | group counters
+    const int bw = range_words_cap + (range_words_cap + 1) / 2;
     uint32_t* bm = lds;
     uint16_t* wrank = reinterpret_cast<uint16_t*>(bm + range_words_cap);
-    uint32_t* gcnt = bm + range_words_cap + (range_words_cap + 1) / 2;
-    const int rec_word = (range_words_cap + (range_words_cap + 1) / 2 + (groups_cap + 1) / 2 + 1) & ~1;
+    uint32_t* bm2 = lds + bw;
+    uint16_t* wrank2 = reinterpret_cast<uint16_t*>(bm2 + range_words_cap);
+    uint32_t* gcnt = lds + (dual_layout ? 2 * bw : bw);
+    const int rec_word = ((dual_layout ? 2 : 1) * bw + (groups_cap + 1) / 2 + 1) & ~1;
     unsigned long long* lrecs = reinterpret_cast<unsigned long long*>(lds + rec_word);
-    uint8_t* lflags = reinterpret_cast<uint8_t*>(lrecs + hcap);
 
     if (tid == 0) {
         sh.min_j = 0x7FFFFFFF; sh.max_j = -1; sh.n_diag = 0; sh.n_lower = 0;
@@ -1661,12 +1851,15 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
     // pass 0: first/last j, diagonal and lower-triangle counts; stage the records, clear the flags, and fill
     // the occupancy bitmap of i - j for the first clustering step
     const bool any_axis = (pr.flags & 3u) != 0u;
+    const bool dual = IN_LDS && dual_layout && (pr.flags & 1u);      // C1: both axes are clustered in one sweep (cluster_dual)
     for (int w = tid; w < range_words; w += CLEAN_THREADS) bm[w] = 0;
+    if (dual)
+        for (int w = tid; w < range_words; w += CLEAN_THREADS) bm2[w] = 0;
     __syncthreads();
     {
         int mn = 0x7FFFFFFF, mx = -1, nd = 0, nl = 0;
         auto take = [&](int h, unsigned long long xr) {
-            const RecV r = rec_decode(xr);
+            const RecV r = rec_decode<false>(xr);
             if (!r.rc) {
                 mn = min(mn, r.j0); mx = max(mx, r.j0 + r.len - 1);
                 nd += (r.j0 == r.i0) ? r.len : 0;
@@ -1678,9 +1871,10 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
                 nd += (D >= 0 && !(D & 1) && (D >> 1) < r.len) ? 1 : 0;
                 nl += D > 0 ? min(r.len, (D + 1) >> 1) : 0;
             }
-            if (IN_LDS) { lrecs[h] = xr; lflags[h] = 0; }
+            if (IN_LDS) lrecs[h] = rec_to_lds(xr);           // (flags and group fields clear)
             else gflags[h] = 0;
             if (any_axis) mark_values(bm, (uint32_t)(r.i0 - r.j0 + len2), r.len, r.rc);
+            if (IN_LDS && dual) mark_values(bm2, (uint32_t)(r.i0 + r.j0), r.len, !r.rc);
         };
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
@@ -1697,18 +1891,24 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
     __syncthreads();
     pc.mark(8, tid == 0);                          // pass 0
     if (IN_LDS) {
-        clean_body<true, PER_MAX>((const unsigned long long*)lrecs, lflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+        clean_body<true, PER_MAX>(lrecs, LFlags{lrecs}, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, bm2, wrank2, groups_cap, dual_layout, &sh, st, pc);
         __syncthreads();
         pc.mark(9, tid == 0);                      // what the nested stamps left of clean_body
-        // four flag bytes per store (the pair's slot and the LDS copy are both padded to a multiple of four)
+        // four flag bytes per store (the pair's slot is padded to a multiple of four): the public bits of four records
         {
-            const uint32_t* lf4 = reinterpret_cast<const uint32_t*>(lflags);
+            const uint32_t* hi = reinterpret_cast<const uint32_t*>(lrecs) + 1;
             uint32_t* gf4 = reinterpret_cast<uint32_t*>(gflags);
-            for (int h = tid; h < (n + 3) / 4; h += CLEAN_THREADS) gf4[h] = lf4[h] & 0x07070707u;
+            for (int h = tid; h < (n + 3) / 4; h += CLEAN_THREADS) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (4 * h + q < n) w |= ((hi[2 * (4 * h + q)] >> 6) & 7u) << (8 * q);
+                gf4[h] = w;
+            }
         }
         pc.mark(10, tid == 0);
     } else {
-        clean_body<false, PER_MAX>(grecs, gflags, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, &sh, st, pc);
+        clean_body<false, PER_MAX>(grecs, GFlags{gflags}, n, n_dots, pr, len2, range_words, bm, wrank, gcnt, bm2, wrank2, groups_cap, dual_layout, &sh, st, pc);
     }
     pc.flush(tid == 0);
 }
@@ -1722,7 +1922,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
     const unsigned long long* __restrict__ n_hits, const unsigned long long* __restrict__ recs_all,
     uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
-    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list, int big_follows)
+    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list, int big_follows, int dual_layout)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
@@ -1755,7 +1955,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
         return;
     }
     clean_pair<true, PER_MAX>(p, lds, sh, pr, n, (int)ndots, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
-                     recs_all, hflags_all, stats, range_words_cap, groups_cap, hcap);
+                     recs_all, hflags_all, stats, range_words_cap, groups_cap, hcap, dual_layout != 0);
 }
 
 // The pairs clean_kernel left (more records than the LDS copy holds, or too many dots for 16-bit counters): the
@@ -1776,7 +1976,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
         __syncthreads();                       // the previous pair's statistics have been read
         clean_pair<false, CLEAN_PER_MAX>(p, lds, sh, pr, (int)(uint32_t)cnt, (int)(uint32_t)(cnt >> 32), pr.len2,
                           min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap), recs_all, hflags_all, stats,
-                          range_words_cap, groups_cap, 0);
+                          range_words_cap, groups_cap, 0, false);
     }
 }
 
