@@ -313,7 +313,7 @@ def test_run_records_expand_to_the_oracle_dots(eng, oracle):
         assert st[t, 0] == len(exp) and got.tolist() == exp.tolist(), (t, rows[t])
         assert 0 < rec[t] <= st[t, 0]
     assert rec[0] * 20 < st[0, 0]                 # an exact copy: 32 dots per record
-    assert rec[4] == st[4, 0]                     # the N switches run forming off for this pair
+    assert rec[4] * 8 < st[4, 0]                  # a read with an N forms runs as well (they end before it)
     plan.close()
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "runs")
 
@@ -397,10 +397,54 @@ def test_runs_with_a_soft_masked_allele(eng, oracle):
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "soft-masked")
 
 
+def test_runs_with_exception_symbols_in_the_read(eng, oracle):
+    """Reads with symbols outside upper-case ACGT (an N, a lower-case stretch) against alleles without (these
+    pairs stored every dot as its own record): a launch of their own (join_kernel<.., EXC = 2>) masks the positions whose
+    k-mer covers such a symbol out of the lookup, ends a run before the first of them and starts none behind one.  Dots and
+    statistics are the oracle's for every window size; the records stay a fraction of the dots."""
+    from vapor_amd import synth
+    rng = np.random.default_rng(61)
+    allele = synth.random_dna(rng, 9000)
+
+    def spoiled(seg, spots, lower=()):
+        b = bytearray(seg.encode())
+        for a in spots:
+            b[a] = ord("N")
+        for a, n in lower:
+            b[a:a + n] = bytes(b[a:a + n]).lower()
+        return b.decode()
+
+    exact = spoiled(allele[100:8900], (0, 9, 10, 31, 32, 33, 500, 1013, 1014, 1023, 1024, 1025, 1055, 2047, 2048, 4000, 4001, 8799),
+                    lower=((3000, 45), (6000, 1)))
+    noisy = spoiled(synth.mutate(np.random.default_rng(10), allele[200:8800], 0.002, 0.004, 0.004)[0], (77, 1500, 1501, 5000, 8000))
+    inv = spoiled(allele[500:3000] + synth.revcomp(allele[3000:5500]) + allele[5500:8000], (1200, 2600, 3100, 4700, 6000))
+    clean_n = sum(1 for c in exact if c not in "ACGT")
+    seqs = [allele, exact, noisy, inv]
+    rows = [(1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (3, 0, 0, 10, 7), (1, 0, 0, 20, 3), (2, 0, 1234, 30, 1), (1, 0, 0, 40, 3), (1, 0, 150, 10, 7)]
+    ss = eng.seqset(seqs)
+    assert ss.n_exc[0] == 0 and ss.n_exc[1] == clean_n and ss.n_exc[2] > 0 and ss.n_exc[3] > 0
+    plan = eng.plan(ss, eng.make_pairs(rows))
+    st = plan.run().copy()
+    rec = plan.record_counts()
+    hits, _fl, off = plan.fetch_hits(range(len(rows)), want_flags=True)
+    for t, (s1, s2, off2, k, _f) in enumerate(rows):
+        exp = oracle.dotdata_array(k, seqs[s1], seqs[s2][off2:])
+        got = hits[off[t]:off[t + 1]]
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        assert st[t, 0] == len(exp) and got.tolist() == exp.tolist(), (t, rows[t])
+    # runs despite the exceptions: the exact copy's diagonal is a few hundred records (32 dots each at most, cut at every
+    # N), not thousands of single dots
+    assert st[0, 0] > 7000 and rec[0] * 8 < st[0, 0], (st[0, 0], rec[0])
+    assert rec[1] * 2 < st[1, 0] and rec[3] * 8 < st[3, 0] and rec[5] * 8 < st[5, 0]
+    plan.close()
+    _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "read exceptions")
+
+
 def test_runs_on_the_four_bit_planes(eng, oracle):
     """Both sides hold symbols outside upper-case ACGT (the self plot of a soft-masked window, a lower-case read against
     a lower-case allele): the 4-bit planes, where lower case matches lower case and N matches N.  Runs are formed there
-    too (window sizes 10 and 20); the expanded dots are dotdata()'s, the statistics the oracle's."""
+    too (up to 32 dots for window sizes 10 and 20, up to 16 for 30 and 40); the expanded dots are dotdata()'s, the statistics the
+    oracle's."""
     from vapor_amd import synth
     rng = np.random.default_rng(58)
     base = synth.random_dna(rng, 7000)
@@ -414,7 +458,8 @@ def test_runs_on_the_four_bit_planes(eng, oracle):
     other = synth.mutate(np.random.default_rng(4), base[100:6000], 0.003, 0.004, 0.004)[0]
     other = other[:1000] + other[1000:2000].lower() + other[2000:]
     seqs = [masked, shifted, other]
-    rows = [(0, 0, 0, 10, 0), (0, 0, 0, 20, 0), (1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (1, 0, 777, 20, 3), (0, 0, 0, 30, 0)]
+    rows = [(0, 0, 0, 10, 0), (0, 0, 0, 20, 0), (1, 0, 0, 10, 7), (2, 0, 0, 10, 7), (1, 0, 777, 20, 3), (0, 0, 0, 30, 0),
+            (0, 0, 0, 40, 0), (1, 0, 333, 30, 7), (2, 0, 0, 40, 3)]
     ss = eng.seqset(seqs)
     assert ss.n_exc[0] > 0 and ss.n_exc[1] > 0 and ss.n_exc[2] > 0
     plan = eng.plan(ss, eng.make_pairs(rows))
@@ -428,7 +473,8 @@ def test_runs_on_the_four_bit_planes(eng, oracle):
         assert st[t, 0] == len(exp) and got.tolist() == exp.tolist(), (t, rows[t])
     assert st[0, 0] >= 6900 and rec[0] * 10 < st[0, 0]      # the self plot's diagonal in runs of up to 32
     assert rec[1] * 10 < st[1, 0]
-    assert rec[5] == st[5, 0]                               # window size 30: single-dot records on these planes
+    # window sizes 30 and 40 (they stored every dot as its own record): runs of up to 16 dots
+    assert rec[5] * 10 < st[5, 0] and rec[6] * 10 < st[6, 0] and rec[7] * 8 < st[7, 0], (rec[5:8], st[5:8, 0])
     plan.close()
     _check_stats_vs_oracle(eng, oracle, seqs, [False] * len(seqs), rows, "x4 runs")
 

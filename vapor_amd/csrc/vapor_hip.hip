@@ -152,7 +152,7 @@ struct vapor_seqset {
 
 struct Launch {
     int bps, k, task_begin, n_tasks;
-    bool aexc;     // 2-bit planes, alleles with symbols outside upper-case ACGT (join_kernel<.., AEXC = true>)
+    int exc;       // 2-bit planes: 1 = alleles with symbols outside upper-case ACGT, 2 = reads with such symbols (join_kernel<.., EXC>)
 };
 
 struct vapor_plan {
@@ -587,8 +587,9 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         int64_t cap = std::min(n1, n2) + ((n1 * n2) >> 17) + 1024;
         d.cap = (uint32_t)std::min<int64_t>(cap, ctx->max_pair_cap);
         // 2: 2-bit planes; 3: 2-bit planes, the allele has symbols outside upper-case ACGT (a launch of its own: the table
-        // leaves their k-mers out and runs end before them); 4: both sides have such symbols - the 4-bit planes
-        mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : (s2.n_exc > 0 ? 3 : 2);
+        // leaves their k-mers out and runs end before them); 5: 2-bit planes, the read has such symbols (a launch of its own:
+        // their positions are masked out of the lookup, runs end before them); 4: both sides have them - the 4-bit planes
+        mode[i] = (s1.n_exc > 0 && s2.n_exc > 0) ? 4 : (s2.n_exc > 0 ? 3 : (s1.n_exc > 0 ? 5 : 2));
         rw = std::max(rw, (s1.len + s2.len + 2 + 31) / 32);
         // records expected: the shared diagonal in runs of a few dots plus the chance dots
         hwant = std::max<int64_t>(hwant, std::min(n1, n2) / 10 + ((n1 * n2) >> 19) + 192);
@@ -668,7 +669,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         }
         std::vector<size_t> cuts;
         pack(lo, &cuts);
-        p->launches.push_back(Launch{m == 4 ? 4 : 2, k, (int)p->tasks.size(), 0, m == 3});
+        p->launches.push_back(Launch{m == 4 ? 4 : 2, k, (int)p->tasks.size(), 0, m == 3 ? 1 : m == 5 ? 2 : 0});
         for (size_t c = 0; c < cuts.size(); ++c) {
             const size_t t0 = q + cuts[c], t1 = q + (c + 1 < cuts.size() ? cuts[c + 1] : n);
             DTask tk;
@@ -712,12 +713,16 @@ template <int BPS, int K>
 static void launch_join(vapor_plan* p, const Launch& L, bool first, hipStream_t st)
 {
     const vapor_seqset* s = p->set;
-    if (BPS == 2 && L.aexc)
-        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, (BPS == 2)>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
+    if (BPS == 2 && L.exc == 1)
+        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, (BPS == 2 ? 1 : 0)>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
+                           st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
+                           p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
+    else if (BPS == 2 && L.exc == 2)
+        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, (BPS == 2 ? 2 : 0)>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
                            st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
                            p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
     else
-        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, false>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
+        hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, 0>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
                            st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
                            p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }

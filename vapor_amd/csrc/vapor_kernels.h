@@ -319,6 +319,16 @@ __device__ __forceinline__ uint32_t canon_hash(const KeyT<BPS, K>& k, const KeyT
     return x;
 }
 
+// The occupancy filter in front of the table is a blocked Bloom filter with two bits per key inside one 32-bit word: the
+// word and the first bit are the hash's top FILT_LOG2 bits (a bit per quarter bucket), the second bit five lower hash
+// bits.  A read k-mer is looked up only when both are set: 20 000 keys in 2^17 bits pass 6.5 % of the absent k-mers
+// instead of 14 % with one bit, at three more vector instructions per read position and no further LDS read
+// (cfg2 join 0.1555 -> 0.1509 ms, cfg3 3.49 -> 3.39 ms: profiles/r03_ab_bloom.txt).
+__device__ __forceinline__ uint32_t filt_mask(uint32_t hx, uint32_t fb)
+{
+    return (1u << (fb & 31u)) | (1u << ((hx >> 10) & 31u));
+}
+
 // Cross-lane steps as DPP modifiers of VALU instructions (gfx9: row_shr, wave_shr, row_bcast15/31) instead of
 // ds_bpermute: they do not occupy the LDS pipe that the table and bitmap traffic needs and their latency is a
 // few cycles.  All 64 lanes must be active.
@@ -451,11 +461,16 @@ __device__ __forceinline__ unsigned long long win2(const uint32_t* plane, uint32
 // MERGE (runs are formed: 2-bit planes, no exception symbol on either side) is a template parameter so that the body is
 // one straight line: with a (uniform) branch on it inside, the compiler reads the symbols after the k-mer in a second
 // round trip under that branch and does not start the second candidate's reads before the first is done.
-// MERGE: 0 = every dot its own record; 1 = runs, neither side has a symbol outside upper-case ACGT; 2 = runs, the allele has
+// MERGE: 0 = every dot its own record; 1 = runs, neither side has a symbol outside upper-case ACGT; 3 = runs, the READ has
+// such symbols (an N in a read; the allele has none): the positions whose k-mer covers one are not looked up at all, a run
+// ends before the first of them and does not continue from a dot whose predecessor's read symbol is one - `etile` then
+// holds the exception bits of the wave's strip of the read; 2 = runs, the allele has
 // such symbols (soft-masked references: the usual case with real genomes for the scorers that do not upper-case) - a
 // k-mer that covers one is not in the table, so a run ends before the first of them and the dot before a candidate
 // exists only if the symbol before it is none.  The allele's exception bits come from etile.
-template <int BPS, int K, int MERGE>
+// NQ: candidates per lane and call (2; 1 for the 4-bit planes at window sizes 30 and 40, where the two streams of ONE
+// candidate take the registers two take elsewhere - the caller then passes at most 64 candidates)
+template <int BPS, int K, int MERGE, int NQ = 2>
 __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, const uint16_t* entries,
                                               const uint32_t* rbuf, const uint32_t* tile, const uint32_t* etile, int cb, int ts,
                                               int off2, int tn, int nk1, unsigned long long* cnt_r, uint32_t cap,
@@ -470,20 +485,20 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     // (for the 2-bit planes the three verdicts of a candidate are kept as integers that are ZERO when true - differences
     // OR-ed with all-ones masks from sign shifts - so that each wave vote is one v_cmp_eq: a vote on a boolean that is
     // the AND of several compares costs a select and a second compare on top of them, and those issue alone)
-    bool same[2], rcm[2], head[2];
-    int len[2];
+    bool same[2] = {false, false}, rcm[2] = {false, false}, head[2] = {false, false};
+    int len[2] = {1, 1};
     const uint32_t out0 = (uint32_t)((lane - n) >> 31), out1 = (uint32_t)((lane + 64 - n) >> 31);   // ~0 if the slot is filled
-    uint32_t who[2];                               // il | e << 16
-    uint32_t item[2], e[2];
+    uint32_t who[2] = {0u, 0u};                    // il | e << 16
+    uint32_t item[2] = {0u, 0u}, e[2] = {0u, 0u};
 #pragma unroll
-    for (int q = 0; q < 2; ++q) item[q] = myq[from + ((q * 64 + lane < n) ? q * 64 + lane : 0)];
+    for (int q = 0; q < NQ; ++q) item[q] = myq[from + ((q * 64 + lane < n) ? q * 64 + lane : 0)];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) e[q] = entries[item[q] & 0xFFFFu];
+    for (int q = 0; q < NQ; ++q) e[q] = entries[item[q] & 0xFFFFu];
     const int emin = max(0, off2 - ts);            // first allele position of this tile that may carry a dot
     // records are assembled by one add: (e << 16 | il) + (ts - off2) << 16 + cb (neither field carries: both stay below 2^16)
     const uint32_t rec_bias = ((uint32_t)(ts - off2) << 16) + (uint32_t)cb;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const uint32_t il = item[q] >> 16;
         const bool in = (q * 64 + lane < n) && ts + (int)e[q] >= off2;
         who[q] = il | (e[q] << 16);
@@ -543,6 +558,12 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
                 const uint32_t eb = (etile[pa1 >> 5] >> ((uint32_t)pa1 & 31u)) & 1u;
                 cont &= eb - 1u;
             }
+            if (MERGE == 3) {
+                // ... and the read symbol before the k-mer is an ordinary one (etile = the exception bits of the wave's strip;
+                // position -1 of a strip is never consulted: its dot sits on a 32-aligned read position)
+                const uint32_t eb = (etile[pr1 >> 5] >> ((uint32_t)pr1 & 31u)) & 1u;
+                cont &= eb - 1u;
+            }
             head[q] = (df | cont) == 0u;
             if (merge) {
                 const uint32_t xl = ES ? __builtin_amdgcn_alignbit(sx[EW + 1], sx[EW], ES) : sx[EW];
@@ -559,14 +580,26 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
                     const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, p & 31u) | 0x80000000u;
                     len[q] = min(len[q], 1 + (int)__builtin_ctzll(((unsigned long long)hi << 32) | lo));
                 }
+                if (MERGE == 3) {
+                    // the same on the read's side: the first exception symbol of the strip at or after il+K, d symbols on,
+                    // allows d + 1 dots
+                    const uint32_t p = il + (uint32_t)K;
+                    const uint32_t w0 = etile[p >> 5], w1 = etile[(p >> 5) + 1], w2 = etile[(p >> 5) + 2];
+                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, p & 31u);
+                    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, p & 31u) | 0x80000000u;
+                    len[q] = min(len[q], 1 + (int)__builtin_ctzll(((unsigned long long)hi << 32) | lo));
+                }
             }
         } else if (merge) {
             // 4-bit planes (both sides hold symbols outside upper-case ACGT, e.g. the self plot of a soft-masked window;
             // no symbol of the allele is one that matches nothing - the caller's condition for `merge` here): the same
             // stream from one symbol before the k-mer, a nibble per symbol, 128 bits of extension
+            // (window sizes 30 and 40: runs of at most 16 dots, cut at 16-aligned read positions - 60 bits of extension instead of
+            // 124, two words less per stream; the record format allows any cut as long as heads and lengths agree on it)
+            constexpr int RB = (NQ == 1) ? 16 : VREC_MAX_LEN;
             constexpr int SB = 4 * (K + 1);
             constexpr int EW = SB / 32, ES = SB % 32;
-            constexpr int NN = EW + 5;
+            constexpr int NN = EW + (RB == 16 ? 3 : 5);
             const int pr1 = (int)il - 1, pa1 = (int)e[q] - 1;
             const uint32_t shr = (uint32_t)(pr1 & 7) * 4u, sha = (uint32_t)(pa1 & 7) * 4u;
             const uint32_t* rp = rbuf + (pr1 >> 3);
@@ -599,16 +632,25 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
             for (int x = 0; x < KT::NW; ++x) dr |= a.w[x] ^ kr.w[x];
             same[q] = df == 0u;
             rcm[q] = dr == 0u;
-            const uint32_t cont = (il & (VREC_MAX_LEN - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
+            const uint32_t cont = (il & (RB - 1)) & (uint32_t)((emin - (int)e[q]) >> 31) &
                                   (uint32_t)((int)((sx[0] & 15u) - 1u) >> 31);
             head[q] = (df | cont) == 0u;
-            uint32_t xw[4];
+            int ext;
+            if (RB == 16) {
+                uint32_t xw[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xw[j] = ES ? __builtin_amdgcn_alignbit(sx[EW + j + 1], sx[EW + j], ES) : sx[EW + j];
-            xw[3] |= 0x10000000u;                        // (31 symbols after the k-mer decide: at most 32 dots per run)
-            const unsigned long long lo64 = ((unsigned long long)xw[1] << 32) | xw[0], hi64 = ((unsigned long long)xw[3] << 32) | xw[2];
-            const int ext = lo64 ? (__builtin_ctzll(lo64) >> 2) : 16 + (__builtin_ctzll(hi64) >> 2);
-            len[q] = min(1 + ext, min(min(VREC_MAX_LEN - (int)(il & (VREC_MAX_LEN - 1)), nk1 - (cb + (int)il)), tn - (int)e[q]));
+                for (int j = 0; j < 2; ++j) xw[j] = ES ? __builtin_amdgcn_alignbit(sx[EW + j + 1], sx[EW + j], ES) : sx[EW + j];
+                xw[1] |= 0x10000000u;                    // (15 symbols after the k-mer decide: at most 16 dots per run)
+                ext = __builtin_ctzll(((unsigned long long)xw[1] << 32) | xw[0]) >> 2;
+            } else {
+                uint32_t xw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xw[j] = ES ? __builtin_amdgcn_alignbit(sx[EW + j + 1], sx[EW + j], ES) : sx[EW + j];
+                xw[3] |= 0x10000000u;                    // (31 symbols after the k-mer decide: at most 32 dots per run)
+                const unsigned long long lo64 = ((unsigned long long)xw[1] << 32) | xw[0], hi64 = ((unsigned long long)xw[3] << 32) | xw[2];
+                ext = lo64 ? (__builtin_ctzll(lo64) >> 2) : 16 + (__builtin_ctzll(hi64) >> 2);
+            }
+            len[q] = min(1 + ext, min(min(RB - (int)(il & (RB - 1)), nk1 - (cb + (int)il)), tn - (int)e[q]));
         } else {
             const KT kf = extract_key<BPS, K>(rbuf, il);
             const KT a = extract_key<BPS, K>(tile, e[q]);
@@ -644,21 +686,26 @@ __device__ __forceinline__ void join_verify_t(uint32_t* myq, int from, int n, co
     if (rcm[1] && slot < cap) out[slot] = record(who[1], 1, 1u);
 }
 
-// runs on the 4-bit planes up to this window size (beyond it a candidate's two streams need more registers than there are)
-constexpr int X4_MERGE_MAX_K = 20;
+// runs on the 4-bit planes: two candidates per lane up to this window size, one beyond it (a candidate's two streams then
+// need the registers two take below)
+constexpr int X4_MERGE_MAX_K = 40;
+constexpr int X4_TWO_PER_LANE_MAX_K = 20;
 
-template <int BPS, int K, bool AEXC>
+template <int BPS, int K, int EXC>
 __device__ __forceinline__ void join_verify(uint32_t* myq, int from, int n, const uint16_t* entries,
                                             const uint32_t* rbuf, const uint32_t* tile, const uint32_t* etile, int cb, int ts,
                                             int off2, int tn, int nk1, bool merge, unsigned long long* cnt_r, uint32_t cap,
                                             unsigned long long* out)
 {
-    if (BPS == 2 && merge) join_verify_t<BPS, K, AEXC ? 2 : 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
-    else if (BPS == 4 && K <= X4_MERGE_MAX_K && merge) join_verify_t<BPS, (K <= X4_MERGE_MAX_K ? K : 10), 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
-    else join_verify_t<BPS, K, 0>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    if (BPS == 2 && merge) join_verify_t<BPS, K, EXC == 1 ? 2 : EXC == 2 ? 3 : 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    else if (BPS == 4 && K <= X4_TWO_PER_LANE_MAX_K && merge) join_verify_t<BPS, K, 1>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    else if (BPS == 4 && merge) {
+        join_verify_t<BPS, K, 1, 1>(myq, from, min(n, 64), entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+        if (n > 64) join_verify_t<BPS, K, 1, 1>(myq, from + 64, n - 64, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
+    } else join_verify_t<BPS, K, 0>(myq, from, n, entries, rbuf, tile, etile, cb, ts, off2, tn, nk1, cnt_r, cap, out);
 }
 
-// Table build, plain case (2-bit plane, no exception symbol in the allele): a thread hashes 16 CONSECUTIVE positions out
+// Table build (both planes): a thread hashes 16 CONSECUTIVE positions out
 // of one register window - forward key by v_alignbit at a constant shift, the reverse complement slides by one symbol -
 // instead of extracting and reverse-complementing a key from scratch per position (about 50 instructions per visit: the
 // build was vector-issue-bound like the probe, 12 us of a 150 us task).  `f(t4, hx[4], valid[4])` is called for every four
@@ -680,9 +727,23 @@ __device__ __forceinline__ void build_walk16(const uint32_t* tile, const uint32_
 #pragma unroll
     for (int x = 0; x < NWIN; ++x) W[x] = tile[(p0 >> 4) * (BPS / 2) + x];     // p0 is a multiple of 16
     W[NWIN] = 0u;
+    // 4-bit planes: a k-mer that holds a symbol which matches nothing (code 15: a character outside the IUPAC alphabet) is
+    // left out of the table.  Such symbols are all but absent, so the window is tested once and the keys one by one only
+    // when it holds one.
+    bool win_invalid = false;
+    if (BPS == 4) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int x = 0; x < NWIN; ++x) any |= W[x] & (W[x] >> 1) & (W[x] >> 2) & (W[x] >> 3) & 0x11111111u;
+        win_invalid = any != 0u;
+    }
     KT kr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+        if (BPS == 4 && g == 2) {                  // positions 8..15 start one word further on
+#pragma unroll
+            for (int x = 0; x < NWIN; ++x) W[x] = W[x + 1];
+        }
         uint32_t hx[4];
         bool valid[4];
 #pragma unroll
@@ -698,21 +759,27 @@ __device__ __forceinline__ void build_walk16(const uint32_t* tile, const uint32_
                 kr = revcomp_key<BPS, K>(kf);
             } else {
                 const uint32_t sym = (kf.w[KT::NW - 1] >> (KT::TOPBITS - BPS)) & SYM;
+                const uint32_t cs = (BPS == 2) ? (sym ^ 3u) : (sym ^ ((sym & 8u) ? 0u : 3u));   // N / n / invalid keep their code
 #pragma unroll
                 for (int x = KT::NW - 1; x > 0; --x) kr.w[x] = (kr.w[x] << BPS) | (kr.w[x - 1] >> (32 - BPS));
-                kr.w[0] = (kr.w[0] << BPS) | (sym ^ 3u);
+                kr.w[0] = (kr.w[0] << BPS) | cs;
                 kr.w[KT::NW - 1] &= KT::TOPMASK;
             }
             hx[t4] = canon_hash<BPS, K>(kf, kr);
             valid[t4] = (p0 + t < tn) & (!AEXC || ((EX >> t) & KM) == 0ULL);
+            if (BPS == 4 && win_invalid) valid[t4] = valid[t4] && !key_has_invalid<BPS, K>(kf);
         }
         f(g * 4, hx, valid);
     }
 }
 
-// AEXC: the launch holds the pairs whose ALLELE has symbols outside upper-case ACGT (2-bit planes; the host groups them):
-// the table leaves out the k-mers that cover one, runs end before them.  The plain launch carries none of that code.
-template <typename C, int BPS, int K, bool AEXC>
+// EXC (2-bit planes; the host groups the pairs): 1 - the launch holds the pairs whose ALLELE has symbols outside upper-case
+// ACGT: the table leaves out the k-mers that cover one, runs end before them.  2 - the pairs whose READ has such symbols (and
+// whose allele has none): the positions whose k-mer covers one are masked out of the lookup, runs end before them; the
+// exception bits of a wave's strip lie in its slice of the (otherwise unused) etile region.  0 - neither: the plain launch
+// carries none of that code.  Both sides with such symbols are joined on the 4-bit planes.
+constexpr int REXC_WORDS = (JCHUNK + 64 + 64) / 32;     // exception words per strip: its positions, the k-mer, 32 symbols of run
+template <typename C, int BPS, int K, int EXC>
 __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
@@ -790,7 +857,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
         const int g1 = differs ? (int)__builtin_ctzll(differs) : task.n_reads;
         const SeqDesc s2 = seqs[seq2];
         const int nk2 = s2.len - K + 1;
-        constexpr bool exc2 = (BPS == 2) && AEXC;
+        constexpr bool exc2 = (BPS == 2) && EXC == 1;
 
         for (int ts = 0; ts < nk2; ts += TA) {
             const int tn = min(TA, nk2 - ts);
@@ -808,7 +875,9 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
             }
             __syncthreads();
             // ---- build 1/3: bucket sizes (two 16-bit counters per LDS word) --------------------
-            constexpr bool plain2 = (BPS == 2);      // (with or without exception symbols in the allele: see build_walk16)
+            // (the 2-bit planes, and the 4-bit planes up to window size 20: with the five-word keys of 30 and 40 the sixteen unrolled
+            // positions of build_walk16 take 125 registers and spill; those two build key by key)
+            constexpr bool plain2 = (BPS == 2 || K <= 20);           // (both planes, with or without exception symbols in the allele: see build_walk16)
             if (plain2) {
                 for (int p0 = tid * 16; p0 < tn; p0 += 16 * JOIN_THREADS)
                     build_walk16<BPS, K, exc2>(tile, etile, p0, tn, [&](int, const uint32_t (&hx)[4], const bool (&valid)[4]) {
@@ -820,7 +889,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             if (!valid[u]) continue;
                             const uint32_t h = hx[u] >> (32 - JNB_LOG2), fb = hx[u] >> (32 - C::FILT_LOG2);
                             atomicAdd(&start32[h >> 1], 1u << ((h & 1u) * 16));
-                            if (!(fw[u] & (1u << (fb & 31u)))) atomicOr(&filt[fb >> 5], 1u << (fb & 31u));
+                            const uint32_t fm = filt_mask(hx[u], fb);
+                            if ((fw[u] & fm) != fm) atomicOr(&filt[fb >> 5], fm);
                         }
                     });
             } else
@@ -834,7 +904,8 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     const uint32_t hx = canon_hash<BPS, K>(key, rc);
                     const uint32_t h = hx >> (32 - JNB_LOG2), fb = hx >> (32 - C::FILT_LOG2);
                     atomicAdd(&start32[h >> 1], 1u << ((h & 1u) * 16));
-                    if (!(filt[fb >> 5] & (1u << (fb & 31u)))) atomicOr(&filt[fb >> 5], 1u << (fb & 31u));
+                    const uint32_t fm = filt_mask(hx, fb);
+                    if ((filt[fb >> 5] & fm) != fm) atomicOr(&filt[fb >> 5], fm);
                 }
             }
             __syncthreads();
@@ -937,9 +1008,17 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     const uint32_t chunk1 = ri_chunk & 0x7FFFFFFFu;
                     const uint32_t* rplane = plane + (size_t)chunk1 * WPC;
                     const uint32_t* re = e1 + (size_t)chunk1;
-                    const bool exc1 = (BPS == 2) && (ri_chunk >> 31) != 0u;
+                    // (2-bit planes: a read with symbols outside upper-case ACGT is in a launch of its own, EXC == 2)
+                    constexpr bool exc1 = (BPS == 2) && EXC == 2;
                     unsigned long long* out = hits + pr.hit_off;
-                    const bool merge = (BPS == 2) ? !exc1 : (K <= X4_MERGE_MAX_K && s2.n_invalid == 0);
+                    const bool merge = (BPS == 2) ? true : (K <= X4_MERGE_MAX_K && s2.n_invalid == 0);
+                    static_assert(BPS != 2 || (C::THREADS / 64) * REXC_WORDS <= etile_words<C, 2>(), "strip exception bits share the etile region");
+                    const uint32_t* vex = (EXC == 2) ? etile + wave * REXC_WORDS : etile;     // what the verification reads as exception bits
+                    if (exc1) {
+                        // the strip's exception bits (words inside the read's own chunks and padding only)
+                        const int have = ((nk1 + K - 1 + 31) >> 5) + VP_PAD_CHUNKS - (cb >> 5);
+                        for (int x = lane; x < REXC_WORDS; x += 64) (etile + wave * REXC_WORDS)[x] = x < have ? re[(cb >> 5) + x] : 0u;
+                    }
                     // stage this wave's strip of the read: positions cb .. cb+1023 (+ K-1 lookahead)
                     {
                         const int nw = min(rbuf_words<BPS>(), (int)((((size_t)(nk1 + K - 1 - cb)) * BPS + 31) >> 5) + 2);
@@ -1009,7 +1088,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             // (bit 0 spread over the word by one v_bfe_i32; written as `0 - (x & 1)` the compiler turns
                             // it into and + compare + select, two of which cannot share an issue slot; the same happens to the builtin)
                             uint32_t take;
-                            asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(take) : "v"((vm4 >> t4) & (fw >> (fb & 31u))));
+                            asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(take) : "v"((vm4 >> t4) & (fw >> (fb & 31u)) & (fw >> ((hx >> 10) & 31u))));
                             sc[t4] = (s0 | ((s1v - s0) << 16)) & take;
                         }
                         pc.mark(2, pw);                    // keys + bucket bounds issued
@@ -1071,7 +1150,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                                     }
                                     qlen += __popcll(m);
                                     if (qlen >= 128) {
-                                        join_verify<BPS, K, AEXC>(myq, qlen - 128, 128, entries, rbuf, tile, etile, cb, ts, pr.off2, tn,
+                                        join_verify<BPS, K, EXC>(myq, qlen - 128, 128, entries, rbuf, tile, vex, cb, ts, pr.off2, tn,
                                                             nk1, merge, &cnt[r], pr.cap, out);
                                         qlen -= 128;
                                     }
@@ -1104,7 +1183,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                             qlen += (int)tot;
                             if (qlen >= 128) {
                                 pc.mark(4, pw);            // queue fill
-                                join_verify<BPS, K, AEXC>(myq, qlen - 128, 128, entries, rbuf, tile, etile, cb, ts, pr.off2, tn, nk1,
+                                join_verify<BPS, K, EXC>(myq, qlen - 128, 128, entries, rbuf, tile, vex, cb, ts, pr.off2, tn, nk1,
                                                     merge, &cnt[r], pr.cap, out);
                                 qlen -= 128;
                                 pc.mark(5, pw);            // verify + store
@@ -1114,7 +1193,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
                     }
                     // the strip changes: drain
                     if (qlen > 0)
-                        join_verify<BPS, K, AEXC>(myq, 0, qlen, entries, rbuf, tile, etile, cb, ts, pr.off2, tn, nk1, merge, &cnt[r], pr.cap, out);
+                        join_verify<BPS, K, EXC>(myq, 0, qlen, entries, rbuf, tile, vex, cb, ts, pr.off2, tn, nk1, merge, &cnt[r], pr.cap, out);
                     pc.mark(5, pw);
                 }
             }
