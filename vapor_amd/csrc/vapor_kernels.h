@@ -268,7 +268,7 @@ constexpr int JCHUNK = 1024;                      // read positions per wave pas
 // Geometry of the join workgroup: it owns a whole CU's LDS (16 waves, one table of up to 24576 positions
 // in 32768 buckets).  Smaller tables would not raise residency: at ~117 VGPRs four waves per SIMD is the
 // register limit as well.
-struct JoinBig { static constexpr int THREADS = 1024, WPS = 4, TA2 = 24576, TA4 = 16384, NB_LOG2 = 15, FILT_LOG2 = 17, QCAP = 256; };
+struct JoinBig { static constexpr int THREADS = 1024, WPS = 4, TA2 = 24576, TA4 = 21504, NB_LOG2 = 15, FILT_LOG2 = 17, QCAP = 256; };
 // (two workgroups per CU with half a table each were tried and lost: DESIGN.md section 4)
 using JoinCfg = JoinBig;
 
