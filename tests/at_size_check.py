@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE (not collected by pytest): checks the rows sampled by tools/run_at_size.py against the CPU twin.
+
+tools/run_at_size.py runs BASELINE.json configs[3] / configs[4] at their stated sizes through the product CLI on the GPU and
+keeps 400 of the output rows.  This script builds the same base world from the recorded seed, runs its loci through the SAME
+CLI with the CPU twin of the C ABI behind it (oracle/_build/libvapor_cpu.so: the oracle; VAPOR_HIP_LIB), and compares every
+sampled row with the twin's row for the locus it is a tile of - text for text (QS, GS, GT, GQ and the per-read scores).
+
+usage: python tests/at_size_check.py gpurun_out/r3_cfg5_at_size.json"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def twin_rows(rec):
+    """The base world's rows from the CPU twin (a child process: the library is chosen at load time)."""
+    from oracle import oracle as orc
+    orc.build()
+    twin = orc.build_twin()
+    out = tempfile.mktemp(suffix=".json")
+    env = dict(os.environ, VAPOR_HIP_LIB=twin, VAPOR_QC_SEED=str(rec["qc_seed"]), PYTHONPATH=ROOT, VAPOR_HOST_PROCS="0")
+    n = rec["base_loci"] if rec["config"] == "cfg5" else rec["base_loci"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), rec["config"], "--loci", str(n), "--base", str(rec["base_loci"]),
+           "--out", out, "--all-rows"]
+    subprocess.check_call(cmd, env=env, stdout=subprocess.DEVNULL)
+    return json.load(open(out))
+
+
+def main():
+    rec = json.load(open(sys.argv[1]))
+    tw = twin_rows(rec)
+    strip = re.compile(r"\.t\d+")
+    by_key = {}
+    for _t, row in tw["sample"]:
+        by_key[strip.sub("", row.split("\tVaPoR", 1)[0]).split("\t")[0:5].__str__()] = strip.sub("", row)
+    bad = 0
+    for t, row in rec["sample"]:
+        want = by_key.get(strip.sub("", row).split("\t")[0:5].__str__())
+        if want is None or want != strip.sub("", row):
+            bad += 1
+            if bad <= 5:
+                print("row %d differs:\n  gpu : %s\n  twin: %s" % (t, strip.sub("", row)[:300], (want or "<no such locus>")[:300]))
+    scored = sum(1 for _t, r in rec["sample"] if "\tNA" not in r)
+    print("%s: %d sampled rows of %d (%d with scores) against the CPU twin's %d base rows: %d differ"
+          % (rec["config"], len(rec["sample"]), rec["rows"], scored, len(tw["sample"]), bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -660,3 +660,39 @@ def test_worker_that_dies_inside_its_reply_is_a_lost_worker():
         procs = list(w.procs)
         w.close()
     assert all(p.poll() is not None for p in procs)
+
+
+def test_memory_backend_native_chop_equals_the_per_record_statement(monkeypatch):
+    """MemorySamtools.chop (one vapor_chop_records call per region over the contig's records as arrays) against the per-record
+    statement of chop_pacbio_read_by_pos (SF:339-354) it replaces in the synthetic worlds: same reads, offsets and miss_bp for
+    random regions, clipped / inserted / deleted CIGAR starts (the SURVEY's known answers among them), and the IndexError of
+    a record without CIGAR."""
+    from vapor_amd import seqio
+    w = synth.make_world(seed=91, n_loci=6, svtypes=("DEL", "TANDUP", "INV", "INS"), span_range=(150, 2500), read_len=5000, n_reads=14)
+    chrom = "c1"
+    base = w.contigs[chrom]
+    extra = [("k1", 1000, "100S500M20I300M"), ("k2", 1000, "50M300D500M"), ("k3", 900, "10I400M5D400M"), ("k4", 1190, "3S20M2000D900M"),
+             ("k5", 1200, "900M"), ("k6", 1201, "900M"), ("k7", 700, "1000=")]
+    for name, pos, cg in extra:
+        n_q = sum(int(n) for n, c in __import__("re").findall(r"(\d+)([MIDNSHP=X])", cg) if c in "SIM=")
+        n_r = sum(int(n) for n, c in __import__("re").findall(r"(\d+)([MIDNSHP=X])", cg) if c in "MD=")
+        w.reads[chrom].append(synth.SamRecord(name, chrom, pos, cg, synth.random_dna(np.random.default_rng(pos), n_q), n_r))
+    be = seqio.MemorySamtools(w)
+    rng = np.random.default_rng(5)
+    n_kept = 0
+    for _ in range(300):
+        c = "c%d" % int(rng.integers(1, 7))
+        a = int(rng.integers(1, 3000)); wd = int(rng.integers(1, 2500)); f = int(rng.choice([0, 1, 50, 200, 500]))
+        monkeypatch.setenv("VAPOR_MEMORY_CHOP", "records")
+        ref = be.chop("x.bam", c, a, a + wd, f)
+        monkeypatch.delenv("VAPOR_MEMORY_CHOP")
+        assert be.chop("x.bam", c, a, a + wd, f) == ref, (c, a, wd, f)
+        n_kept += len(ref)
+    assert n_kept > 300
+    # the known answers of cigar2alignstart_by_pos (SURVEY 8f-1) through the batch helper
+    got = {r[2]: r for r in be.chop("x.bam", chrom, 1200, 1400, 500)}
+    assert got["k1"][1] == 0 and got["k2"][1] == 150 and "k6" not in got and "k5" in got
+    w.reads[chrom].append(synth.SamRecord("nocigar", chrom, 1100, "*", "ACGT" * 300, 1200))
+    be2 = seqio.MemorySamtools(w)
+    with pytest.raises(IndexError):
+        be2.chop("x.bam", chrom, 1200, 1400, 500)

@@ -1,0 +1,90 @@
+"""Host-side cost of the driver pipeline WITHOUT a device (development container): an engine whose plans answer with constant
+statistics and scores, so that what is timed is everything the Python side does per locus - BED parsing, the driver
+generators, read extraction from the in-memory world, the assembly of sequence sets / pair tables / read tables, result rows.
+Not a product path and not a measurement of the product: a profiler's harness.  usage: python tools/prof_host.py [n_loci] [--profile]"""
+import cProfile
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from vapor_amd import _lib as L
+from vapor_amd import cli, pipeline, seqio, synth
+from vapor_amd import simple_function as SF
+from vapor_amd.finish import result_organize_ins
+
+
+class _SS:
+    def __init__(self, seqs):
+        self.n = len(seqs)
+        self.lens = np.fromiter(map(len, seqs), dtype=np.int32, count=self.n)
+        self.n_invalid = np.zeros(self.n, dtype=np.int32)
+        self.n_exc = np.zeros(self.n, dtype=np.int32)
+
+    def close(self):
+        pass
+
+
+class _Plan:
+    def __init__(self, ss, pairs):
+        self.n = len(pairs)
+
+    def run(self):
+        st = np.zeros((max(self.n, 1), 16), dtype=np.int64)
+        st[:, 0] = 1000; st[:, 7] = 1000
+        return st[:self.n]
+
+    def set_reads(self, reads, n_loci):
+        self.read_scores = np.full(max(len(reads), 1), 0.5)
+
+    def run_loci(self, device_out=0, want_host=True, want_scores=False):
+        return None
+
+    def close(self):
+        pass
+
+
+class NullEngine:
+    def seqset(self, seqs, upper=None):
+        return _SS(seqs)
+
+    def plan(self, ss, pairs):
+        return _Plan(ss, pairs)
+
+
+args = sys.argv[1:]
+n = int(args[0]) if args and args[0].isdigit() else 2000
+svtypes = tuple(args[args.index("--svtypes") + 1].split(",")) if "--svtypes" in args else ("DEL", "DEL", "INV", "INS")
+t0 = time.perf_counter()
+w = synth.make_world(seed=11, n_loci=n, svtypes=svtypes, span_range=(100, 4000), read_len=9500, n_reads=20)
+print("world of %d loci in %.1fs" % (n, time.perf_counter() - t0), flush=True)
+tmp = tempfile.mkdtemp()
+bed = os.path.join(tmp, "in.bed")
+open(bed, "w").write(synth.bed_text(w))
+seqio.set_backend(seqio.MemorySamtools(w))
+bed_info = cli.bed_info_readin(bed, tmp)
+pipeline._engine = NullEngine()
+
+
+def run():
+    jobs = cli.bed_jobs(bed_info, 3, "x.bam", "ref.fa", tmp + "/", "s")
+    scores = cli.score_jobs(jobs, 2048, None)
+    rows = []
+    for j, sc in zip(jobs, scores):
+        res = result_organize_ins([j.key, sc])
+        rows.append(SF.format_output_row(res[0].split(':') + [j.row_prefix] + res[1:]))
+    return rows
+
+
+run()
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); rows = run(); best = min(best, time.perf_counter() - t0)
+print("%d loci in %.3f s -> %.1f loci/s of host work alone (best of 3; %.1f us per locus)" % (len(rows), best, len(rows) / best, best / len(rows) * 1e6))
+if "--profile" in args:
+    cProfile.run("run()", "/tmp/host.prof")
+    pstats.Stats("/tmp/host.prof").sort_stats("tottime").print_stats(28)

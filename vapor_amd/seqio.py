@@ -220,11 +220,87 @@ class MemorySamtools:
     def fetch_seq(self, ref: str, chrom: str, start: int, end: int) -> str:
         return self.world.fetch(chrom, start, end) if chrom in self.world.contigs else ""
 
+    # chop_pacbio_read_by_pos in one native call per region: the contig's records as arrays (binary CIGARs, made once per
+    # contig), the region rule / CIGAR walk / keep rules in the library's host helper (vapor_chop_records), only the kept
+    # reads sliced here.  The per-record path above (records + cigar2alignstart_by_pos per read) stays the statement it is
+    # tested against; VAPOR_MEMORY_CHOP=records selects it.
+    _OPS = {c: i for i, c in enumerate("MIDNSHP=X")}
+
+    def _arrays(self, chrom: str):
+        cache = self.__dict__.setdefault("_chop_cache", {})
+        recs = self.world.reads.get(chrom, ())
+        key = id(recs)                       # (contigs that share one record list - tiled worlds - share its arrays)
+        got = cache.get(key)
+        if got is None or got[0] is not recs:
+            import numpy as np
+            per = [cigar_to_ops(r.cigar) for r in recs]
+            off = np.concatenate(([0], np.cumsum([len(x) for x in per]))) if per else np.zeros(1, dtype=np.int64)
+            ops = np.concatenate(per) if per and int(off[-1]) else np.zeros(1, dtype=np.uint32)
+            arrs = (np.array([r.pos for r in recs], dtype=np.int64), np.array([r.ref_span for r in recs], dtype=np.int64),
+                    np.asarray(off, dtype=np.int64), np.ascontiguousarray(ops, dtype=np.uint32),
+                    np.array([len(r.seq) for r in recs], dtype=np.int64), np.zeros(2 * max(len(recs), 1), dtype=np.int64),
+                    np.zeros(max(len(recs), 1), dtype=np.uint8))
+            # (the addresses once: a `.ctypes` view per array and call costs more than the walk itself)
+            got = (recs, arrs, tuple(a.ctypes.data for a in arrs))
+            if len(cache) > 4096:
+                cache.clear()
+            cache[key] = got
+        return got
+
+    def chop(self, bam: str, chrom: str, start: int, end: int, flank_length):
+        if os.environ.get("VAPOR_MEMORY_CHOP", "") == "records":
+            return _chop_records(self.records(bam, chrom, start, end), start, end, flank_length)
+        recs, arrs, ptr = self._arrays(chrom)
+        if not recs:
+            return []
+        fn = self.__dict__.get("_chop_fn")
+        if fn is None:
+            from . import _lib
+            fn = self.__dict__["_chop_fn"] = _lib.load().vapor_chop_records
+        start, end = int(start), int(end)
+        if fn(len(recs), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], start, end, int(flank_length), ptr[5], ptr[6]) != 0:
+            raise IndexError("string index out of range")      # what '' [1] raises in SF:331
+        kept = arrs[6].nonzero()[0]
+        if not len(kept):
+            return []
+        qm = arrs[5][:2 * len(recs)].tolist()
+        out = []
+        for t in kept.tolist():
+            q0, miss = qm[2 * t], qm[2 * t + 1]
+            r = recs[t]
+            out.append([r.seq[q0:q0 + (end - start - miss)] if q0 >= 0 else r.seq[q0:][:end - start - miss], miss, r.qname])
+        return out
+
     def isfile(self, path: str) -> bool:
         return True
 
     def fai_lines(self, ref: str) -> Iterable[str]:
         return ["%s\t%d\t0\t60\t61" % (k, len(v)) for k, v in self.world.contigs.items()]
+
+
+def cigar_to_ops(cigar: str):
+    """CIGAR text -> the binary operations of a BAM record (uint32: length << 4 | code, codes "MIDNSHP=X"), with numpy
+    (a long read's CIGAR holds thousands of operations).  Characters that are neither digits nor operations end a number
+    and are skipped with it, as the regular expression of cigar2alignstart_by_pos (SF:313) would."""
+    import numpy as np
+    b = np.frombuffer(cigar.encode("ascii", "replace"), dtype=np.uint8)
+    if b.size == 0:
+        return np.zeros(0, dtype=np.uint32)
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate(b"MIDNSHP=X"):
+        code[c] = i
+    is_digit = (b >= 48) & (b <= 57)
+    # every non-digit ends a number; it counts as an operation when it is one of the nine letters and digits precede it
+    ends = np.flatnonzero(~is_digit)
+    starts = np.concatenate(([0], ends[:-1] + 1))
+    nd = ends - starts
+    ok = (code[b[ends]] != 255) & (nd > 0)
+    ends, starts, nd = ends[ok], starts[ok], nd[ok]
+    val = np.zeros(len(ends), dtype=np.int64)
+    for j in range(int(nd.max()) if len(nd) else 0):
+        has = nd > j
+        val[has] = val[has] * 10 + (b[starts[has] + j].astype(np.int64) - 48)
+    return ((val << 4) | code[b[ends]].astype(np.int64)).astype(np.uint32)
 
 
 def set_backend(b) -> None:
@@ -351,6 +427,12 @@ def chop_pacbio_read_by_pos(bam_in_new, chrom, start, end, flank_length):
             if not f or f[0] == "@":
                 continue
             recs.append((f[0], f[3], f[5], f[9]))
+    return _chop_records(recs, start, end, flank_length)
+
+
+def _chop_records(recs, start, end, flank_length):
+    """The body of chop_pacbio_read_by_pos (SF:345-353) over (qname, pos, cigar, seq) records."""
+    out = []
     for qname, pos, cigar, seq in recs:
         if int(pos) < start + 1:
             q0, miss_bp = cigar2alignstart_by_pos(cigar, int(pos), start, end)
