@@ -11,6 +11,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                      # (kernel_source_id: bench.py quotes these files only for the source they were measured on)
 rnd, workload, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
@@ -64,6 +66,12 @@ for name, c in agg.items():
                        "fabric traffic 2 % of HBM peak" if name == "join_kernel" else
                        "; the rest is workgroup start-up and dependent global/LDS round trips"))
         util[name] = u
+SRC = bench.kernel_source_id()
+if traffic:
+    traffic["source_id"] = SRC
+    traffic["measured_with"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_run.sh: bench.py --plans 1 --passes-per-step 1"
+if util:
+    util["source_id"] = SRC
 if traffic:
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, workload)), "w"), indent=1)
 if util:
