@@ -304,10 +304,35 @@ def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
     t0 = time.perf_counter()
     mine = vdist.my_share(len(jobs))
     local: dict = {}
-    for a in range(0, len(mine), max(chunk, 1)):
+
+    def one_chunk(a, engine=None):
         part = mine[a:a + chunk]
         todo = [t for t in part if jobs[t].make is not None]
-        res = pipeline.run_batch([jobs[t].make() for t in todo], figure_fn=figure_fn)
+        res = pipeline.run_batch([jobs[t].make() for t in todo], engine=engine, figure_fn=figure_fn)
+        return part, todo, res
+
+    starts = list(range(0, len(mine), max(chunk, 1)))
+    in_flight = max(1, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "2")))
+    if len(starts) >= 2 and in_flight >= 2:
+        # Two chunks in flight (the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage): each on a thread
+        # with a library context of its own (one host thread per context), so that the host preparation of one chunk - allele
+        # strings, read extraction, tables - runs while the other waits for its uploads and kernels; on the device the two
+        # contexts' streams overlap as well.  Results are taken in chunk order.
+        from concurrent.futures import ThreadPoolExecutor
+        engines = pipeline.get_engines(min(in_flight, len(starts)))
+        with ThreadPoolExecutor(max_workers=len(engines)) as pool:
+            import threading
+            slot = {}
+            lock = threading.Lock()
+
+            def work(a):
+                with lock:
+                    k = slot.setdefault(threading.get_ident(), len(slot))
+                return one_chunk(a, engines[k])
+            done = list(pool.map(work, starts))
+    else:
+        done = [one_chunk(a) for a in starts]
+    for part, todo, res in done:
         for t, r in zip(todo, res):
             local[t] = r
         for t in part:

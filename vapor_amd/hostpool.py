@@ -19,6 +19,7 @@ from concurrent.futures import Future, ThreadPoolExecutor
 from typing import Optional
 
 _pool: Optional["Workers"] = None
+_pool_lock = threading.Lock()
 
 
 def n_workers() -> int:
@@ -122,12 +123,14 @@ def get() -> Optional[Workers]:
     """The process-wide pool, started on first use; None when the work is to be done by the caller."""
     global _pool
     if _pool is None:
-        n = n_workers()
-        if n < 2:
-            return None
-        import atexit
-        _pool = Workers(n)
-        atexit.register(shutdown)
+        with _pool_lock:                           # (chunks of a run are scored on two threads)
+            if _pool is None:
+                n = n_workers()
+                if n < 2:
+                    return None
+                import atexit
+                _pool = Workers(n)
+                atexit.register(shutdown)
     return _pool
 
 

@@ -29,8 +29,25 @@ def get_engine():
 
 
 def set_engine(e) -> None:
-    global _engine
+    global _engine, _more_engines
     _engine = e
+    _more_engines = []
+
+
+_more_engines: list = []
+
+
+def get_engines(n: int) -> list:
+    """`n` engines on the current device, the default one first: one per thread that scores chunks (a library context serves
+    one host thread).  An engine that is not this package's own (the tests' stand-in) is shared: it has no such rule."""
+    first = get_engine()
+    from .engine import Engine
+    if not isinstance(first, Engine):
+        return [first] * n
+    from .dist import _device_ordinal
+    while len(_more_engines) < n - 1:
+        _more_engines.append(Engine(_device_ordinal()))
+    return [first] + _more_engines[:n - 1]
 
 
 class _SeqTable:

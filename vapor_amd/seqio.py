@@ -238,8 +238,7 @@ class MemorySamtools:
             ops = np.concatenate(per) if per and int(off[-1]) else np.zeros(1, dtype=np.uint32)
             arrs = (np.array([r.pos for r in recs], dtype=np.int64), np.array([r.ref_span for r in recs], dtype=np.int64),
                     np.asarray(off, dtype=np.int64), np.ascontiguousarray(ops, dtype=np.uint32),
-                    np.array([len(r.seq) for r in recs], dtype=np.int64), np.zeros(2 * max(len(recs), 1), dtype=np.int64),
-                    np.zeros(max(len(recs), 1), dtype=np.uint8))
+                    np.array([len(r.seq) for r in recs], dtype=np.int64))
             # (the addresses once: a `.ctypes` view per array and call costs more than the walk itself)
             got = (recs, arrs, tuple(a.ctypes.data for a in arrs))
             if len(cache) > 4096:
@@ -248,7 +247,7 @@ class MemorySamtools:
         return got
 
     def chop(self, bam: str, chrom: str, start: int, end: int, flank_length):
-        if os.environ.get("VAPOR_MEMORY_CHOP", "") == "records":
+        if _memory_chop_by_records():
             return _chop_records(self.records(bam, chrom, start, end), start, end, flank_length)
         recs, arrs, ptr = self._arrays(chrom)
         if not recs:
@@ -257,13 +256,17 @@ class MemorySamtools:
         if fn is None:
             from . import _lib
             fn = self.__dict__["_chop_fn"] = _lib.load().vapor_chop_records
+        import numpy as np
+        # (the answers go to arrays of the call's own: chunks of a run are scored on two threads, and tiled worlds share a
+        # record list between contigs)
+        qm_a, keep_a = np.empty(2 * len(recs), dtype=np.int64), np.empty(len(recs), dtype=np.uint8)
         start, end = int(start), int(end)
-        if fn(len(recs), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], start, end, int(flank_length), ptr[5], ptr[6]) != 0:
+        if fn(len(recs), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], start, end, int(flank_length), qm_a.ctypes.data, keep_a.ctypes.data) != 0:
             raise IndexError("string index out of range")      # what '' [1] raises in SF:331
-        kept = arrs[6].nonzero()[0]
+        kept = keep_a.nonzero()[0]
         if not len(kept):
             return []
-        qm = arrs[5][:2 * len(recs)].tolist()
+        qm = qm_a.tolist()
         out = []
         for t in kept.tolist():
             q0, miss = qm[2 * t], qm[2 * t + 1]
@@ -276,6 +279,13 @@ class MemorySamtools:
 
     def fai_lines(self, ref: str) -> Iterable[str]:
         return ["%s\t%d\t0\t60\t61" % (k, len(v)) for k, v in self.world.contigs.items()]
+
+
+def _memory_chop_by_records() -> bool:
+    # (os.environ is a mapping with an encode per lookup: 5 us a call, asked once per locus)
+    e = os.environ
+    v = e._data.get(b"VAPOR_MEMORY_CHOP") if hasattr(e, "_data") else e.get("VAPOR_MEMORY_CHOP")
+    return v in (b"records", "records")
 
 
 def cigar_to_ops(cigar: str):
