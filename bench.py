@@ -256,6 +256,7 @@ def main() -> None:
     if rank == 0 and world == 1:
         if not args.no_extras:
             extras["inclusive"] = inclusive_rate(eng, w, wl)
+            extras["pipeline"] = pipeline_rate()
             if args.sub and args.sub != args.workload:
                 extras["sub"] = sub_record(eng, wl, args.sub, torch, cpu_seconds=0.0 if args.no_cpu else min(args.cpu_seconds, 10.0))
         if not args.no_cpu:
@@ -312,6 +313,8 @@ def main() -> None:
             "cpu_baseline": cpu,
         }
         out.update(extras)
+        if "pipeline" in extras and "value" in extras["pipeline"]:
+            out["pipeline_value"] = extras["pipeline"]["value"]    # the drivers end to end, one process (host-bound)
         if "inclusive" in extras:
             # the same batch when every pass also pays upload + packing, the window self plots, planning and a blocking pass
             out["inclusive_value"] = extras["inclusive"]["value"]
@@ -383,6 +386,46 @@ def inclusive_rate(eng, w, wl, reps: int = 6):
             "includes": "host ASCII -> pinned staging -> H2D -> pack_kernel; %d self dot plots (k = 10) for window_size_refine's "
                         "integer part; vapor_plan_create + set_reads; one blocking join -> clean -> finish; records to host. "
                         "Median of %d batches, one at a time" % (len(allele_idx), reps)}
+
+
+def pipeline_rate(n_loci: int = 400):
+    """The product path beside the kernel rate: the reference-named drivers (vapor_vali/vapor:334-367, SF:1701-1933) over a
+    seeded in-memory world - BED parsing, read extraction and trimming, allele strings, window_size_refine, dot plots and
+    scores on the device, result rows - in this process, figures off.  Host-bound: this is the rate a `vapor bed` run sees
+    per process (tools/bench_pipeline.py, tools/run_at_size.py measure it at size and from FASTA/BAM files)."""
+    import tempfile
+    try:
+        from vapor_amd import cli, pipeline, seqio, synth
+        from vapor_amd import simple_function as SF
+        from vapor_amd.finish import result_organize_ins
+        w = synth.make_world(seed=11, n_loci=n_loci, svtypes=("DEL", "DEL", "INV", "INS"), span_range=(100, 4000), read_len=9500, n_reads=20)
+        tmp = tempfile.mkdtemp(prefix="vapor_bench_")
+        bed = os.path.join(tmp, "in.bed")
+        open(bed, "w").write(synth.bed_text(w))
+        seqio.set_backend(seqio.MemorySamtools(w))
+        try:
+            bed_info = cli.bed_info_readin(bed, tmp)
+
+            def run():
+                jobs = cli.bed_jobs(bed_info, 3, "x.bam", "ref.fa", tmp + "/", "s")
+                scores = cli.score_jobs(jobs, 2048, None)
+                return [SF.format_output_row((lambda res: res[0].split(':') + [j.row_prefix] + res[1:])(result_organize_ins([j.key, sc])))
+                        for j, sc in zip(jobs, scores)]
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                run()
+                best, rows = 1e9, []
+                for _ in range(3):
+                    t0 = time.perf_counter(); rows = run(); best = min(best, time.perf_counter() - t0)
+        finally:
+            seqio.set_backend(None)
+        scored = sum(1 for r in rows if "\tNA" not in r)
+        return {"value": round(len(rows) / best, 1), "unit": "loci/s", "loci": len(rows), "loci_with_scores": scored,
+                "includes": "cli.bed_jobs -> drivers -> pipeline.run_batch (one sequence set and plan per round) -> result rows; in-memory "
+                            "world of %d DEL/INV/INS loci x 20 reads of 9.5 kb, one process, figures off; best of 3" % n_loci}
+    except Exception as e:      # noqa: BLE001 - a side record must not take the headline down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def sub_record(eng, wl, name, torch, passes: int = 12, cpu_seconds: float = 0.0):

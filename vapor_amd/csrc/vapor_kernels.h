@@ -1974,15 +1974,17 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
         __syncthreads();
         pc.mark(9, tid == 0);                      // what the nested stamps left of clean_body
         // four flag bytes per store (the pair's slot is padded to a multiple of four): the public bits of four records
+        // (a thread takes the flags of ONE record - consecutive lanes read consecutive records - and the four lanes of a
+        // quad put their bytes together with two quad permutes; the quad's first lane stores the word)
         {
             const uint32_t* hi = reinterpret_cast<const uint32_t*>(lrecs) + 1;
             uint32_t* gf4 = reinterpret_cast<uint32_t*>(gflags);
-            for (int h = tid; h < (n + 3) / 4; h += CLEAN_THREADS) {
-                uint32_t w = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (4 * h + q < n) w |= ((hi[2 * (4 * h + q)] >> 6) & 7u) << (8 * q);
-                gf4[h] = w;
+            const int n4 = (n + 3) & ~3;
+            for (int h = tid; h < n4; h += CLEAN_THREADS) {           // (n4 and CLEAN_THREADS are multiples of 4: whole quads)
+                uint32_t x = h < n ? (((hi[2 * h] >> 6) & 7u) << (8 * (h & 3))) : 0u;
+                x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                x |= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+                if ((h & 3) == 0) gf4[h >> 2] = x;
             }
         }
         pc.mark(10, tid == 0);
