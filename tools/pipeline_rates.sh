@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_pipeline_rates.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03}_pipeline_rates.txt
 echo "# end-to-end rates of the round's final build on one MI355X box (16-core CPU quota); commands from the repo root" > $O
 run() { echo "\$ $*" >> $O; "$@" 2>&1 | grep -E "loci/s|identical" | grep -v Warning >> $O; }
 run python tools/bench_pipeline.py 2000

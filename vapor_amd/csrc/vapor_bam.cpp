@@ -114,7 +114,7 @@ static bool crc_ok(const uint8_t* blk, int bsize, const uint8_t* out, int isize)
 {
     const uint8_t* t = blk + bsize - 8;
     const uint32_t want = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)isize) == want;
+    return vapor_inflate::crc32_fast(out, (size_t)isize) == want;
 }
 
 static bool inflate_block(const uint8_t* blk, int bsize, uint8_t* out, int isize, vapor_inflate::Decoder& dec)

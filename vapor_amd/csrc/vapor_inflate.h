@@ -378,4 +378,38 @@ inline bool inflate_raw(const uint8_t* in, size_t in_n, uint8_t* out, size_t out
     return o == o_end;
 }
 
+// CRC-32 of a BGZF block's data (the gzip polynomial, reflected 0xEDB88320), sixteen bytes a step through sixteen
+// tables made from the polynomial at first use (slicing-by-16: about four times the byte-at-a-time loop of the system zlib,
+// whose 1.2 GB/s would cost a block half as much again as inflating it).
+struct Crc32Tables {
+    uint32_t t[16][256];
+    Crc32Tables()
+    {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 16; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFFu];
+    }
+};
+inline uint32_t crc32_fast(const uint8_t* p, size_t n)
+{
+    static const Crc32Tables T;
+    uint32_t c = ~0u;
+    while (n >= 16) {
+        uint32_t a, b, d, e;
+        memcpy(&a, p, 4); memcpy(&b, p + 4, 4); memcpy(&d, p + 8, 4); memcpy(&e, p + 12, 4);     // (little-endian host)
+        a ^= c;
+        c = T.t[15][a & 0xFFu] ^ T.t[14][(a >> 8) & 0xFFu] ^ T.t[13][(a >> 16) & 0xFFu] ^ T.t[12][a >> 24] ^
+            T.t[11][b & 0xFFu] ^ T.t[10][(b >> 8) & 0xFFu] ^ T.t[9][(b >> 16) & 0xFFu] ^ T.t[8][b >> 24] ^
+            T.t[7][d & 0xFFu] ^ T.t[6][(d >> 8) & 0xFFu] ^ T.t[5][(d >> 16) & 0xFFu] ^ T.t[4][d >> 24] ^
+            T.t[3][e & 0xFFu] ^ T.t[2][(e >> 8) & 0xFFu] ^ T.t[1][(e >> 16) & 0xFFu] ^ T.t[0][e >> 24];
+        p += 16; n -= 16;
+    }
+    while (n--) c = T.t[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
+    return ~c;
+}
+
 }  // namespace vapor_inflate
