@@ -1285,13 +1285,18 @@ __device__ __forceinline__ RecV rec_decode(unsigned long long r)
 {
     RecV v;
     v.i0 = VREC_I(r); v.j0 = VREC_J(r);
+    // A record of ONE dot has no direction: everything the cleaning computes of it - i - j, i + j, the counts, the closed
+    // forms - is the same whichever strand it came from.  The join writes reverse-complement dots as single-dot records
+    // (a quarter of a noisy pair's records), so treating those as strandless keeps every wave out of the dot-by-dot
+    // branches that reverse-complement RUNS need (the format allows them; callers of vapor_clean_hits may bring them).
     if (LFMT) { v.len = (int)((r >> 32) & 31ull) + 1; v.rc = (bool)((r >> 37) & 1ull); }
-    else { v.len = VREC_LEN(r); v.rc = VREC_RC(r); }
+    else { v.len = VREC_LEN(r); v.rc = VREC_RC(r) && v.len > 1; }
     return v;
 }
 __device__ __forceinline__ unsigned long long rec_to_lds(unsigned long long r)
 {
-    return (r & 0xFFFFFFFFull) | ((unsigned long long)((uint32_t)(VREC_LEN(r) - 1) | ((uint32_t)VREC_RC(r) << 5)) << 32);
+    const uint32_t len = (uint32_t)VREC_LEN(r);
+    return (r & 0xFFFFFFFFull) | ((unsigned long long)((len - 1u) | ((uint32_t)(VREC_RC(r) && len > 1u) << 5)) << 32);
 }
 // The flag byte of record h.  Global path (clean_big_kernel): a byte beside the record.  LDS path: bits 38..45 of the
 // staged record itself (no flag array: a byte per record less in LDS, and one read gives record and flags), the group
@@ -1391,12 +1396,9 @@ struct FinalAcc {
 __device__ __forceinline__ void mark_values(uint32_t* bm, uint32_t v0, int len, bool strided)
 {
     const uint32_t w = v0 >> 5, sh = v0 & 31u;
-    if (!strided || len == 1) {
-        const uint32_t bit = 1u << sh;
-        if (!(bm[w] & bit)) atomicOr(&bm[w], bit);
-        return;
-    }
-    const unsigned long long pat = 0x5555555555555555ull >> (64 - 2 * len);     // len <= 32
+    // (one straight line for single values and strided runs: a wave holds both kinds, and a branch between them made
+    // every wave walk both sides)
+    const unsigned long long pat = strided ? (0x5555555555555555ull >> (64 - 2 * len)) : 1ull;     // len <= 32
     const uint32_t lo = (uint32_t)pat, hi = (uint32_t)(pat >> 32);
     const uint32_t m0 = lo << sh;
     const uint32_t m1 = sh ? ((lo >> (32u - sh)) | (hi << sh)) : hi;
