@@ -241,14 +241,14 @@ int vapor_bam_chop(vapor_bam* bam, int32_t tid, int64_t start, int64_t end, int6
                    const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
                    int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need);
 /*
- * chop_pacbio_read_by_pos (SF:339-354) over n alignment records the caller holds in memory as arrays (no file, no device):
+ * chop_pacbio_read_by_pos (SF:339-354) over n alignment records the caller holds in memory (no file, no device):
  * pos 1-based leftmost aligned base, ref_span the reference bases a record is taken to cover (the region rule of
- * `samtools view`), ops_off[n+1] / ops the binary CIGARs (length << 4 | code, "MIDNSHP=X"), seq_len the read lengths.
- * keep[r] = 1 and q0_miss[2r], q0_miss[2r+1] = offset into the read and miss_bp for the reads the reference would keep
- * (POS < start + 1, miss_bp <= flank / 2, more than end - start - miss_bp bases from the offset on); the caller slices.
- * VAPOR_E_ARG for a record without CIGAR operation (IndexError in the reference, SF:331).
+ * `samtools view`), cigar[r] the record's CIGAR as text (a C string, walked only as far as the window start), seq_len the
+ * read lengths.  keep[r] = 1 and q0_miss[2r], q0_miss[2r+1] = offset into the read and miss_bp for the reads the reference
+ * would keep (POS < start + 1, miss_bp <= flank / 2, more than end - start - miss_bp bases from the offset on); the caller
+ * slices.  VAPOR_E_ARG for a record without CIGAR operation (IndexError in the reference, SF:331).
  */
-int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, const int64_t* ops_off, const uint32_t* ops,
+int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, const char* const* cigar,
                        const int64_t* seq_len, int64_t start, int64_t end, int64_t flank, int64_t* q0_miss, uint8_t* keep);
 /*
  * The block decoder of vapor_bam_chop by itself (host, no device): a raw DEFLATE stream (RFC 1951; the payload of a BGZF

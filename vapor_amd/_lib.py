@@ -132,7 +132,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_bam_chop.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp,
                                  vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), vp]
     L.vapor_inflate_raw.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64]
-    L.vapor_chop_records.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp]
+    L.vapor_chop_records.argtypes = [ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp]
     L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
     L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]
     L.vapor_dotplot_batch.argtypes = [vp, vp, ctypes.c_int64, vp, i32p, ctypes.c_int64, i64p, i64p]

@@ -392,40 +392,47 @@ extern "C" int vapor_bam_chop(vapor_bam* b, int32_t tid, int64_t start, int64_t 
 }
 
 // chop_pacbio_read_by_pos (SF:339-354) over alignment records that are in memory already (a caller that holds its reads as
-// arrays - the synthetic worlds of the tests and benches, a reader of another format): the region rule of `samtools view`,
-// the reference's `POS < start + 1`, the CIGAR walk to the window start (cigar2alignstart_by_pos, SF:309-337, binary
-// operations as in a BAM record), `miss_bp > flank / 2` and `len(read[q0:]) > end - start - miss_bp`, for n records in one
-// call.  keep[r] = 1 and q0_miss[2r], q0_miss[2r+1] = offset into the read and miss_bp for the reads the reference keeps.
-// VAPOR_E_ARG for a record without CIGAR operation that reaches the walk (IndexError in the reference, SF:331).
-extern "C" int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, const int64_t* ops_off,
-                                  const uint32_t* ops, const int64_t* seq_len, int64_t start, int64_t end, int64_t flank,
+// objects - the synthetic worlds of the tests and benches, a reader of another format): the region rule of `samtools view`,
+// the reference's `POS < start + 1`, the CIGAR walk to the window start (cigar2alignstart_by_pos, SF:309-337, over the CIGAR
+// TEXT, as vapor_cigar2alignstart walks it: the walk ends where the reference cursor passes the window start, a few dozen
+// operations into a long read's thousands, so nothing is parsed ahead of time), `miss_bp > flank / 2` and
+// `len(read[q0:]) > end - start - miss_bp`, for n records in one call.  keep[r] = 1 and q0_miss[2r], q0_miss[2r+1] = offset
+// into the read and miss_bp for the reads the reference keeps.  VAPOR_E_ARG for a record without CIGAR operation that
+// reaches the walk (IndexError in the reference, SF:331).
+extern "C" int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, const char* const* cigar,
+                                  const int64_t* seq_len, int64_t start, int64_t end, int64_t flank,
                                   int64_t* q0_miss, uint8_t* keep)
 {
-    if (n < 0 || (n && (!pos || !ref_span || !ops_off || !seq_len || !q0_miss || !keep)))
+    if (n < 0 || (n && (!pos || !ref_span || !cigar || !seq_len || !q0_miss || !keep)))
         return bfail(VAPOR_E_ARG, "vapor_chop_records: null argument");
     for (int32_t r = 0; r < n; ++r) {
         keep[r] = 0;
         if (!(pos[r] <= end && pos[r] + ref_span[r] - 1 >= start)) continue;      // not in the region
         if (!(pos[r] < start + 1)) continue;
-        const int64_t o0 = ops_off[r], o1 = ops_off[r + 1];
-        if (o1 <= o0 || !ops) return bfail(VAPOR_E_ARG, "vapor_chop_records: record without CIGAR (the reference raises IndexError, SF:331)");
-        int64_t q = 0, rr = pos[r];
-        uint32_t last = 0;
-        for (int64_t t = o0; t < o1; ++t) {
-            const int64_t len = ops[t] >> 4;
-            last = ops[t] & 15u;
-            if (last == 4u || last == 1u) q += len;                        // S, I
-            else if (last == 0u || last == 7u) { q += len; rr += len; }    // M, =
-            else if (last == 2u) rr += len;                                // D
-            if (rr > start - 1) break;
+        int64_t q = 0, rr = pos[r], num = 0;
+        bool have_n = false;
+        char last = 0;
+        for (const char* c = cigar[r] ? cigar[r] : ""; *c; ++c) {
+            const char ch = *c;
+            if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); have_n = true; continue; }
+            const bool op = ch == 'M' || ch == 'I' || ch == 'D' || ch == 'N' || ch == 'S' || ch == 'H' || ch == 'P' || ch == '=' || ch == 'X';
+            if (op && have_n) {
+                if (ch == 'S' || ch == 'I') q += num;
+                else if (ch == 'M' || ch == '=') { q += num; rr += num; }
+                else if (ch == 'D') rr += num;
+                last = ch;
+                if (rr > start - 1) break;
+            }
+            num = 0; have_n = false;           // any other character ends the number, as the regular expression would
         }
+        if (!last) return bfail(VAPOR_E_ARG, "vapor_chop_records: record without CIGAR (the reference raises IndexError, SF:331)");
         const int64_t over = rr - start;
         int64_t q0, miss;
-        if (last == 0u || last == 7u) { q0 = q - over; miss = 0; } else { q0 = q; miss = over; }
+        if (last == 'M' || last == '=') { q0 = q - over; miss = 0; } else { q0 = q; miss = over; }
         if (2 * miss > flank) continue;                                    // miss_bp > flank_length / 2
         const int64_t want = end - start - miss;
         // len(seq[q0:]) as Python slices (a negative q0 counts from the end)
-        int64_t from = q0 < 0 ? std::max<int64_t>(seq_len[r] + q0, 0) : std::min(q0, seq_len[r]);
+        const int64_t from = q0 < 0 ? std::max<int64_t>(seq_len[r] + q0, 0) : std::min(q0, seq_len[r]);
         if (!(seq_len[r] - from > want)) continue;
         keep[r] = 1;
         q0_miss[2 * r] = q0;

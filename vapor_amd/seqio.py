@@ -220,28 +220,28 @@ class MemorySamtools:
     def fetch_seq(self, ref: str, chrom: str, start: int, end: int) -> str:
         return self.world.fetch(chrom, start, end) if chrom in self.world.contigs else ""
 
-    # chop_pacbio_read_by_pos in one native call per region: the contig's records as arrays (binary CIGARs, made once per
-    # contig), the region rule / CIGAR walk / keep rules in the library's host helper (vapor_chop_records), only the kept
-    # reads sliced here.  The per-record path above (records + cigar2alignstart_by_pos per read) stays the statement it is
-    # tested against; VAPOR_MEMORY_CHOP=records selects it.
-    _OPS = {c: i for i, c in enumerate("MIDNSHP=X")}
-
+    # chop_pacbio_read_by_pos in one native call per region: the contig's records as small arrays (positions, spans, read
+    # lengths, pointers to the CIGAR texts - made once per record list; nothing is parsed ahead: the walk reads a CIGAR only as
+    # far as the window start), the region rule / CIGAR walk / keep rules in the library's host helper (vapor_chop_records),
+    # only the kept reads sliced here.  The per-record path (records + cigar2alignstart_by_pos per read) stays the statement
+    # it is tested against; VAPOR_MEMORY_CHOP=records selects it.
     def _arrays(self, chrom: str):
         cache = self.__dict__.setdefault("_chop_cache", {})
         recs = self.world.reads.get(chrom, ())
         key = id(recs)                       # (contigs that share one record list - tiled worlds - share its arrays)
         got = cache.get(key)
-        if got is None or got[0] is not recs:
+        if got is None or got[0] is not recs or got[4] != len(recs):
+            import ctypes
             import numpy as np
-            per = [cigar_to_ops(r.cigar) for r in recs]
-            off = np.concatenate(([0], np.cumsum([len(x) for x in per]))) if per else np.zeros(1, dtype=np.int64)
-            ops = np.concatenate(per) if per and int(off[-1]) else np.zeros(1, dtype=np.uint32)
+            # (a str's own UTF-8 buffer, NUL-terminated and alive as long as the str: no copy of a 10 kb CIGAR per read)
+            from .engine import _utf8
+            size = ctypes.c_ssize_t()
+            cig = [r.cigar for r in recs]
+            ptrs = (ctypes.c_void_p * max(len(recs), 1))(*[_utf8(c, ctypes.byref(size)) for c in cig])
             arrs = (np.array([r.pos for r in recs], dtype=np.int64), np.array([r.ref_span for r in recs], dtype=np.int64),
-                    np.asarray(off, dtype=np.int64), np.ascontiguousarray(ops, dtype=np.uint32),
                     np.array([len(r.seq) for r in recs], dtype=np.int64))
-            # (the addresses once: a `.ctypes` view per array and call costs more than the walk itself)
-            got = (recs, arrs, tuple(a.ctypes.data for a in arrs))
-            if len(cache) > 4096:
+            got = (recs, arrs, (arrs[0].ctypes.data, arrs[1].ctypes.data, ctypes.addressof(ptrs), arrs[2].ctypes.data), (cig, ptrs), len(recs))
+            if len(cache) > 200000:
                 cache.clear()
             cache[key] = got
         return got
@@ -249,7 +249,7 @@ class MemorySamtools:
     def chop(self, bam: str, chrom: str, start: int, end: int, flank_length):
         if _memory_chop_by_records():
             return _chop_records(self.records(bam, chrom, start, end), start, end, flank_length)
-        recs, arrs, ptr = self._arrays(chrom)
+        recs, arrs, ptr, _keep, _n = self._arrays(chrom)
         if not recs:
             return []
         fn = self.__dict__.get("_chop_fn")
@@ -261,7 +261,7 @@ class MemorySamtools:
         # record list between contigs)
         qm_a, keep_a = np.empty(2 * len(recs), dtype=np.int64), np.empty(len(recs), dtype=np.uint8)
         start, end = int(start), int(end)
-        if fn(len(recs), ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], start, end, int(flank_length), qm_a.ctypes.data, keep_a.ctypes.data) != 0:
+        if fn(len(recs), ptr[0], ptr[1], ptr[2], ptr[3], start, end, int(flank_length), qm_a.ctypes.data, keep_a.ctypes.data) != 0:
             raise IndexError("string index out of range")      # what '' [1] raises in SF:331
         kept = keep_a.nonzero()[0]
         if not len(kept):
@@ -286,31 +286,6 @@ def _memory_chop_by_records() -> bool:
     e = os.environ
     v = e._data.get(b"VAPOR_MEMORY_CHOP") if hasattr(e, "_data") else e.get("VAPOR_MEMORY_CHOP")
     return v in (b"records", "records")
-
-
-def cigar_to_ops(cigar: str):
-    """CIGAR text -> the binary operations of a BAM record (uint32: length << 4 | code, codes "MIDNSHP=X"), with numpy
-    (a long read's CIGAR holds thousands of operations).  Characters that are neither digits nor operations end a number
-    and are skipped with it, as the regular expression of cigar2alignstart_by_pos (SF:313) would."""
-    import numpy as np
-    b = np.frombuffer(cigar.encode("ascii", "replace"), dtype=np.uint8)
-    if b.size == 0:
-        return np.zeros(0, dtype=np.uint32)
-    code = np.full(256, 255, dtype=np.uint8)
-    for i, c in enumerate(b"MIDNSHP=X"):
-        code[c] = i
-    is_digit = (b >= 48) & (b <= 57)
-    # every non-digit ends a number; it counts as an operation when it is one of the nine letters and digits precede it
-    ends = np.flatnonzero(~is_digit)
-    starts = np.concatenate(([0], ends[:-1] + 1))
-    nd = ends - starts
-    ok = (code[b[ends]] != 255) & (nd > 0)
-    ends, starts, nd = ends[ok], starts[ok], nd[ok]
-    val = np.zeros(len(ends), dtype=np.int64)
-    for j in range(int(nd.max()) if len(nd) else 0):
-        has = nd > j
-        val[has] = val[has] * 10 + (b[starts[has] + j].astype(np.int64) - 48)
-    return ((val << 4) | code[b[ends]].astype(np.int64)).astype(np.uint32)
 
 
 def set_backend(b) -> None:
