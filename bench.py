@@ -45,10 +45,12 @@ def _load_json(name):
 
 
 def kernel_source_id() -> str:
-    """sha256 (16 hex digits) over the library's sources: what a committed counter summary must have been measured on."""
+    """sha256 (16 hex digits) over the device code, the host code that launches it and the compiler flags: what a committed
+    counter summary must have been measured on (the host-only helpers - BAM reader, inflate - and the header's prose are not
+    part of it: they cannot move a kernel's counters)."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("vapor_amd/csrc/vapor_kernels.h", "vapor_amd/csrc/vapor_hip.hip", "include/vapor_hip.h", "vapor_amd/build.py"):
+    for rel in ("vapor_amd/csrc/vapor_kernels.h", "vapor_amd/csrc/vapor_hip.hip", "vapor_amd/build.py"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
