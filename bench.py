@@ -4,7 +4,8 @@
 One PASS = the hot path over one batch of synthetic loci (BASELINE.json configs[1], "cfg2": 100 DEL/TANDUP loci x 20
 reads of 10 kb x ref and alt windows of 20 kb) whose packed sequences and pair descriptors are already resident in HBM:
     join kernel(s) -> clean kernel -> finish kernel (float64: per-read scores, VaPoR_QS / VaPoR_GS / VaPoR_GT /
-    VaPoR_GQ per locus) -> per-locus records to the host (N = 1) or RCCL all-gather (N > 1).
+    VaPoR_GQ per locus) -> per-locus records to the host (N = 1) or into the step's device buffer, which is all-gathered
+    over RCCL once per step (N > 1: every pass's records, in one collective per step).
 One STEP = `passes_per_step` passes back to back; the number is sized by a probe before the timed region so that the
 K timed steps last about a second or more (a single pass takes 0.3 ms; K is the driver's).  Two plans over the same
 batch are kept in flight and alternate (the library runs each plan on one of its two streams), so the clean and finish
@@ -71,6 +72,7 @@ class Resident:
             self.plans.append(p)
             self.rec.append(torch.empty((w.n_loci, 8), dtype=torch.float64, device="cuda"))
         self.gathered = None
+        self.stepbuf = self.gbuf = None
         self.i = 0
         # one blocking run per plan sizes the record slots (reruns pairs that overflow their first guess); its
         # kernel times are those of the kernels running alone
@@ -78,20 +80,38 @@ class Resident:
             p.run_loci(device_out=r.data_ptr(), want_host=False)
         self.alone = self.plans[0].timings()
 
-    def one_pass(self):
+    def set_step(self, inner):
+        """N > 1: the per-locus records of a whole step (`inner` passes) go to one device buffer and are all-gathered ONCE per
+        step - fewer, larger collectives: a pass is 0.18 ms, an all-gather call costs the host half of that whatever it
+        carries (measured with one rank: 0.178 -> 0.265 ms per pass with a gather behind every pass), and a real run gathers
+        its scores once.  Every pass's records are still gathered."""
+        if self.dist is None:
+            return
+        n = self.w.n_loci
+        self.stepbuf = self.torch.empty((inner, n, 8), dtype=self.torch.float64, device="cuda")
+        self.gbuf = self.torch.empty((self.world * inner, n, 8), dtype=self.torch.float64, device="cuda")
+
+    def one_pass(self, slot=0):
         k = self.i % len(self.plans)
         self.i += 1
-        p, r = self.plans[k], self.rec[k]
-        p.run_loci_async(device_out=r.data_ptr())       # join -> clean -> finish enqueued, no host round trip
-        if self.dist is not None:
-            # the collective runs on torch's stream: it waits (on the device) for this pass, and the plan's next
-            # pass waits for the collective before it overwrites the records
-            p.then(self.coll.cuda_stream)
+        p = self.plans[k]
+        out = self.rec[k] if self.stepbuf is None else self.stepbuf[slot]
+        p.run_loci_async(device_out=out.data_ptr())     # join -> clean -> finish enqueued, no host round trip
+
+    def begin_step(self):
+        if self.stepbuf is not None:
+            # the passes of this step overwrite the buffer the last step's all-gather reads: they wait for it on the device
+            for p in self.plans:
+                p.after(self.coll.cuda_stream)
+
+    def end_step(self):
+        if self.stepbuf is not None:
+            # the collective runs on torch's stream, which waits (on the device) for the last pass of every plan
+            for p in self.plans:
+                p.then(self.coll.cuda_stream)
             with self.torch.cuda.stream(self.coll):
-                out = self.torch.empty((self.world * r.shape[0], r.shape[1]), dtype=r.dtype, device=r.device)
-                self.dist.all_gather_into_tensor(out, r)
-                self.gathered = out
-            p.after(self.coll.cuda_stream)
+                self.dist.all_gather_into_tensor(self.gbuf, self.stepbuf)
+            self.gathered = self.gbuf
 
     def drain(self, want_host=False):
         """Waits for every plan; returns (passes folded per plan, timings per plan, last records of plan 0)."""
@@ -144,11 +164,20 @@ def main() -> None:
     local = local % n_dev
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # (VAPOR_BENCH_FORCE_DIST=1: a process group even for one rank - RCCL with a world of one exercises the collective's
+    # stream ordering against the library's streams on a one-GPU box)
+    if world > 1 or os.environ.get("VAPOR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl" and os.environ.get("VAPOR_BENCH_NCCL_EAGER") == "1":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        elif backend == "nccl":
+            # (no device_id: with it torch creates the RCCL communicator eagerly, and from then on this process's clean and
+            # finish kernels - which write to pinned host memory - ran 1.5 x slower on the one-GPU box: 0.178 -> 0.267 ms per
+            # pass with not a single collective in the timed region; created at the first collective it costs nothing.
+            # VAPOR_BENCH_NCCL_EAGER=1 reproduces it.)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll = torch.cuda.Stream()          # the collectives' stream; the library's kernels run on its own two streams
@@ -166,7 +195,10 @@ def main() -> None:
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # probe: how many passes make a step long enough
@@ -187,9 +219,13 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)     # every rank runs the same number of passes
         inner = int(t.item())
 
+    res.set_step(inner)
+
     def step():
-        for _ in range(inner):
-            res.one_pass()
+        res.begin_step()
+        for j in range(inner):
+            res.one_pass(j)
+        res.end_step()
 
     for _ in range(args.warmup):
         step()
@@ -211,7 +247,8 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if res.gathered is not None:
-            last_rec = res.gathered.cpu().numpy()
+            # the last pass of every rank: slot inner - 1 of its share of the gathered step
+            last_rec = res.gathered.view(world, inner, w.n_loci, 8)[:, inner - 1].cpu().numpy()
 
     # untimed: per-pair statistics once, for the algorithmic byte count and the oracle cross-check; and the
     # host-side finish on the same statistics must agree with what the device produced
