@@ -129,3 +129,27 @@ def test_figure_specs_match_what_the_reference_plots_gpu():
     pipeline.set_engine(None)
     figure_cases.check_specs()
     figure_cases.check_driver_requests()
+
+
+@pytest.mark.parametrize("in_flight", ["1", "2", "3"])
+def test_bed_cli_chunks_in_flight_gpu(in_flight, tmp_path, monkeypatch):
+    """`vapor bed --chunk 3` on the eight-locus world: several chunks of a run scored at once (cli.score_jobs: a thread and a
+    library context per chunk in flight, VAPOR_CHUNKS_IN_FLIGHT) give the reference's table byte for byte, whatever the
+    number in flight."""
+    from vapor_amd import cli, pipeline, seqio, synth
+    case = [c for c in LOCUS if c["name"] == "bed_small_mix"][0]
+    monkeypatch.setenv("VAPOR_CHUNKS_IN_FLIGHT", in_flight)
+    pipeline.set_engine(None)
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
+    try:
+        bed = tmp_path / "in.bed"
+        bed.write_text(case["bed"])
+        out = tmp_path / "out.vapor"
+        rc = cli.main(["bed", "--sv-input", str(bed), "--reference", "ref.fa", "--pacbio-input", "x.bam", "--chunk", "3",
+                       "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"])
+        assert rc == 0
+        assert out.read_text() == case["vapor_text"]
+        assert len(pipeline.get_engines(int(in_flight))) == int(in_flight)
+    finally:
+        seqio.set_backend(None)
+        pipeline.set_engine(None)

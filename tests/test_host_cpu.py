@@ -696,3 +696,19 @@ def test_memory_backend_native_chop_equals_the_per_record_statement(monkeypatch)
     be2 = seqio.MemorySamtools(w)
     with pytest.raises(IndexError):
         be2.chop("x.bam", chrom, 1200, 1400, 500)
+
+
+@pytest.mark.parametrize("in_flight", ["1", "2"])
+def test_bed_cli_chunks_in_flight(fake, in_flight, tmp_path, monkeypatch):
+    """cli.score_jobs with several chunks (--chunk 3 on the eight-locus world), one or two of them in flight on threads:
+    the reference's table byte for byte either way (the tests' stand-in engine is shared by the threads)."""
+    case = [c for c in LOCUS if c["name"] == "bed_small_mix"][0]
+    monkeypatch.setenv("VAPOR_CHUNKS_IN_FLIGHT", in_flight)
+    seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
+    bed = tmp_path / "in.bed"
+    bed.write_text(case["bed"])
+    out = tmp_path / "out.vapor"
+    assert cli.main(["bed", "--sv-input", str(bed), "--reference", "ref.fa", "--pacbio-input", "x.bam", "--chunk", "3",
+                     "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+    assert out.read_text() == case["vapor_text"]
+    assert len(fake.batches) >= 3            # three chunks, a few plans each
