@@ -1,0 +1,27 @@
+"""The at-size runner (tools/run_at_size.py: BASELINE configs[3] / configs[4] through the product CLI, tiled worlds) at a size
+that takes seconds, and its checker (tests/at_size_check.py: the same base world through the CPU twin of the C ABI in a child
+process, sampled rows compared text for text) - so that what produced profiles/r03_cfg4_at_size.json and r03_cfg5_at_size.json
+is itself under test."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg,loci,base", [("cfg4", 180, 60), ("cfg5", 60, 20)])
+def test_at_size_runner_and_twin_check(cfg, loci, base, tmp_path):
+    out = str(tmp_path / "at_size.json")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), cfg, "--loci", str(loci), "--base", str(base), "--out", out],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    assert rec["records"] == loci and rec["rows"] >= loci and rec["rc"] == 0 and len(rec["sample"]) >= min(loci, 400) - 1
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "at_size_check.py"), out], env=env, capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0 and " 0 differ" in c.stdout, (c.stdout[-1500:], c.stderr[-1500:])
