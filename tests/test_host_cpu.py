@@ -712,3 +712,28 @@ def test_bed_cli_chunks_in_flight(fake, in_flight, tmp_path, monkeypatch):
                      "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
     assert out.read_text() == case["vapor_text"]
     assert len(fake.batches) >= 3            # three chunks, a few plans each
+
+
+def test_output_row_equals_the_reference_named_composition():
+    """cli.output_row / finish.row_tail (one rounding per score, numpy's summation order restated) against the composition it
+    replaces - result_organize_ins (SF:1219-1231) -> format_output_row with gt_estimate_log_likelihood (SF:2054-2088) - on
+    random score lists: empty, short and long ones, scores that round to 0.0 / -0.0, a head field that reads NA."""
+    import random
+    from vapor_amd import cli, finish
+    from vapor_amd import simple_function as SF
+    rng = random.Random(7)
+    for t in range(4000):
+        n = rng.choice([0, 1, 2, 5, 7, 8, 9, 15, 16, 17, 20, 20, 20, 33, 64, 127, 128, 140])
+        sc = []
+        for _ in range(n):
+            r = rng.random()
+            sc.append(rng.choice([r, -r * 30, 0.004999, 0.005, 0.0050001, -0.004, 0.0, 1.0 - r * 1e-9, np.float64(r)]))
+        head = ["c%d" % t, "100", "200", rng.choice(["DEL", "NA", "sv1"])]
+        key = ":".join(head[:3])
+        old = SF.format_output_row(key.split(":") + [head[3]] + finish.result_organize_ins([key, sc])[1:])
+        assert cli.output_row(key.split(":") + [head[3]], sc)[0] == old, (t, sc)
+        old_vcf = SF.format_output_row(finish.result_organize_ins([key, sc]))
+        assert cli.output_row([key], sc)[0] == old_vcf
+    for _ in range(20000):
+        a = [rng.random() ** rng.randint(1, 5) for _ in range(rng.randint(1, 150))]
+        assert finish._mean_like_numpy(a) == np.mean(a) and str(finish._mean_like_numpy(a)) == str(np.mean(a))

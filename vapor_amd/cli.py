@@ -19,7 +19,7 @@ from typing import List, Optional
 from . import dist as vdist
 from . import drivers, pipeline
 from . import simple_function as SF
-from .finish import result_organize_ins
+from .finish import result_organize_ins, row_tail
 
 
 # ------------------------------------------------------------------------------------------
@@ -297,6 +297,17 @@ def svelter_jobs(sv_hash, num_reads_cff, bam_in, ref, out_path, sample_name) -> 
     return jobs
 
 
+def output_row(head: list, scores) -> tuple:
+    """The line write_output_main (SF:2084-2088) appends for one locus - `head` fields, then what result_organize_ins
+    (SF:1219-1231) and gt_estimate_log_likelihood (SF:2054-2069) make of the scores - and the five values behind it
+    (finish.row_tail: one rounding per score instead of round -> str -> split -> float).  The reference's test for an
+    unscored locus is `'NA' in out_list`, over ALL fields: a head field that reads NA turns GT, GQ and Rec into NA as well."""
+    tail = row_tail(scores)
+    if tail[0] != 'NA' and 'NA' in head:
+        tail = [tail[0], tail[1], 'NA', 'NA', 'NA']
+    return '\t'.join([str(i) for i in head + tail]), tail
+
+
 def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
     """Score every job (sharded over ranks, batched on each GPU); returns per job the list of read
     scores, in job order, identical on every rank."""
@@ -393,9 +404,10 @@ def main(argv: Optional[List[str]] = None) -> int:
             SF.write_output_initiate(args.output_file)
             with open(args.output_file, 'a') as fo:
                 for j, sc in zip(jobs, scores):
-                    res = result_organize_ins([j.key, sc])
-                    print(SF.format_output_row(res[0].split(':') + [j.row_prefix] + res[1:]), file=fo)
-                    print(res)
+                    # (result_organize_ins + write_output_main of vapor_vali/vapor:356-357 in one go: finish.row_tail)
+                    line, tail = output_row(j.key.split(':') + [j.row_prefix], sc)
+                    print(line, file=fo)
+                    print([j.key, tail[0], tail[1], tail[4]])
     elif mode == 'vcf':
         vcf_list, rec_hash = vcf_list_readin(args.sv_input)
         rec_new = SF.vcf_rec_hash_modify(rec_hash)
@@ -405,7 +417,7 @@ def main(argv: Optional[List[str]] = None) -> int:
             SF.write_output_initiate(args.sv_input + '.vapor')
             with open(args.sv_input + '.vapor', 'a') as fo:
                 for j, sc in zip(jobs, scores):
-                    print(SF.format_output_row(result_organize_ins([j.key, sc])), file=fo)
+                    print(output_row([j.key], sc)[0], file=fo)
             SF.vcf_vapor_modify(args.sv_input, rec_new)
     elif mode == 'svelter':
         jobs = svelter_jobs(svelter_readin(args.sv_input), num_reads_cff, bam_in, ref, out_path, sample_name)
@@ -413,7 +425,7 @@ def main(argv: Optional[List[str]] = None) -> int:
         if vdist.rank() == 0:
             with open(args.output_file, 'a') as fo:      # appended, never initialised (vapor_vali/vapor:492)
                 for j, sc in zip(jobs, scores):
-                    print(SF.format_output_row(result_organize_ins([j.key, sc])), file=fo)
+                    print(output_row([j.key], sc)[0], file=fo)
     elif mode == 'ins':
         from . import melt
         melt.run(args.sv_input, out_path, sample_name.split('.')[0], bam_in, ref, num_reads_cff, args.chunk, figure_fn)

@@ -140,6 +140,57 @@ def result_organize_ins(info_list):
     return [info_list[0], "NA", "NA", "NA"]
 
 
+def _mean_like_numpy(a):
+    """np.mean of a list of fewer than 128 floats, bit for bit, without the array round trip (7 us a locus): numpy's
+    add.reduce sums fewer than 8 values one by one and otherwise keeps eight strided partial sums over the first n - n % 8
+    values, combines them as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds the rest one by one (its block size is 128; the
+    finish kernel sums the same way).  tests/test_host_cpu.py compares the two on random lists."""
+    n = len(a)
+    if n >= 128:
+        return np.mean(a)
+    if n < 8:
+        r = 0.0
+        for x in a:
+            r += x
+        return np.float64(r) / n
+    r0, r1, r2, r3, r4, r5, r6, r7 = a[:8]
+    m = n - (n % 8)
+    i = 8
+    while i < m:
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7]
+        i += 8
+    res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+    while i < n:
+        res += a[i]
+        i += 1
+    return np.float64(res) / n
+
+
+def row_tail(scores):
+    """[VaPoR_QS, VaPoR_GS, VaPoR_GT, VaPoR_GQ, VaPoR_Rec] of one locus - what result_organize_ins (SF:1219-1231) followed by
+    gt_estimate_log_likelihood (SF:2054-2069) inside write_output_main (SF:2084-2088) put into its row -, or five 'NA': the
+    same values through one rounding of every score instead of round -> str -> split -> float (the strings parse back to the
+    rounded values exactly)."""
+    n = len(scores)
+    if n == 0:
+        return ["NA", "NA", "NA", "NA", "NA"]
+    fl = [float(s) for s in scores]
+    pos = [s for s in fl if s > 0]
+    gs = float(len(pos)) / float(n)
+    qs = _mean_like_numpy(pos) if pos else 0
+    rd = [round(s, 2) for s in fl]
+    l = 0
+    for s in rd:
+        if not s > 0:
+            l += 1
+    idx, gq = _gt_from_counts(n, l)
+    gt = _GT_NAMES[idx]
+    if gt == "0/0" and gs > .15:
+        gt = "0/1"
+    return [qs, gs, gt, gq, ",".join([str(s) for s in rd])]
+
+
 _GT_NAMES = ("0/0", "0/1", "1/1")
 _GT_CACHE = {}
 
