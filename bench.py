@@ -448,8 +448,7 @@ def pipeline_rate(n_loci: int = 400):
             def run():
                 jobs = cli.bed_jobs(bed_info, 3, "x.bam", "ref.fa", tmp + "/", "s")
                 scores = cli.score_jobs(jobs, 2048, None)
-                return [SF.format_output_row((lambda res: res[0].split(':') + [j.row_prefix] + res[1:])(result_organize_ins([j.key, sc])))
-                        for j, sc in zip(jobs, scores)]
+                return [cli.output_row(j.key.split(':') + [j.row_prefix], sc)[0] for j, sc in zip(jobs, scores)]   # (as cli.main writes them)
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):

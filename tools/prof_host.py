@@ -75,8 +75,7 @@ def run():
     scores = cli.score_jobs(jobs, 2048, None)
     rows = []
     for j, sc in zip(jobs, scores):
-        res = result_organize_ins([j.key, sc])
-        rows.append(SF.format_output_row(res[0].split(':') + [j.row_prefix] + res[1:]))
+        rows.append(cli.output_row(j.key.split(':') + [j.row_prefix], sc)[0])          # (as cli.main writes them)
     return rows
 
 
