@@ -1,0 +1,24 @@
+"""Does a clean workgroup beside a join workgroup pay?  The 'small' shape (2 kb reads x 4 kb windows: a clean workgroup needs
+~5 KB of LDS) with two plans in flight, on developer builds whose join leaves more or less of a CU's LDS free
+(-DVAPOR_DEV_TA2=...).  usage (GPU box): VAPOR_HIP_LIB=tools/libvapor_ab_ta16.so python tools/coresident_probe.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vapor_amd import workload as wl
+from vapor_amd.engine import Engine
+name = sys.argv[1] if len(sys.argv) > 1 else "small"
+w = wl.make_workload(name, seed=1000, **wl.WORKLOADS[name])
+eng = Engine(0)
+ss = eng.seqset(w.seqs)
+plans = []
+for _ in range(2):
+    p = eng.plan(ss, w.pairs); p.set_reads(wl.read_table(w), w.n_loci); p.run_loci(want_host=False); plans.append(p)
+alone = plans[0].timings()
+def timed(ps, n=60):
+    for i in range(2 * len(ps)): ps[i % len(ps)].run_loci_async()
+    for p in ps: p.sync(want_host=False)
+    t0 = time.perf_counter()
+    for i in range(n): ps[i % len(ps)].run_loci_async()
+    for p in ps: p.sync(want_host=False)
+    return (time.perf_counter() - t0) / n * 1e3
+one, two = timed(plans[:1]), timed(plans)
+print("%s: %d pairs; alone join %.4f clean %.4f ms; per pass one plan %.4f ms, two plans %.4f ms" % (name, len(w.pairs), alone["join_ms"], alone["clean_ms"], one, two))

@@ -88,6 +88,8 @@ WORKLOADS = {
     # the largest shape BASELINE names (configs[4]: 30 kb reads, 40 kb windows, 60x), a single-GPU slice of it
     "cfg5s": dict(n_loci=200, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), read_len=30000, allele_len=40000,
                   reads_per_locus=60),
+    # a shape whose clean workgroup needs ~5 KB of LDS (experiments on what runs beside a join workgroup)
+    "small": dict(n_loci=2000, svtypes=("DEL", "TANDUP"), read_len=2000, allele_len=4000, reads_per_locus=20),
     "tiny": dict(n_loci=8, svtypes=("DEL", "TANDUP", "INV", "INS"), read_len=1500, allele_len=3000, reads_per_locus=6),
 }
 
