@@ -1,6 +1,7 @@
 """Does a clean workgroup beside a join workgroup pay?  The 'small' shape (2 kb reads x 4 kb windows: a clean workgroup needs
-~5 KB of LDS) with two plans in flight, on developer builds whose join leaves more or less of a CU's LDS free
-(-DVAPOR_DEV_TA2=...).  usage (GPU box): VAPOR_HIP_LIB=tools/libvapor_ab_ta16.so python tools/coresident_probe.py"""
+~12 KB of LDS) with one and with two plans in flight.  Round 3 ran it on developer builds whose join tile was 24 576 or
+18 432 positions (a -DVAPOR_DEV_TA2 switch in JoinBig, removed again: 0 or 14.6 KB of a CU's LDS left beside a join
+workgroup) and found no difference - profiles/r03_coresident_probe.txt.  usage (GPU box): python tools/coresident_probe.py [shape]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vapor_amd import workload as wl
