@@ -448,7 +448,7 @@ def pipeline_rate(n_loci: int = 400):
             def run():
                 jobs = cli.bed_jobs(bed_info, 3, "x.bam", "ref.fa", tmp + "/", "s")
                 scores = cli.score_jobs(jobs, 2048, None)
-                return [cli.output_row(j.key.split(':') + [j.row_prefix], sc)[0] for j, sc in zip(jobs, scores)]   # (as cli.main writes them)
+                return cli.output_rows([j.key.split(':') + [j.row_prefix] for j in jobs], scores)[0]   # (as cli.main writes them)
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):

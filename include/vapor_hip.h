@@ -251,12 +251,29 @@ int vapor_bam_chop(vapor_bam* bam, int32_t tid, int64_t start, int64_t end, int6
 int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, const char* const* cigar,
                        const int64_t* seq_len, int64_t start, int64_t end, int64_t flank, int64_t* q0_miss, uint8_t* keep);
 /*
+ * The row tails of a whole output table in one call (host, no device): per locus t with read scores
+ * scores[off[t] .. off[t+1]) what result_organize_ins (SF:1219-1231) and gt_estimate_log_likelihood (SF:2054-2069, reading
+ * the rounded Rec string back, SF:2056) derive from them - n_pos[t] = scores > 0, qs[t] = their np.mean (numpy's pairwise
+ * summation order; 0 when none), n_nonpos[t] = scores not > 0 after round(s, 2), and Rec = ','.join(str(round(s, 2))) as
+ * text[text_off[t] .. text_off[t+1]) (ASCII, no terminator).  n_nonpos[t] = -1 where a score is not finite or at least 1e13
+ * in size: the caller formats that locus itself.  VAPOR_E_OVERFLOW with text_off[n_loci] = bytes needed when text_cap is too
+ * small.  Replaces the per-locus round -> str -> join -> split -> float of the reference's writer (SF:1229, 2056).
+ */
+int vapor_row_tails(int32_t n_loci, const int64_t* off, const double* scores, double* qs, int32_t* n_pos, int32_t* n_nonpos,
+                    char* text, int64_t text_cap, int64_t* text_off);
+/*
  * The block decoder of vapor_bam_chop by itself (host, no device): a raw DEFLATE stream (RFC 1951; the payload of a BGZF
  * block) of in_n bytes into exactly out_n bytes.  VAPOR_E_ARG for anything that is not such a stream (truncated, damaged,
  * another size); it reads and writes nothing outside the two buffers.  Replaces the inflate inside `samtools view`
  * (SF:342 runs it as a process per locus).
  */
 int vapor_inflate_raw(const uint8_t* in, int64_t in_n, uint8_t* out, int64_t out_n);
+/*
+ * The CRC-32 (gzip polynomial) every inflated BGZF block is checked against its trailer with (host, no device), by itself:
+ * carry-less-multiply folding where the CPU has it, table lookups for the rest and - tables_only != 0 - for everything.
+ * 0 for an empty buffer.  Replaces the check inside `samtools view` (htslib verifies each block, SF:342 runs it per locus).
+ */
+uint32_t vapor_crc32(const uint8_t* data, int64_t n, int32_t tables_only);
 
 #ifdef __cplusplus
 }

@@ -358,6 +358,28 @@ def test_block_decoder_against_zlib():
     assert n_cases == 6 * 10 * 4 * 4
 
 
+def test_block_crc_against_zlib():
+    """vapor_crc32 - the CRC-32 every inflated block is checked with - against zlib.crc32 on both of its paths (carry-less
+    multiply folding for the 16-byte multiples of 64 bytes and more where the host has it; tables for the rest and,
+    tables_only, for everything): every length around the folding steps, block-sized buffers, unaligned starts."""
+    import ctypes
+    from vapor_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    sizes = list(range(0, 340)) + [511, 512, 513, 1000, 4095, 4096, 65279, 65280, 65535, 65536] + [int(x) for x in rng.integers(1, 70000, 120)]
+    for n in sizes:
+        for off in (0, 1, 5):
+            buf = rng.integers(0, 256, n + off, dtype=np.uint8)
+            view = buf[off:]
+            want = zlib.crc32(view.tobytes()) if n else 0
+            assert lib.vapor_crc32(view.ctypes.data, n, 0) == want, (n, off)
+            assert lib.vapor_crc32(view.ctypes.data, n, 1) == want, (n, off)
+    assert lib.vapor_crc32(None, 10, 0) == 0
+    for fill in (0, 255):                                   # (all-zero and all-one data: the register's inversions)
+        buf = np.full(70000, fill, dtype=np.uint8)
+        assert lib.vapor_crc32(buf.ctypes.data, 70000, 0) == zlib.crc32(buf.tobytes()) == lib.vapor_crc32(buf.ctypes.data, 70000, 1)
+
+
 def test_block_decoder_refuses_what_zlib_refuses():
     """Truncated streams and streams with a flipped bit: the decoder accepts exactly those zlib accepts, with the same
     bytes, and never touches memory outside its buffers (guard bytes behind the output; the sanitizer build of

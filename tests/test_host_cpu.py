@@ -714,6 +714,68 @@ def test_bed_cli_chunks_in_flight(fake, in_flight, tmp_path, monkeypatch):
     assert len(fake.batches) >= 3            # three chunks, a few plans each
 
 
+def test_output_rows_of_a_table_equal_the_reference_named_composition():
+    """cli.output_rows / finish.row_tails - the whole table's tails from one call of the library's host helper
+    (vapor_row_tails: rounding, Rec strings, mean of the positive scores, counts) - against result_organize_ins (SF:1219-1231)
+    -> format_output_row with gt_estimate_log_likelihood (SF:2054-2088) per locus: ties of round(s, 2) (0.125, 2.675, 1.005,
+    x.xx5 in general), scores that round to 0.0 / -0.0, integers, long lists (numpy's pairwise blocks), loci the helper hands
+    back (NaN, inf, huge), empty lists, a head field that reads NA; and the helper's argument checks."""
+    import ctypes
+    import random
+    from vapor_amd import _lib, cli, finish
+    from vapor_amd import simple_function as SF
+    rng = random.Random(11)
+    special = [0.0, -0.0, 0.005, -0.005, 0.125, 0.375, 2.675, 1.005, -1.005, 0.015, 0.025, 0.035, 0.045, 1e-9, -1e-9, 0.004999999,
+               0.00500000001, 1.0, -1.0, 10.0, 100.5, 0.995, 0.9949999, 3, -2, np.float64(0.25)]
+    heads, tables = [], []
+    for t in range(6000):
+        n = rng.choice([0, 1, 2, 3, 7, 8, 9, 15, 16, 17, 20, 20, 20, 40, 127, 128, 129, 300])
+        sc = []
+        for _ in range(n):
+            r = rng.random()
+            if r < .1:
+                sc.append(rng.choice(special))
+            elif r < .2:
+                sc.append((rng.randint(-10 ** 5, 10 ** 5) + .5) / 100.0)
+            elif r < .25:
+                sc.append(rng.uniform(-1e12, 1e12))
+            else:
+                sc.append(1 - rng.expovariate(1.0) * rng.choice([.1, 1, 10]))
+        if n and rng.random() < .03:
+            sc[rng.randrange(n)] = rng.choice([float("nan"), float("inf"), -float("inf"), 1e13, -3e15, 1e300])
+        heads.append(["c%d" % t, "100", "200", rng.choice(["DEL", "NA", "sv1"])])
+        tables.append(sc)
+    with np.errstate(divide="ignore"):
+        lines, tails = cli.output_rows(heads, tables)
+        for head, sc, line, tail in zip(heads, tables, lines, tails):
+            key = ":".join(head[:3])
+            assert line == SF.format_output_row(key.split(":") + [head[3]] + finish.result_organize_ins([key, sc])[1:]), sc
+            exp = finish.row_tail(sc)
+            assert [str(x) for x in tail] == [str(x) for x in exp] and [type(x) for x in tail] == [type(x) for x in exp]
+        vcf_lines = cli.output_rows([[":".join(h[:3])] for h in heads[:500]], tables[:500])[0]
+        for head, sc, line in zip(heads, tables, vcf_lines):
+            assert line == SF.format_output_row(finish.result_organize_ins([":".join(head[:3]), sc]))
+    assert cli.output_rows([], []) == ([], [])
+    odd = [[0.5], ["0.25", "-1"], (0.125, 7)]                                     # (numerals as text, a tuple)
+    assert finish.row_tails(odd) == [finish.row_tail(sc) for sc in odd]
+    with pytest.raises((TypeError, ValueError)):
+        finish.row_tails([[0.5], None])                                          # as row_tail(None) raises
+    lib = _lib.load()
+    off = np.array([0, 2, 1], dtype=np.int64)
+    one = np.zeros(4)
+    i32 = np.zeros(4, dtype=np.int32)
+    to = np.zeros(4, dtype=np.int64)
+    buf = ctypes.create_string_buffer(64)
+    assert lib.vapor_row_tails(2, off.ctypes.data, one.ctypes.data, one.ctypes.data, i32.ctypes.data, i32.ctypes.data,
+                               ctypes.addressof(buf), 64, to.ctypes.data) == _lib.E_ARG
+    assert lib.vapor_row_tails(1, None, None, None, None, None, None, 0, None) == _lib.E_ARG
+    off = np.array([0, 3], dtype=np.int64)
+    sc = np.array([0.5, -1.25, 123456.789])
+    assert lib.vapor_row_tails(1, off.ctypes.data, sc.ctypes.data, one.ctypes.data, i32.ctypes.data, i32.ctypes.data,
+                               ctypes.addressof(buf), 4, to.ctypes.data) == _lib.E_OVERFLOW
+    assert to[1] == len("0.5,-1.25,123456.79")
+
+
 def test_output_row_equals_the_reference_named_composition():
     """cli.output_row / finish.row_tail (one rounding per score, numpy's summation order restated) against the composition it
     replaces - result_organize_ins (SF:1219-1231) -> format_output_row with gt_estimate_log_likelihood (SF:2054-2088) - on

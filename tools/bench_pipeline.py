@@ -72,10 +72,7 @@ pipeline.get_engine()
 def run():
     jobs = cli.bed_jobs(bed_info, 3, "x.bam", "ref.fa", tmp + "/", "s")
     scores = cli.score_jobs(jobs, 2048, None)
-    rows = []
-    for j, sc in zip(jobs, scores):
-        rows.append(cli.output_row(j.key.split(':') + [j.row_prefix], sc)[0])          # (as cli.main writes them)
-    return rows
+    return cli.output_rows([j.key.split(':') + [j.row_prefix] for j in jobs], scores)[0]          # (as cli.main writes them)
 
 
 run()

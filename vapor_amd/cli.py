@@ -308,6 +308,20 @@ def output_row(head: list, scores) -> tuple:
     return '\t'.join([str(i) for i in head + tail]), tail
 
 
+def output_rows(heads: list, scores_list: list) -> tuple:
+    """output_row's line for every locus of the table, and the five values of finish.row_tail behind each (as computed: the
+    NA rule of the writer changes the line only - vapor_vali/vapor:357 prints the result before the writer looks at it);
+    the tails through finish.row_tails, one call of the library's host helper for the whole table."""
+    from .finish import row_tails
+    tails = row_tails(scores_list)
+    lines = []
+    for head, tail in zip(heads, tails):
+        if tail[0] != 'NA' and 'NA' in head:
+            tail = [tail[0], tail[1], 'NA', 'NA', 'NA']
+        lines.append('\t'.join([str(i) for i in head + tail]))
+    return lines, tails
+
+
 def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
     """Score every job (sharded over ranks, batched on each GPU); returns per job the list of read
     scores, in job order, identical on every rank."""
@@ -403,10 +417,10 @@ def main(argv: Optional[List[str]] = None) -> int:
         if vdist.rank() == 0:
             SF.write_output_initiate(args.output_file)
             with open(args.output_file, 'a') as fo:
-                for j, sc in zip(jobs, scores):
-                    # (result_organize_ins + write_output_main of vapor_vali/vapor:356-357 in one go: finish.row_tail)
-                    line, tail = output_row(j.key.split(':') + [j.row_prefix], sc)
-                    print(line, file=fo)
+                # (result_organize_ins + write_output_main of vapor_vali/vapor:356-357 in one go: finish.row_tails)
+                lines, tails = output_rows([j.key.split(':') + [j.row_prefix] for j in jobs], scores)
+                fo.write(''.join([l + '\n' for l in lines]))
+                for j, tail in zip(jobs, tails):
                     print([j.key, tail[0], tail[1], tail[4]])
     elif mode == 'vcf':
         vcf_list, rec_hash = vcf_list_readin(args.sv_input)
@@ -416,16 +430,14 @@ def main(argv: Optional[List[str]] = None) -> int:
         if vdist.rank() == 0:
             SF.write_output_initiate(args.sv_input + '.vapor')
             with open(args.sv_input + '.vapor', 'a') as fo:
-                for j, sc in zip(jobs, scores):
-                    print(output_row([j.key], sc)[0], file=fo)
+                fo.write(''.join([l + '\n' for l in output_rows([[j.key] for j in jobs], scores)[0]]))
             SF.vcf_vapor_modify(args.sv_input, rec_new)
     elif mode == 'svelter':
         jobs = svelter_jobs(svelter_readin(args.sv_input), num_reads_cff, bam_in, ref, out_path, sample_name)
         scores = score_jobs(jobs, args.chunk, figure_fn)
         if vdist.rank() == 0:
             with open(args.output_file, 'a') as fo:      # appended, never initialised (vapor_vali/vapor:492)
-                for j, sc in zip(jobs, scores):
-                    print(output_row([j.key], sc)[0], file=fo)
+                fo.write(''.join([l + '\n' for l in output_rows([[j.key] for j in jobs], scores)[0]]))
     elif mode == 'ins':
         from . import melt
         melt.run(args.sv_input, out_path, sample_name.split('.')[0], bam_in, ref, num_reads_cff, args.chunk, figure_fn)

@@ -15,6 +15,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -147,6 +150,14 @@ extern "C" int vapor_inflate_raw(const uint8_t* in, int64_t in_n, uint8_t* out, 
     return VAPOR_OK;
 }
 
+// the CRC-32 the block trailers are checked with, by itself (tests compare it with zlib's; `tables_only` takes the path of a
+// host without carry-less multiply)
+extern "C" uint32_t vapor_crc32(const uint8_t* data, int64_t n, int32_t tables_only)
+{
+    if (!data || n <= 0) return 0u;
+    return vapor_inflate::crc32_fast(data, (size_t)n, !tables_only);
+}
+
 // inflates blocks [b0, b1) into data (their ustart already laid out), a few threads when there are several
 static bool inflate_range(vapor_bam* b, size_t b0, size_t b1)
 {
@@ -171,13 +182,17 @@ static bool inflate_range(vapor_bam* b, size_t b0, size_t b1)
     return true;
 }
 
-// lays the newly scanned blocks [b0, ..) out behind the inflated bytes and inflates them
-static bool take_blocks(vapor_bam* b, size_t b0)
+// lays the next scanned blocks, up to block b1, out behind the inflated bytes and inflates them (blocks are inflated in file
+// order: the first blk_ustart.size() of the scanned ones are)
+static bool take_blocks(vapor_bam* b, size_t b1)
 {
+    const size_t b0 = b->blk_ustart.size();
+    b1 = std::min(b1, b->blk_coff.size());
+    if (b1 <= b0) return true;
     int64_t u = (int64_t)b->data.size();
-    for (size_t i = b0; i < b->blk_coff.size(); ++i) { b->blk_ustart.push_back(u); u += b->blk_usize[i]; }
+    for (size_t i = b0; i < b1; ++i) { b->blk_ustart.push_back(u); u += b->blk_usize[i]; }
     b->data.resize((size_t)u);
-    return inflate_range(b, b0, b->blk_coff.size());
+    return inflate_range(b, b0, b1);
 }
 
 // reads `bytes` more file bytes behind `comp`; false at end of file
@@ -197,11 +212,13 @@ static bool ensure(vapor_bam* b, int64_t upto)
 {
     g_bam_damaged = false;
     while ((int64_t)b->data.size() < upto) {
-        if (!read_more(b, (size_t)1 << 18)) return false;
-        const size_t b0 = b->blk_coff.size();
+        // blocks that were read with the chunk but lie behind its end (a record runs into them), a few at a time
+        if (b->blk_ustart.size() < b->blk_coff.size()) {
+            if (!take_blocks(b, b->blk_ustart.size() + (size_t)std::max(b->n_threads, 1))) { g_bam_damaged = true; return false; }
+            continue;
+        }
+        if (!read_more(b, (size_t)1 << 17)) return false;
         if (scan_blocks(b) < 0) { g_bam_damaged = true; return false; }
-        if (b->blk_coff.size() == b0) continue;              // not even one whole block yet: read on
-        if (!take_blocks(b, b0)) { g_bam_damaged = true; return false; }
     }
     return true;
 }
@@ -267,7 +284,10 @@ static int bam_chop_impl(vapor_bam* b, int32_t tid, int64_t start, int64_t end, 
         const size_t span = (size_t)((int64_t)(ce >> 16) - b->comp_base) + ((ce & 0xFFFFu) ? ((size_t)1 << 16) + 64 : 0);
         if (span == 0 || !read_more(b, span)) continue;
         if (scan_blocks(b) < 0) return bfail(VAPOR_E_ARG, "vapor_bam_chop: not a BGZF block in " + b->path);
-        if (!take_blocks(b, 0)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: inflate failed in " + b->path);
+        // the blocks the chunk covers (the read holds a few more behind its end block: those wait until a record needs them)
+        size_t own = 0;
+        while (own < b->blk_coff.size() && ((uint64_t)b->blk_coff[own] << 16) < ce) ++own;
+        if (!take_blocks(b, own)) return bfail(VAPOR_E_ARG, "vapor_bam_chop: inflate failed in " + b->path);
         int64_t pos_u = (int64_t)(cs & 0xFFFF);                              // position in `data`
         size_t blk = 0;
         for (;;) {
@@ -276,8 +296,9 @@ static int bam_chop_impl(vapor_bam* b, int32_t tid, int64_t start, int64_t end, 
             // before anything more is read, so that the end of the chunk does not cost another read and inflate
             uint64_t voff;
             if (pos_u >= (int64_t)b->data.size()) {
-                if (b->blk_coff.empty()) break;
-                voff = (uint64_t)(b->blk_coff.back() + b->blk_csize.back()) << 16;
+                const size_t taken = b->blk_ustart.size();
+                if (taken == 0) break;
+                voff = (uint64_t)(b->blk_coff[taken - 1] + b->blk_csize[taken - 1]) << 16;
             } else {
                 while (blk + 1 < b->blk_ustart.size() && pos_u >= b->blk_ustart[blk + 1]) ++blk;
                 voff = ((uint64_t)b->blk_coff[blk] << 16) | (uint64_t)(pos_u - b->blk_ustart[blk]);
@@ -320,8 +341,9 @@ static int bam_chop_impl(vapor_bam* b, int32_t tid, int64_t start, int64_t end, 
                 }
             }
             // reference length; the region-overlap rule of `samtools view`
+            // (only as far as the answer: a long read's thousands of operations end far behind the window)
             int64_t rlen = 0;
-            for (int32_t t = 0; t < n_ops; ++t) {
+            for (int32_t t = 0; t < n_ops && (int64_t)pos + rlen <= beg; ++t) {
                 const uint32_t o = (uint32_t)rd32(ops + 4 * t), code = o & 15u;
                 if (code == 0 || code == 2 || code == 3 || code == 7 || code == 8) rlen += o >> 4;
             }
@@ -357,11 +379,14 @@ static int bam_chop_impl(vapor_bam* b, int32_t tid, int64_t start, int64_t end, 
             }
             uint8_t* dst = seq_out + seq_used;
             if (l_seq > 0) {
-                for (int64_t t = 0; t < want_len; ++t) {
-                    const int64_t i = q0 + t;
+                int64_t t = 0, i = q0;
+                if ((i & 1) && t < want_len) { dst[t++] = (uint8_t)NT16[sq[i >> 1] & 15]; ++i; }
+                for (; t + 2 <= want_len; t += 2, i += 2) {              // two bases a byte
                     const uint8_t byte = sq[i >> 1];
-                    dst[t] = (uint8_t)NT16[(i & 1) ? (byte & 15) : (byte >> 4)];
+                    dst[t] = (uint8_t)NT16[byte >> 4];
+                    dst[t + 1] = (uint8_t)NT16[byte & 15];
                 }
+                if (t < want_len) dst[t] = (uint8_t)NT16[sq[i >> 1] >> 4];
             } else if (want_len > 0) {
                 dst[0] = '*';
             }
@@ -439,4 +464,120 @@ extern "C" int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* 
         q0_miss[2 * r + 1] = miss;
     }
     return VAPOR_OK;
+}
+
+// The row tails of a whole table in one call (no device): what result_organize_ins (SF:1219-1231) and
+// gt_estimate_log_likelihood (SF:2054-2069) compute per locus from its read scores, minus the parts that are table lookups on
+// the caller's side.  Per locus t with scores[off[t] .. off[t+1]):
+//   n_pos[t]    = scores > 0 (GS = n_pos / n);  qs[t] = np.mean of those, summed as numpy's add.reduce sums a contiguous
+//                 double array (pairwise: blocks of at most 128 with eight strided partial sums, SF:1225's np.mean)
+//   n_nonpos[t] = scores that are not > 0 AFTER round(s, 2) - the l of log_likelihood_calcu (SF:2071-2077), which the
+//                 reference reads back from the Rec string
+//   rec         = ','.join(str(round(s, 2))): text[text_off[t] .. text_off[t+1]).  str(round(s, 2)) of a float is the
+//                 correctly rounded two-decimal numeral without trailing zeros but with one decimal at least ("0.5", "-1.0",
+//                 "-0.0"): round() rounds the exact binary value half-even through the shortest-string machinery, and below
+//                 2^46 two doubles are less than 0.005 apart so no shorter numeral reads back as the same double.
+//                 n_nonpos[t] = -1 instead where a score is not finite or is 1e13 and more in size: the caller formats that
+//                 locus itself.
+// VAPOR_E_OVERFLOW with text_off[n_loci] = bytes needed when text_cap is too small (16 bytes a score are always enough for
+// |s| < 1e13).
+namespace {
+double pairwise_sum(const double* a, int64_t n)
+{
+    if (n < 8) {
+        double r = 0.;          // (numpy starts from -0.0; adding it to the first value gives the same double except for an
+        for (int64_t i = 0; i < n; ++i) r += a[i];     //  all-negative-zero list, which cannot be: these values are > 0)
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+
+// the numeral of round(x, 2) as Python prints it; returns its length, sets *positive to (rounded value > 0)
+int two_decimals(double x, char* out, bool* positive)
+{
+    const double y = x * 100.;
+    const double fl = std::floor(y);
+    double cents;               // round(x, 2) * 100 as an integer-valued double (sign kept apart for -0.0)
+    // x * 100 carries a relative error below 2^-53: away from a tie by more than that, the side it falls on is the exact one
+    if (std::fabs((y - fl) - .5) > 1e-9 * (std::fabs(y) + 1.)) {
+        cents = std::nearbyint(y);
+    } else {
+        char buf[40];
+        std::snprintf(buf, sizeof buf, "%.2f", x);       // exact, half-even on the binary value
+        cents = std::nearbyint(std::strtod(buf, nullptr) * 100.);
+    }
+    const bool neg = std::signbit(x);
+    uint64_t c = (uint64_t)std::fabs(cents);
+    *positive = !neg && c > 0;
+    char tmp[32];
+    int m = 0;
+    const unsigned frac = (unsigned)(c % 100);
+    c /= 100;
+    do { tmp[m++] = (char)('0' + c % 10); c /= 10; } while (c);
+    int len = 0;
+    if (neg) out[len++] = '-';
+    while (m) out[len++] = tmp[--m];
+    out[len++] = '.';
+    out[len++] = (char)('0' + frac / 10);
+    if (frac % 10) out[len++] = (char)('0' + frac % 10);
+    return len;
+}
+}   // namespace
+
+extern "C" int vapor_row_tails(int32_t n_loci, const int64_t* off, const double* scores, double* qs, int32_t* n_pos,
+                               int32_t* n_nonpos, char* text, int64_t text_cap, int64_t* text_off)
+{
+    if (n_loci < 0 || !off || !text_off || (n_loci && (!qs || !n_pos || !n_nonpos)) || text_cap < 0 || (text_cap && !text))
+        return bfail(VAPOR_E_ARG, "vapor_row_tails: null argument");
+    for (int32_t t = 0; t < n_loci; ++t)
+        if (off[t + 1] < off[t] || off[t] < 0) return bfail(VAPOR_E_ARG, "vapor_row_tails: offsets must not decrease");
+    if (n_loci && off[n_loci] > 0 && !scores) return bfail(VAPOR_E_ARG, "vapor_row_tails: null scores");
+    try {
+        std::vector<double> pos;
+        int64_t w = 0;
+        bool fits = true;
+        for (int32_t t = 0; t < n_loci; ++t) {
+            const double* s = scores + off[t];
+            const int64_t n = off[t + 1] - off[t];
+            text_off[t] = w;
+            pos.clear();
+            int32_t nonpos = 0;
+            bool plain = true;
+            for (int64_t i = 0; i < n; ++i) {
+                if (s[i] > 0) pos.push_back(s[i]);
+                if (!(std::fabs(s[i]) < 1e13)) { plain = false; continue; }      // (also NaN)
+                char num[40];
+                bool positive;
+                const int len = two_decimals(s[i], num, &positive);
+                nonpos += !positive;
+                if (fits && w + len + 1 <= text_cap) {
+                    if (i) text[w++] = ',';
+                    std::memcpy(text + w, num, (size_t)len);
+                    w += len;
+                } else {
+                    fits = false;
+                    w += len + (i ? 1 : 0);
+                }
+            }
+            n_pos[t] = (int32_t)pos.size();
+            qs[t] = pos.empty() ? 0. : pairwise_sum(pos.data(), (int64_t)pos.size()) / (double)pos.size();
+            n_nonpos[t] = plain ? nonpos : -1;
+        }
+        text_off[n_loci] = w;
+        return fits ? VAPOR_OK : bfail(VAPOR_E_OVERFLOW, "vapor_row_tails: text buffer too small");
+    } catch (const std::bad_alloc&) {
+        return bfail(VAPOR_E_NOMEM, "vapor_row_tails: out of memory");
+    }
 }

@@ -111,19 +111,20 @@ def pack_records(local: Dict[int, object], items: Sequence[int]):
             extra[t] = v
         else:
             flat.append(float(len(v)))
-            flat.extend(float(x) for x in v)
+            flat.extend(v)
     return np.asarray(flat, dtype=np.float64), extra
 
 
 def unpack_records(flat: np.ndarray, items: Sequence[int], extra: Dict[int, object], out: List[object]) -> None:
     p = 0
+    fl = flat.tolist()
     for t in items:
-        n = int(flat[p])
+        n = int(fl[p])
         p += 1
         if n < 0:
             out[t] = extra[t]
         else:
-            out[t] = [float(x) for x in flat[p:p + n]]
+            out[t] = fl[p:p + n]
             p += n
 
 
@@ -133,10 +134,10 @@ def gather_results(local: Dict[int, object], n_items: int, costs: Sequence[float
     all-gather of the ranks' own score vectors padded to the longest - a few hundred bytes per locus, no NaN rows
     for other ranks' loci, and no pickling unless some locus raised."""
     out: List[object] = [None] * n_items
-    if _pg is None:
-        items = list(range(n_items))
-        flat, extra = pack_records(local, items)
-        unpack_records(flat, items, extra, out)
+    if _pg is None:                               # one process: the lists as they are (as floats, as the vector would give them)
+        for t in range(n_items):
+            v = local[t]
+            out[t] = v if isinstance(v, BaseException) or v is None else [float(x) for x in v]
         return out
     import torch
     import torch.distributed as dist

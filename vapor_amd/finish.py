@@ -191,6 +191,55 @@ def row_tail(scores):
     return [qs, gs, gt, gq, ",".join([str(s) for s in rd])]
 
 
+def row_tails(scores_list) -> list:
+    """row_tail for every locus of a table through one call of the library's host helper (vapor_row_tails: the rounding, the
+    Rec strings, the positive scores' mean and the two counts for all loci; what stays here is a dict lookup and two str() per
+    locus).  A locus the helper hands back (a score that is not finite, or huge) and a table that is not made of lists of
+    numbers go through row_tail."""
+    n = len(scores_list)
+    if n == 0:
+        return []
+    import ctypes
+    from itertools import chain
+    try:
+        lens = np.fromiter(map(len, scores_list), dtype=np.int64, count=n)
+        total = int(lens.sum())
+        flat = np.fromiter(chain.from_iterable(scores_list), dtype=np.float64, count=total)
+    except (TypeError, ValueError):
+        return [row_tail(sc) for sc in scores_list]
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    qs, n_pos, n_nonpos = np.empty(n, dtype=np.float64), np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+    text = ctypes.create_string_buffer(16 * total + 16)
+    text_off = np.empty(n + 1, dtype=np.int64)
+    lib = L.load()
+    rc = lib.vapor_row_tails(n, off.ctypes.data, flat.ctypes.data, qs.ctypes.data, n_pos.ctypes.data, n_nonpos.ctypes.data,
+                             ctypes.addressof(text), len(text), text_off.ctypes.data)
+    if rc == L.E_OVERFLOW:                        # (scores of 1e13 and more are not written, so this does not happen)
+        text = ctypes.create_string_buffer(int(text_off[n]) + 16)
+        rc = lib.vapor_row_tails(n, off.ctypes.data, flat.ctypes.data, qs.ctypes.data, n_pos.ctypes.data, n_nonpos.ctypes.data,
+                                 ctypes.addressof(text), len(text), text_off.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("vapor_row_tails: %s" % lib.vapor_bam_last_error().decode())
+    recs = text.raw[:int(text_off[n])].decode("ascii")
+    to = text_off.tolist()
+    out = []
+    for t, (k, np_, l) in enumerate(zip(lens.tolist(), n_pos.tolist(), n_nonpos.tolist())):
+        if k == 0:
+            out.append(["NA", "NA", "NA", "NA", "NA"])
+            continue
+        if l < 0:
+            out.append(row_tail(scores_list[t]))
+            continue
+        gs = float(np_) / float(k)
+        idx, gq = _gt_from_counts(k, l)
+        gt = _GT_NAMES[idx]
+        if gt == "0/0" and gs > .15:
+            gt = "0/1"
+        out.append([qs[t] if np_ else 0, gs, gt, gq, recs[to[t]:to[t + 1]]])
+    return out
+
+
 _GT_NAMES = ("0/0", "0/1", "1/1")
 _GT_CACHE = {}
 
