@@ -565,3 +565,125 @@ def test_truncated_file_is_an_exception_not_a_crash(tmp_path):
         got = be._open(bad).chop_native("c", 9000, 10500, 200)
         whole = be._open(path).chop_native("c", 9000, 10500, 200)
         assert all(r in whole for r in got)
+
+
+def _asan_harness(tmp_path_factory):
+    """tools/bam_check.cpp built with AddressSanitizer and UBSan (g++); None where that does not build or run here."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path_factory.mktemp("asan") / "bam_check")
+    cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + os.path.join(root, "include"),
+           "-I" + os.path.join(root, "vapor_amd", "csrc"), "-o", exe, os.path.join(root, "tools", "bam_check.cpp"), "-lz", "-lpthread"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    return exe if r.returncode == 0 else None
+
+
+@pytest.fixture(scope="module")
+def asan_bam_check(tmp_path_factory):
+    exe = _asan_harness(tmp_path_factory)
+    if exe is None:
+        pytest.skip("no sanitizer build of tools/bam_check.cpp here")
+    return exe
+
+
+def _run_checked(exe, path, first, window=(3500, 5000, 200), threads=2):
+    import subprocess
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, path, str(first), "0", str(window[0]), str(window[1]), str(window[2]), str(threads)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (path, r.returncode, r.stderr[-2000:])
+    return r.stdout
+
+
+def test_native_reader_under_sanitizers_on_good_and_damaged_files(tmp_path, asan_bam_check):
+    """vapor_bam_chop in an AddressSanitizer + UBSan build (tools/bam_check.cpp; ADVICE round 2: a damaged ISIZE reached the
+    inflaters as a buffer size and corrupted the heap) over a good file - every record walked, the overflow answer and its
+    sizes, the reads - and over damaged ones: the block and record fields of the tests above, a truncated file, and 120 files
+    with random damage (bytes of the compressed file; bytes of the inflated stream written back in valid blocks, so that the
+    record rules are what is tested).  Every run must end in a status - no report of a sanitizer."""
+    path = _small_bam(tmp_path)
+    first = bamio.BamFile(path).first_record
+    out = _run_checked(asan_bam_check, path, first, (4000, 5500, 200))
+    assert "sized buffers: rc 0 reads" in out and " reads 0 " not in out.splitlines()[-1]
+    raw = open(path, "rb").read()
+    bl = _blocks(raw)
+    off, bsize, xlen = bl[6]
+    n_err = 0
+    variants = []
+    for field in ("isize_huge", "isize_small", "bsize_tiny", "bsize_big", "crc", "payload_bit", "xlen_big", "truncated"):
+        b = bytearray(raw)
+        if field == "isize_huge":
+            struct.pack_into("<I", b, off + bsize - 4, 0xFFFFFFFF)
+        elif field == "isize_small":
+            struct.pack_into("<I", b, off + bsize - 4, 17)
+        elif field == "bsize_tiny":
+            struct.pack_into("<H", b, off + 16, 9)
+        elif field == "bsize_big":
+            struct.pack_into("<H", b, off + 16, 0xFFFF)
+        elif field == "crc":
+            b[off + bsize - 8] ^= 0x40
+        elif field == "payload_bit":
+            b[off + 12 + xlen + (bsize - xlen - 20) // 2] ^= 0x04
+        elif field == "xlen_big":
+            struct.pack_into("<H", b, off + 10, 0xFFF0)
+        else:
+            b = b[:off + bsize // 2]
+        variants.append((field, bytes(b)))
+    rng = np.random.default_rng(23)
+    for t in range(60):                                       # random bytes of the compressed file
+        b = bytearray(raw)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(bl[1][0], len(b)))] = int(rng.integers(0, 256))
+        variants.append(("bytes%d" % t, bytes(b)))
+    # the inflated stream with random damage, in valid blocks again (block k of the copy holds the bytes block k held)
+    datas = [zlib.decompress(raw[o + 12 + x:o + bz - 8], -15) for o, bz, x in bl]
+    whole = b"".join(datas)
+    rec0 = len(datas[0]) if (first >> 16) else (first & 0xFFFF)
+    starts, q = [], rec0                                       # where the records begin in the inflated stream
+    while q + 4 <= len(whole):
+        starts.append(q)
+        q += 4 + struct.unpack_from("<i", whole, q)[0]
+    edge = [-1, -5, 0, 1, 8, 31, 32, 0x7FFFFFF0, 0x10000, 65535, 1 << 29, (1 << 29) + 1]
+    for t in range(60):
+        w = bytearray(whole)
+        for _ in range(int(rng.integers(1, 4))):
+            if t % 2:                                         # a byte or a word anywhere
+                at = int(rng.integers(rec0, len(w) - 4))
+                if rng.random() < .5:
+                    w[at] = int(rng.integers(0, 256))
+                else:
+                    struct.pack_into("<i", w, at, int(rng.choice(edge + [int(rng.integers(0, 1 << 20))])))
+            else:                                             # a fixed field of a record: block_size, refID, pos, l_read_name ..
+                at = starts[int(rng.integers(0, len(starts)))]      # .. n_cigar_op, l_seq (sizes and counts live in those)
+                fld = int(rng.integers(0, 6))
+                if fld == 0:
+                    struct.pack_into("<i", w, at, int(rng.choice(edge)))
+                elif fld == 1:
+                    struct.pack_into("<i", w, at + 4, int(rng.choice([-1, 0, 1, 7])))
+                elif fld == 2:
+                    struct.pack_into("<i", w, at + 8, int(rng.choice([-1, 0, 3999, 0x7FFFFFFF])))
+                elif fld == 3:
+                    w[at + 12] = int(rng.choice([0, 1, 255]))
+                elif fld == 4:
+                    struct.pack_into("<H", w, at + 16, int(rng.choice([0, 1, 2, 0xFFFF, 30000])))
+                else:
+                    struct.pack_into("<i", w, at + 20, int(rng.choice(edge)))
+        blob, q = b"", 0
+        for d in datas:
+            blob += bamio._bgzf_block(bytes(w[q:q + len(d)]))
+            q += len(d)
+        variants.append(("stream%d" % t, blob))
+    for name, blob in variants:
+        bad = str(tmp_path / ("v_%s.bam" % name))
+        open(bad, "wb").write(blob)
+        # (stream variants: stored blocks differ in size from the original's, the records start behind the first block)
+        f0 = first if not name.startswith("stream") else ((len(bamio._bgzf_block(datas[0])) << 16) if (first >> 16) else first)
+        # (the random ones with a window behind the last read's start: every record of the file is walked)
+        out = _run_checked(asan_bam_check, bad, f0, (4000, 5500, 200) if name[-1].isalpha() else (25000, 26500, 200), threads=int(rng.integers(1, 4)))
+        n_err += "rc -4" in out or "open:" in out
+        os.remove(bad)
+    print("damaged files answered with an error:", n_err, "of", len(variants))
+    assert n_err >= 70, n_err                                 # most of the damage is noticed (some lands in bytes nothing reads)
