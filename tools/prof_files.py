@@ -9,7 +9,18 @@ tmp = tempfile.mkdtemp()
 fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
 bed = os.path.join(tmp, "in.bed"); open(bed, "w").write(synth.bed_text(w))
 def run(tag):
-    return cli.main(["bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam, "--output-path", tmp + "/f", "--output-file", tmp + "/o%s.vapor" % tag] + ([] if os.environ.get("VAPOR_PROF_FIGURES") else ["--no-figures"]))
+    return cli.main(["bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam, "--output-path", tmp + "/f", "--output-file", tmp + "/o%s.vapor" % tag] + ([] if os.environ.get("VAPOR_PROF_FIGURES") else ["--no-figures"]) + (["--chunk", os.environ["VAPOR_PROF_CHUNK"]] if os.environ.get("VAPOR_PROF_CHUNK") else []))
+if len(sys.argv) > 2 and sys.argv[2] == "--grid":
+    import contextlib, io
+    for chunk, fl in ((2048, 2), (1024, 2), (1024, 3), (512, 2), (512, 3), (512, 4), (256, 4)):
+        os.environ["VAPOR_PROF_CHUNK"] = str(chunk)
+        os.environ["VAPOR_CHUNKS_IN_FLIGHT"] = str(fl)
+        best = 1e9
+        for _ in range(4):
+            with contextlib.redirect_stdout(io.StringIO()):
+                t0 = time.perf_counter(); run("g"); best = min(best, time.perf_counter() - t0)
+        print("chunk %4d, %d in flight: %.3f s -> %.0f loci/s" % (chunk, fl, best, n / best), file=sys.stderr, flush=True)
+    sys.exit(0)
 run("a")
 t0 = time.perf_counter(); run("b"); dt = time.perf_counter() - t0
 print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt))

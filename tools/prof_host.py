@@ -1,7 +1,7 @@
 """Host-side cost of the driver pipeline WITHOUT a device (development container): an engine whose plans answer with constant
 statistics and scores, so that what is timed is everything the Python side does per locus - BED parsing, the driver
 generators, read extraction from the in-memory world, the assembly of sequence sets / pair tables / read tables, result rows.
-Not a product path and not a measurement of the product: a profiler's harness.  usage: python tools/prof_host.py [n_loci] [--profile]"""
+Not a product path and not a measurement of the product: a profiler's harness.  usage: python tools/prof_host.py [n_loci] [--svtypes A,B] [--read-len L] [--reads R] [--profile]"""
 import cProfile
 import os
 import pstats
@@ -60,7 +60,9 @@ args = sys.argv[1:]
 n = int(args[0]) if args and args[0].isdigit() else 2000
 svtypes = tuple(args[args.index("--svtypes") + 1].split(",")) if "--svtypes" in args else ("DEL", "DEL", "INV", "INS")
 t0 = time.perf_counter()
-w = synth.make_world(seed=11, n_loci=n, svtypes=svtypes, span_range=(100, 4000), read_len=9500, n_reads=20)
+read_len = int(args[args.index("--read-len") + 1]) if "--read-len" in args else 9500
+n_reads = int(args[args.index("--reads") + 1]) if "--reads" in args else 20
+w = synth.make_world(seed=11, n_loci=n, svtypes=svtypes, span_range=(100, 4000), read_len=read_len, n_reads=n_reads)
 print("world of %d loci in %.1fs" % (n, time.perf_counter() - t0), flush=True)
 tmp = tempfile.mkdtemp()
 bed = os.path.join(tmp, "in.bed")
