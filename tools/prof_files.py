@@ -21,6 +21,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "--grid":
                 t0 = time.perf_counter(); run("g"); best = min(best, time.perf_counter() - t0)
         print("chunk %4d, %d in flight: %.3f s -> %.0f loci/s" % (chunk, fl, best, n / best), file=sys.stderr, flush=True)
     sys.exit(0)
+if os.environ.get("VAPOR_PROF_SWITCH"):
+    sys.setswitchinterval(float(os.environ["VAPOR_PROF_SWITCH"]))
 run("a")
 t0 = time.perf_counter(); run("b"); dt = time.perf_counter() - t0
 print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt))

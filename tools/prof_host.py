@@ -1,7 +1,7 @@
 """Host-side cost of the driver pipeline WITHOUT a device (development container): an engine whose plans answer with constant
 statistics and scores, so that what is timed is everything the Python side does per locus - BED parsing, the driver
 generators, read extraction from the in-memory world, the assembly of sequence sets / pair tables / read tables, result rows.
-Not a product path and not a measurement of the product: a profiler's harness.  usage: python tools/prof_host.py [n_loci] [--svtypes A,B] [--read-len L] [--reads R] [--profile]"""
+Not a product path and not a measurement of the product: a profiler's harness.  usage: python tools/prof_host.py [n_loci] [--svtypes A,B] [--read-len L] [--reads R] [--files] [--profile]"""
 import cProfile
 import os
 import pstats
@@ -67,13 +67,20 @@ print("world of %d loci in %.1fs" % (n, time.perf_counter() - t0), flush=True)
 tmp = tempfile.mkdtemp()
 bed = os.path.join(tmp, "in.bed")
 open(bed, "w").write(synth.bed_text(w))
-seqio.set_backend(seqio.MemorySamtools(w))
+bam_path, fa_path = "x.bam", "ref.fa"
+if "--files" in args:                       # FASTA/BAM files through the in-process readers instead of the in-memory world
+    for c in w.reads:
+        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+    fa_path, bam_path = synth.write_world_files(w, tmp, block_size=0xFF00)
+    seqio.set_backend(seqio.InProcessBam())
+else:
+    seqio.set_backend(seqio.MemorySamtools(w))
 bed_info = cli.bed_info_readin(bed, tmp)
 pipeline._engine = NullEngine()
 
 
 def run():
-    jobs = cli.bed_jobs(bed_info, 3, "x.bam", "ref.fa", tmp + "/", "s")
+    jobs = cli.bed_jobs(bed_info, 3, bam_path, fa_path, tmp + "/", "s")
     scores = cli.score_jobs(jobs, 2048, None)
     return cli.output_rows([j.key.split(':') + [j.row_prefix] for j in jobs], scores)[0]          # (as cli.main writes them)
 

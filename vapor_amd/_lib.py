@@ -150,6 +150,24 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     return L
 
 
+_held = None
+
+
+def load_holding_gil():
+    """The same library through ctypes.PyDLL: its calls keep the interpreter lock.  For the host helpers that take a few
+    microseconds and are called once per locus (vapor_chop_records): releasing the lock around them hands it to the other
+    chunk's thread each time, and the hand-over costs more than the call (two chunks of a run are scored on two threads)."""
+    global _held
+    if _held is None:
+        load()
+        h = ctypes.PyDLL(SO_PATH)
+        vp = ctypes.c_void_p
+        h.vapor_chop_records.argtypes = [ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp]
+        h.vapor_chop_records.restype = ctypes.c_int
+        _held = h
+    return _held
+
+
 def check(rc: int) -> None:
     if rc != 0:
         raise VaporHipError(rc, load().vapor_last_error().decode("utf-8", "replace"))

@@ -255,7 +255,7 @@ class MemorySamtools:
         fn = self.__dict__.get("_chop_fn")
         if fn is None:
             from . import _lib
-            fn = self.__dict__["_chop_fn"] = _lib.load().vapor_chop_records
+            fn = self.__dict__["_chop_fn"] = _lib.load_holding_gil().vapor_chop_records      # (a ~10 us call: see there)
         import numpy as np
         # (the answers go to arrays of the call's own: chunks of a run are scored on two threads, and tiled worlds share a
         # record list between contigs)
