@@ -140,9 +140,14 @@ class InProcessBam(SamtoolsHybrid):
     def chop(self, bam: str, chrom: str, start: int, end: int, flank_length: int):
         """chop_pacbio_read_by_pos (SF:339-354) straight from the BAM file: the library's native reader
         (vapor_bam_chop), or with VAPOR_BAM_NATIVE=0 the Python statement of the same steps below."""
-        if os.environ.get("VAPOR_BAM_NATIVE", "1") != "0":
+        if not _env_is(b"VAPOR_BAM_NATIVE", b"0"):
             return self._open(bam).chop_native(chrom, int(start), int(end), int(flank_length))
         return self.chop_python(bam, chrom, start, end, flank_length)
+
+    def isfile(self, path: str) -> bool:
+        # (bam_in_decide, SF:69-89, asks once per locus: a file this reader holds open is a file - no stat, and no release of
+        # the interpreter lock around one, for the loci after the first)
+        return path in self._bam or os.path.isfile(path)
 
     def chop_python(self, bam: str, chrom: str, start: int, end: int, flank_length: int):
         """The same from the records as Python parses them: the CIGAR is walked in its binary form (the library's
@@ -281,11 +286,15 @@ class MemorySamtools:
         return ["%s\t%d\t0\t60\t61" % (k, len(v)) for k, v in self.world.contigs.items()]
 
 
-def _memory_chop_by_records() -> bool:
-    # (os.environ is a mapping with an encode per lookup: 5 us a call, asked once per locus)
+def _env_is(name: bytes, value: bytes) -> bool:
+    # (os.environ is a mapping with an encode per lookup: 5 us a call, and these are asked once per locus)
     e = os.environ
-    v = e._data.get(b"VAPOR_MEMORY_CHOP") if hasattr(e, "_data") else e.get("VAPOR_MEMORY_CHOP")
-    return v in (b"records", "records")
+    v = e._data.get(name) if hasattr(e, "_data") else e.get(name.decode())
+    return v in (value, value.decode())
+
+
+def _memory_chop_by_records() -> bool:
+    return _env_is(b"VAPOR_MEMORY_CHOP", b"records")
 
 
 def set_backend(b) -> None:
