@@ -698,6 +698,32 @@ def test_memory_backend_native_chop_equals_the_per_record_statement(monkeypatch)
         be2.chop("x.bam", chrom, 1200, 1400, 500)
 
 
+def test_score_jobs_relaxes_the_collector_and_puts_it_back(monkeypatch):
+    """cli.score_jobs raises the cyclic collector's thresholds for the duration of the scoring (its passes over everything a
+    run keeps alive cost a quarter of an 8 000-locus run) and restores what it found - also when the scoring raises."""
+    import gc
+    seen = []
+    was = gc.get_threshold()
+
+    def inner(jobs, chunk, figure_fn, t0):
+        seen.append(gc.get_threshold())
+        if jobs == "boom":
+            raise ValueError("x")
+        return []
+    monkeypatch.setattr(cli, "_score_jobs", inner)
+    assert cli.score_jobs([], 4) == [] and gc.get_threshold() == was
+    with pytest.raises(ValueError):
+        cli.score_jobs("boom", 4)
+    assert gc.get_threshold() == was
+    assert all(t[0] >= 200000 and t[1] >= 50 and t[2] >= 1000 for t in seen) and len(seen) == 2
+    gc.set_threshold(300000, 60, 2000)                       # (a caller's own, higher thresholds are kept)
+    try:
+        cli.score_jobs([], 4)
+        assert seen[-1] == (300000, 60, 2000) and gc.get_threshold() == (300000, 60, 2000)
+    finally:
+        gc.set_threshold(*was)
+
+
 @pytest.mark.parametrize("in_flight", ["1", "2"])
 def test_bed_cli_chunks_in_flight(fake, in_flight, tmp_path, monkeypatch):
     """cli.score_jobs with several chunks (--chunk 3 on the eight-locus world), one or two of them in flight on threads:

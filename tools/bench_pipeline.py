@@ -75,6 +75,14 @@ def run():
     return cli.output_rows([j.key.split(':') + [j.row_prefix] for j in jobs], scores)[0]          # (as cli.main writes them)
 
 
+import gc
+if os.environ.get("VAPOR_BENCH_GC") == "freeze":        # experiment: the world and the jobs out of the collector's sight
+    gc.collect(); gc.freeze()
+elif os.environ.get("VAPOR_BENCH_GC") == "off":
+    gc.disable()
+if os.environ.get("VAPOR_BENCH_GC_STATS"):
+    gc.callbacks.append(lambda phase, info, _t=[0.0, 0]: (_t.__setitem__(0, time.perf_counter()) if phase == "start" else
+                        (info["generation"] == 2 and print("gen2 collection %.1f ms" % ((time.perf_counter() - _t[0]) * 1e3), file=sys.stderr))))
 run()
 best = 1e9
 for _ in range(3):

@@ -325,8 +325,24 @@ def output_rows(heads: list, scores_list: list) -> tuple:
 def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
     """Score every job (sharded over ranks, batched on each GPU); returns per job the list of read
     scores, in job order, identical on every rank."""
+    import gc
     import time
     t0 = time.perf_counter()
+    # The cyclic collector looks at every container alive each time its oldest generation is due, and a run keeps its jobs,
+    # generators and read lists alive until the table is written: on an 8 000-locus run a quarter of the time went into
+    # three or four such passes of ~50 ms, and the share grows with the run.  The loop makes no reference cycles outside its error
+    # paths (reference counting frees the rest), so the thresholds are raised for its duration: young objects are still
+    # collected every 200 000 net allocations, the older generations practically never.
+    gc_was = gc.get_threshold()
+    gc.set_threshold(max(gc_was[0], 200000), max(gc_was[1], 50), max(gc_was[2], 1000))
+    try:
+        return _score_jobs(jobs, chunk, figure_fn, t0)
+    finally:
+        gc.set_threshold(*gc_was)
+
+
+def _score_jobs(jobs, chunk, figure_fn, t0):
+    import time
     mine = vdist.my_share(len(jobs))
     local: dict = {}
 
