@@ -611,6 +611,64 @@ def test_repeat_clustering_in_host_workers_equals_the_callers_own(fake, monkeypa
     assert repr(pooled) == repr(own)
 
 
+def test_repeat_clustering_direct_routes_equal_the_public_calls():
+    """repeat_qc's direct routes - the k-means++ / Lloyd routines KMeans.fit calls, and scipy.cluster.vq.kmeans's loop on its
+    compiled routines - against the public calls they stand for (sklearn.cluster.KMeans(...).fit, scipy.cluster.vq.kmeans)
+    with a seed: labels, centres and code books equal bit for bit over random point sets of the shapes a self dot plot gives
+    (lines off the diagonal, noise, duplicates, a handful of points), and the X-means block sizes of whole windows equal
+    either way.  In a child process with one OpenMP thread, as the host workers run."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, warnings
+import numpy as np
+sys.path.insert(0, %r)
+from scipy.cluster.vq import whiten
+from vapor_amd import repeat_qc as R
+warnings.simplefilter("ignore")
+assert R._direct_ok(), "the direct routes were refused by their self-check"
+rng = np.random.default_rng(77)
+n_fit = n_vq = 0
+for t in range(160):
+    n = int(rng.choice([1, 2, 3, 4, 5, 9, 30, 120, 400, 900]))
+    kind = t %% 4
+    if kind == 0:
+        pts = np.column_stack((rng.integers(0, 5000, n), rng.integers(0, 5000, n)))
+    elif kind == 1:                                  # a line off the diagonal plus noise
+        i = rng.integers(1000, 1000 + 3 * n, n); pts = np.column_stack((i + 700, i))
+        pts[: n // 5] = np.column_stack((rng.integers(0, 5000, n // 5), rng.integers(0, 5000, n // 5)))
+    elif kind == 2:                                  # two blocks
+        pts = np.column_stack((rng.integers(0, 300, n), rng.integers(0, 300, n))); pts[n // 2:] += 4000
+    else:                                            # many duplicates
+        pts = np.column_stack((rng.integers(0, 3, n) * 100, rng.integers(0, 3, n) * 100))
+    ks = list(range(1, min(5, n + 1)))
+    seed = int(rng.integers(0, 1000))
+    for a, b in zip(R._kmeans_fits_public(pts, ks, seed), R._kmeans_fits_direct(pts, ks, seed)):
+        assert np.array_equal(a.labels_, b.labels_) and np.array_equal(a.cluster_centers_, b.cluster_centers_) and a.n_clusters == b.n_clusters, (t, n)
+        n_fit += 1
+    if pts[:, 0].std() > 0 and pts[:, 1].std() > 0:
+        w = whiten(pts)
+        for k in ks[1:]:
+            assert np.array_equal(R._vq_kmeans_public(w, k, seed), R._vq_kmeans_direct(w, k, seed)), (t, n, k)
+            n_vq += 1
+os.environ["VAPOR_QC_SEED"] = "7"
+wins = []
+for span in (120, 400, 900, 2500):
+    i = np.arange(3000, 3000 + span)
+    nj, ni = rng.integers(0, 12000, 150), rng.integers(0, 12000, 150)
+    keep = nj > ni
+    wins.append(np.column_stack((np.concatenate((i + span, nj[keep])), np.concatenate((i, ni[keep])))))
+direct = [R.cluster_sizes_of_points(w) for w in wins]
+R._DIRECT = False
+public = [R.cluster_sizes_of_points(w) for w in wins]
+assert repr(direct) == repr(public) and any(len(d) > 1 for d in direct)
+print("fits", n_fit, "code books", n_vq, "windows", len(wins))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fits" in r.stdout, r.stderr[-3000:]
+
+
 def test_kept_figure_writes_the_same_bytes_as_a_fresh_one(fake, tmp_path):
     """figures.render keeps its matplotlib figure between calls; figures.render_fresh makes the reference's calls one by
     one on a new figure: the PNG files are equal byte for byte, whatever was drawn before (larger, smaller, other ticks)."""

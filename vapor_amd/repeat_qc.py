@@ -69,22 +69,120 @@ def _bic(km, X) -> float:
     return np.sum(terms) - 0.5 * m * _log10(N)
 
 
+class _Fit:
+    """What _bic and _split_once read of a fitted sklearn KMeans."""
+    __slots__ = ("labels_", "cluster_centers_", "n_clusters")
+
+    def __init__(self, labels, centers, k):
+        self.labels_, self.cluster_centers_, self.n_clusters = labels, centers, k
+
+
+def _kmeans_fits_public(pts, ks, rs):
+    from sklearn import cluster
+    return [cluster.KMeans(n_clusters=k, init="k-means++", random_state=rs).fit(pts) for k in ks]
+
+
+def _kmeans_fits_direct(pts, ks, rs):
+    """The same fits - the same arithmetic on the same random draws, bit for bit - through the routines KMeans.fit itself calls
+    (k-means++ seeding, one Lloyd run: n_init is 1 for this init), without what the estimator spends around them on a few
+    hundred points: parameter and input validation per fit, the mean, norms and tolerance of the same points four times
+    (1.5 ms of a 2 ms fit).  Private routines of scikit-learn: `_direct_ok` decides once per process whether they are there and
+    answer as the estimator does."""
+    from sklearn.cluster import _kmeans as K
+    from sklearn.utils import check_random_state
+    from sklearn.utils._openmp_helpers import _openmp_effective_n_threads
+    from sklearn.utils.extmath import row_norms
+    n_threads = _openmp_effective_n_threads()          # (as KMeans.fit asks: 1 in the host workers, which run with OMP_NUM_THREADS=1)
+    X = np.array(pts, dtype=np.float64, order="C")
+    mean = X.mean(axis=0)
+    X -= mean
+    norms = row_norms(X, squared=True)
+    tol = K._tolerance(X, 1e-4)
+    weight = np.ones(X.shape[0], dtype=X.dtype)
+    fits = []
+    for k in ks:
+        init, _ = K._kmeans_plusplus(X, k, random_state=check_random_state(rs), x_squared_norms=norms, sample_weight=weight)
+        labels, _inertia, centers, _n = K._kmeans_single_lloyd(X, weight, init, max_iter=300, verbose=0, tol=tol, n_threads=n_threads)
+        fits.append(_Fit(labels, centers + mean, k))
+    return fits
+
+
+def _vq_kmeans_public(white, k, rs):
+    from scipy.cluster.vq import kmeans
+    return kmeans(white, k, seed=rs)[0] if rs is not None else kmeans(white, k)[0]
+
+
+def _vq_kmeans_direct(white, k, rs):
+    """scipy.cluster.vq.kmeans(white, k): twenty runs from k observations drawn at random, each until the mean distortion
+    moves by 1e-5 or less, the code book of the lowest distortion - the same loop on the same draws with the same compiled
+    routines (`_vq.vq`, `_vq.update_cluster_means`), without the array-namespace conversions SciPy wraps around every step
+    (eight of ten parts of its time on a few hundred points).  Private module of SciPy: see `_direct_ok`."""
+    from scipy._lib._util import check_random_state
+    from scipy.cluster import _vq
+    obs = np.ascontiguousarray(white, dtype=np.float64)
+    rng = check_random_state(rs)
+    best_book, best = None, np.inf
+    for _ in range(20):
+        book = obs[rng.choice(obs.shape[0], size=int(k), replace=False)]
+        before, last = np.inf, np.inf
+        while True:
+            code, dist = _vq.vq(obs, book)
+            before, last = last, np.add.reduce(dist) / dist.shape[0]          # (= np.mean(dist): the same sum, the same division)
+            book, has = _vq.update_cluster_means(obs, code, book.shape[0])
+            book = book[has]
+            if not abs(before - last) > 1e-5:
+                break
+        if last < best:
+            best_book, best = book, last
+    return best_book
+
+
+_DIRECT = None
+
+
+def _direct_ok() -> bool:
+    """Whether the two direct routes exist in the installed scikit-learn / SciPy and give what the public calls give, on seeded
+    cases of the sizes met here (once per process; VAPOR_QC_DIRECT=0 keeps the public calls)."""
+    global _DIRECT
+    if _DIRECT is None:
+        ok = os.environ.get("VAPOR_QC_DIRECT", "1") != "0"
+        if ok:
+            try:
+                import warnings
+                from scipy.cluster.vq import whiten
+                rng = np.random.default_rng(20260704)
+                with warnings.catch_warnings(), _one_thread():
+                    warnings.simplefilter("ignore")
+                    for n in (3, 40, 300):
+                        pts = np.column_stack((rng.integers(0, 4000, n), rng.integers(0, 4000, n)))
+                        pts[n // 2:, 0] += 3000
+                        ks = list(range(1, min(5, n + 1)))
+                        for a, b in zip(_kmeans_fits_public(pts, ks, 5), _kmeans_fits_direct(pts, ks, 5)):
+                            ok = ok and np.array_equal(a.labels_, b.labels_) and np.array_equal(a.cluster_centers_, b.cluster_centers_)
+                        for k in ks[1:]:
+                            ok = ok and np.array_equal(_vq_kmeans_public(whiten(pts), k, 5), _vq_kmeans_direct(whiten(pts), k, 5))
+            except Exception:              # noqa: BLE001 - another version of either library: the public calls
+                ok = False
+        _DIRECT = bool(ok)
+    return _DIRECT
+
+
 def _split_once(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     """k_means_cluster, SF:856-887: choose k in 1..4 by BIC, split with scipy's kmeans."""
     if not (max(xs) - min(xs) > 10 and max(ys) - min(ys) > 10):
         return [[list(xs), list(ys)]]
-    from scipy.cluster.vq import kmeans, vq, whiten
-    from sklearn import cluster
+    from scipy.cluster.vq import vq, whiten
     seed = os.environ.get("VAPOR_QC_SEED")
     rs = int(seed) if seed else None
     pts = np.column_stack((np.asarray(xs), np.asarray(ys)))        # = np.array([[x, y] ...]) of SF:858
     ks = list(range(1, min([5, len(xs) + 1])))
+    direct = _direct_ok()
     # the reference fits every k twice (SF:860-861: once for the BIC, once more only to test whether a
     # cluster came out empty); one fit serves both here - the draws are unseeded either way
     # a few hundred 2-D points: one OpenMP thread (the team start-up of sklearn's Lloyd loop costs several times the
     # fit itself at this size; the arithmetic is the same)
     with _one_thread():
-        fits = [cluster.KMeans(n_clusters=k, init="k-means++", random_state=rs).fit(pts) for k in ks]
+        fits = (_kmeans_fits_direct if direct else _kmeans_fits_public)(pts, ks, rs)
     preds = [f.labels_ for f in fits]
     bic, bic_k = [], []
     for k in ks:
@@ -98,10 +196,7 @@ def _split_once(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     if picked == 1:
         return [[list(xs), list(ys)]]
     white = whiten(pts)
-    if rs is not None:
-        cent, _ = kmeans(white, picked, seed=rs)
-    else:
-        cent, _ = kmeans(white, picked)
+    cent = (_vq_kmeans_direct if direct else _vq_kmeans_public)(white, picked, rs)
     idx, _ = vq(white, cent)
     return [[pts[idx == c, 0].tolist(), pts[idx == c, 1].tolist()] for c in range(picked)]
 
