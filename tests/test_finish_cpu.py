@@ -30,3 +30,22 @@ def test_rounded_nonpositive_matches_python_round():
                         -0.0, 0.0, 0.015, 0.004999999999999999, np.nextafter(0.005, 0), np.nextafter(0.005, 1)])])
     exp = np.array([not float(str(round(float(x), 2))) > 0 for x in v])
     assert (finish.rounded_nonpositive(v) == exp).all()
+
+
+def test_genotype_table_equals_the_scalar_statement():
+    """finish.gt_table (what vapor_plan_set_reads hands the device-side finish; built a row of l at a time) against
+    _gt_from_counts - log_likelihood_calcu and the arg-max / quality of gt_estimate_log_likelihood (SF:2054-2077) term by
+    term - for every (k, l) of the table: genotype index and quality equal bit for bit."""
+    from vapor_amd import _lib as L
+    t = finish._gt_table_rows(L.GT_TABLE_N)
+    assert t.shape == (L.GT_TABLE_N, L.GT_TABLE_N, 2)
+    n = 0
+    with np.errstate(divide="ignore"):
+        for k in range(1, L.GT_TABLE_N):
+            for l in range(k + 1):
+                idx, gq = finish._gt_from_counts(k, l)
+                assert t[k, l, 0] == idx and (t[k, l, 1] == gq or (np.isnan(gq) and np.isnan(t[k, l, 1]))), (k, l)
+                n += 1
+            assert not t[k, k + 1:].any()
+    assert n == (L.GT_TABLE_N - 1) * (L.GT_TABLE_N + 2) // 2
+    assert finish.gt_table() is finish.gt_table()

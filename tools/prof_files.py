@@ -23,6 +23,16 @@ if len(sys.argv) > 2 and sys.argv[2] == "--grid":
     sys.exit(0)
 if os.environ.get("VAPOR_PROF_SWITCH"):
     sys.setswitchinterval(float(os.environ["VAPOR_PROF_SWITCH"]))
+if os.environ.get("VAPOR_PROF_FIRST"):                   # where the first (cold) run of a process spends its time
+    import contextlib, io
+    pr = cProfile.Profile()
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter(); pr.runcall(run, "a"); dt = time.perf_counter() - t0
+    print("first run: %d loci in %.3f s" % (n, dt), file=sys.stderr)
+    st = pstats.Stats(pr, stream=sys.stderr)
+    st.sort_stats("tottime").print_stats(16)
+    st.sort_stats("cumulative").print_stats(40)
+    sys.exit(0)
 run("a")
 t0 = time.perf_counter(); run("b"); dt = time.perf_counter() - t0
 print("in-process files run: %d loci in %.3f s -> %.1f loci/s" % (n, dt, n / dt))

@@ -311,11 +311,33 @@ def gt_table() -> np.ndarray:
     for the device-side finish (include/vapor_hip.h, vapor_plan_set_reads)."""
     global _GT_TABLE
     if _GT_TABLE is None:
-        t = np.zeros((L.GT_TABLE_N, L.GT_TABLE_N, 2), dtype=np.float64)
-        for k in range(1, L.GT_TABLE_N):
-            for l in range(0, k + 1):
-                idx, gq = _gt_from_counts(k, l)
-                t[k, l, 0] = idx
-                t[k, l, 1] = gq
-        _GT_TABLE = t
+        _GT_TABLE = _gt_table_rows(L.GT_TABLE_N)
     return _GT_TABLE
+
+
+def _gt_table_rows(n: int) -> np.ndarray:
+    """_gt_from_counts for every (k, l), k < n, with the same float64 operations in the same order, a row of l at a time
+    (0.4 s of scalar loops at every process start otherwise): the log-likelihood of genotype g is -k ln 2, then l times
+    + ln((2-g) 0.05 + g 0.95), then (k - l) times + ln((2-g) 0.95 + g 0.05), added one by one (SF:2071-2077) - a running sum
+    over l for the first part, k steps over the whole row for the second; arg-max, normalisation, median of three and the
+    quality as SF:2058-2066.  tests/test_finish_cpu.py compares the table with the scalar statement entry for entry."""
+    t = np.zeros((n, n, 2), dtype=np.float64)
+    ln2 = np.log(2)
+    for k in range(1, n):
+        ll = []
+        for g in (2, 1, 0):
+            a = np.log((2 - g) * 0.05 + g * (1 - 0.05))
+            b = np.log((2 - g) * (1 - 0.05) + g * 0.05)
+            cur = np.cumsum(np.concatenate(([-k * ln2], np.full(k, a))))       # cur[l] = (..((-k ln 2 + a) + a) ..) l times
+            for step in range(1, k + 1):
+                cur[:k - step + 1] += b                                         # the entries with k - l >= step
+            ll.append(cur)
+        ll = np.stack(ll)                                                       # (3, k + 1): rows g = 2, 1, 0
+        top = ll.max(axis=0)
+        ori = np.exp(ll - top)
+        norm = ori / ((ori[0] + ori[1]) + ori[2])
+        with np.errstate(divide="ignore"):
+            gq = -np.log(np.sort(norm, axis=0)[1]) / np.log(10)
+        t[k, :k + 1, 0] = np.argmax(ll, axis=0)                                 # (the first of equal maxima, as list.index)
+        t[k, :k + 1, 1] = gq
+    return t
