@@ -268,6 +268,38 @@ def test_melt_ins_mode(fake, tmp_path):
     assert rc == 0 and got == exp
 
 
+def test_chromos_readin_keeps_the_names_until_the_index_changes(tmp_path):
+    """seqio.chromos_readin (SF:356-363; the reference reads the .fai again per unclassified record): the names as a list,
+    `in` as the list would answer, read once per index file and backend - and again when the file changes or, for an
+    in-memory world, when its contig table does."""
+    import time
+    fa = tmp_path / "ref.fa"
+    fai = tmp_path / "ref.fa.fai"
+    fai.write_text("chr1\t1000\t6\t60\t61\nchr2 extra\t500\t1100\t60\t61\n\n")
+    calls = []
+
+    class Be(seqio.InProcessBam):
+        def fai_lines(self, ref):
+            calls.append(ref)
+            return super().fai_lines(ref)
+    seqio.set_backend(Be())
+    try:
+        a = seqio.chromos_readin(str(fa))
+        assert a == ["chr1", "chr2"] and isinstance(a, list) and "chr2" in a and "chr3" not in a and ["x"] not in a and 7 not in a
+        assert seqio.chromos_readin(str(fa)) is a and len(calls) == 1
+        time.sleep(0.01)
+        fai.write_text("chr1\t1000\t6\t60\t61\nchr2\t500\t1100\t60\t61\nchr3\t9\t1700\t60\t61\n")
+        assert seqio.chromos_readin(str(fa)) == ["chr1", "chr2", "chr3"] and len(calls) == 2
+        w = synth.make_world(seed=5, n_loci=2, svtypes=("DEL",), span_range=(100, 300), read_len=1200, n_reads=3)
+        seqio.set_backend(seqio.MemorySamtools(w))
+        names = seqio.chromos_readin("ref.fa")
+        assert names == list(w.contigs) and seqio.chromos_readin("ref.fa") is names
+        w.contigs["later"] = "ACGT"
+        assert seqio.chromos_readin("ref.fa") == list(w.contigs) and "later" in seqio.chromos_readin("ref.fa")
+    finally:
+        seqio.set_backend(None)
+
+
 def test_fai_fasta_reader_matches_faidx_semantics(tmp_path):
     """In-process .fai reader: 1-based inclusive windows, clipping, and the lines ref_seq_readin parses."""
     rng = np.random.default_rng(3)
