@@ -8,8 +8,10 @@
  * and calls through this ABI with ctypes (INTEGRATION.md shows the binding).
  *
  * Conventions: plain pointers and sizes; all buffers caller-allocated and never retained;
- * every function returns 0 or a negative VAPOR_E_* code; vapor_last_error() gives a
- * thread-local message.  One host thread per context.  No exception crosses the boundary.
+ * every function returns 0 or a negative VAPOR_E_* code (vapor_abi_version, vapor_build_flags, the two *_last_error
+ * calls and vapor_crc32 return what their names say); vapor_last_error() gives a thread-local message (vapor_bam_last_error()
+ * for the host helpers of the read extraction and the output table).  One host thread per context.  No exception crosses the
+ * boundary.
  */
 #ifndef VAPOR_HIP_H
 #define VAPOR_HIP_H
