@@ -381,6 +381,19 @@ def test_inprocess_bam_reader_equals_memory_backend(tmp_path):
         assert r1 == r2
 
 
+def test_workflow_chooses_ranks_per_gpu_from_input_and_cores(tmp_path):
+    """The launcher's default for --ranks-per-gpu: one rank per four cores of the host's quota, four at most, 3 000
+    records per rank at least - so small inputs still run in the calling process."""
+    from vapor_amd import workflow
+    f = workflow.auto_ranks_per_gpu
+    assert f(19, 1, 16) == 1 and f(2999, 1, 64) == 1 and f(6000, 1, 16) == 2 and f(12000, 1, 16) == 4 and f(10 ** 6, 1, 16) == 4
+    assert f(50000, 1, 8) == 2 and f(50000, 1, 3) == 1 and f(50000, 8, 128) == 2 and f(10 ** 6, 8, 128) == 4 and f(10 ** 6, 8, 16) == 1
+    assert f(0, 1, 16) == 1 and f(10 ** 6, 0, 16) == 4
+    bed = tmp_path / "x.bed"
+    bed.write_text("#chr\tstart\n" + "".join("c\t%d\t%d\tDEL\n" % (i, i + 9) for i in range(7)) + "\n\n")
+    assert workflow._count_records(str(bed)) == 7 and workflow._count_records(str(tmp_path / "none.bed")) == 0
+
+
 def test_workflow_sorted_bgzipped_indexed_table(fake, tmp_path):
     """§8f-4: the node launcher's gather side - the CLI's table, version-sorted, block-gzipped and tabix-indexed
     (what the reference's WDL does with sort -V | bgzip | tabix -p bed)."""

@@ -24,7 +24,8 @@ from vapor_amd.finish import result_organize_ins
 args = sys.argv[1:]
 n = int(args[0]) if args and args[0].isdigit() else 400
 svtypes = tuple(args[args.index("--svtypes") + 1].split(",")) if "--svtypes" in args else ("DEL", "DEL", "INV", "INS")
-ranks = int(args[args.index("--ranks") + 1]) if "--ranks" in args else 1
+ranks = (args[args.index("--ranks") + 1] if "--ranks" in args else "1")
+ranks = ranks if ranks == "auto" else int(ranks)          # ("auto": the launcher's own choice, files mode only)
 t0 = time.perf_counter()
 w = synth.make_world(seed=11, n_loci=n, svtypes=svtypes, span_range=(100, 4000), read_len=9500, n_reads=20)
 print("world of %d loci (%s) in %.1fs" % (n, "/".join(svtypes), time.perf_counter() - t0), flush=True)
@@ -39,17 +40,17 @@ if "--files" in args:
     fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
     print("files in %.1fs (%.1f MB BAM)" % (time.perf_counter() - t0, os.path.getsize(bam) / 1e6), flush=True)
     env = dict(os.environ, PYTHONPATH=ROOT, VAPOR_TIMING="1", OMP_NUM_THREADS="1")
-    for r in sorted({1, ranks}):
-        out = os.path.join(tmp, "out%d.vapor" % r)
+    for r in ([1, "auto"] if ranks == "auto" else sorted({1, ranks})):
+        out = os.path.join(tmp, "out%s.vapor" % r)
         t0 = time.perf_counter()
         p = subprocess.run([sys.executable, "-m", "vapor_amd.workflow", "--gpus", "1", "--ranks-per-gpu", str(r), "--prefix",
-                            os.path.join(tmp, "o%d" % r), "bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam,
+                            os.path.join(tmp, "o%s" % r), "bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam,
                             "--output-path", tmp + "/figs", "--output-file", out, "--no-figures"], env=env, cwd=ROOT,
                            capture_output=True, text=True)
         wall = time.perf_counter() - t0
         line = [l for l in p.stderr.splitlines() if "loci/s" in l]
-        print("ranks=%d rc=%d wall %.1fs  %s" % (r, p.returncode, wall, line[-1] if line else p.stderr[-400:]), flush=True)
-    a, b = open(os.path.join(tmp, "out1.vapor")).read(), open(os.path.join(tmp, "out%d.vapor" % ranks)).read()
+        print("ranks=%s rc=%d wall %.1fs  %s" % (r, p.returncode, wall, line[-1] if line else p.stderr[-400:]), flush=True)
+    a, b = open(os.path.join(tmp, "out1.vapor")).read(), open(os.path.join(tmp, "out%s.vapor" % ranks)).read()
     print("tables identical:", a == b, " rows:", a.count("\n"))
     sys.exit(0)
 

@@ -7,7 +7,7 @@ the scatter is needed - `vapor_amd.cli` shards the loci over the ranks of a torc
 is the gather side only: the same sorted, block-gzipped table plus its tabix index, written in-process
 (no bgzip / tabix binaries), and a launcher that runs the CLI on N GPUs and then produces them.
 
-    python -m vapor_amd.workflow --gpus 8 [--ranks-per-gpu R] --prefix sample1 bed --sv-input x.bed --reference ref.fa \\
+    python -m vapor_amd.workflow --gpus 8 [--ranks-per-gpu R|auto] --prefix sample1 bed --sv-input x.bed --reference ref.fa \\
            --pacbio-input reads.bam --output-path figs/ --output-file sample1.vapor
 
 writes sample1.vapor (the CLI's table, unchanged), sample1.bed.gz and sample1.bed.gz.tbi.
@@ -214,14 +214,31 @@ def merge_tables(tables: Sequence[str], prefix: str, index: bool = True) -> str:
 # ---------------------------------------------------------------------------------------------
 # launcher
 # ---------------------------------------------------------------------------------------------
+def auto_ranks_per_gpu(n_records: int, gpus: int, cores: int) -> int:
+    """Ranks per GPU when the caller does not say: a whole run waits for the host side (the interpreter's share of every
+    locus, BAM decompression) far longer than for the kernels, and that share does not thread - so ranks share a GPU, one per
+    four cores of the host's quota, four at most (10 800 instead of 5 600 loci/s from files on a 16-core box), but only
+    where every rank gets 3 000 records at least: a rank costs half a second to start."""
+    gpus = max(1, gpus)
+    return max(1, min(4, cores // (4 * gpus), n_records // (3000 * gpus)))
+
+
+def _count_records(path: str) -> int:
+    try:
+        with open(path, "rb") as f:
+            return sum(1 for ln in f if ln.strip() and not ln.startswith(b"#"))
+    except OSError:
+        return 0
+
+
 def main(argv: List[str] = None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
-    gpus, prefix, index, per_gpu = 1, None, True, 1
+    gpus, prefix, index, per_gpu = 1, None, True, "auto"
     while argv and argv[0].startswith("--"):
         if argv[0] == "--gpus":
             gpus = int(argv[1]); argv = argv[2:]
         elif argv[0] == "--ranks-per-gpu":
-            per_gpu = int(argv[1]); argv = argv[2:]
+            per_gpu = argv[1] if argv[1] == "auto" else int(argv[1]); argv = argv[2:]
         elif argv[0] == "--prefix":
             prefix = argv[1]; argv = argv[2:]
         elif argv[0] == "--no-index":
@@ -238,6 +255,11 @@ def main(argv: List[str] = None) -> int:
     table = opt("--sv-input") + ".vapor" if mode == "vcf" else opt("--output-file")
     if prefix is None:
         prefix = re.sub(r"\.vapor$", "", table)
+    if per_gpu == "auto":
+        from . import pipeline
+        per_gpu = auto_ranks_per_gpu(_count_records(opt("--sv-input")), gpus, pipeline._usable_cores())
+        if per_gpu > 1:
+            print("vapor_amd.workflow: %d ranks per GPU (--ranks-per-gpu to choose)" % per_gpu, file=sys.stderr)
     if gpus * per_gpu > 1:
         # one rank per GPU over RCCL, or several per GPU (LOCAL_RANK modulo the GPUs; gloo between them): a whole
         # `vapor` run waits for the host side - BAM decompression, CIGAR walks, the per-locus Python - far longer
