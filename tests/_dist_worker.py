@@ -1,5 +1,5 @@
 """Worker for tests/test_dist_gloo.py: one rank of a world_size-N `vapor bed` run on CPU
-(gloo), device work answered by the oracle-backed fake engine (test infrastructure)."""
+(gloo, or the launcher's own exchange through files), device work answered by the oracle-backed fake engine (test infrastructure)."""
 import os
 import sys
 
@@ -18,7 +18,7 @@ def main():
     case = [c for c in load_golden("locus_bed.json.gz")["cases"] if c["name"] == case_name][0]
     pipeline.set_engine(FakeEngine(orc))
     seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
-    dist.init_from_env("gloo")
+    dist.init_from_env(os.environ.get("VAPOR_TEST_BACKEND", "gloo"))
     rc = cli.main(["bed", "--sv-input", bed, "--reference", "ref.fa", "--pacbio-input", "x.bam",
                    "--output-path", figs, "--output-file", out, "--no-figures", "--chunk", "3"])
     n_plans = len(pipeline.get_engine().batches)

@@ -45,3 +45,58 @@ def test_two_rank_bed_run_matches_reference(tmp_path, world, oracle):
     assert out.read_text() == case["vapor_text"]
     # every rank did device work on its own share only
     assert all("plans" in l for l in logs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_exchanging_through_files_match_reference(tmp_path, world, oracle):
+    """The exchange the workflow launcher's own ranks use (several per GPU on one node; vapor_amd.dist's "files" backend: a
+    file per rank in a directory of the launcher's, no process group and no torch): the same table as one process and the
+    reference write."""
+    case = [c for c in load_golden("locus_bed.json.gz")["cases"] if c["name"] == "bed_hom_alt"][0]
+    bed = tmp_path / "in.bed"
+    bed.write_text(case["bed"])
+    out = tmp_path / "out.vapor"
+    d = tmp_path / "ranks"
+    d.mkdir()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), OMP_NUM_THREADS="1",
+                   VAPOR_TEST_BACKEND="files", VAPOR_DIST_DIR=str(d), VAPOR_LOCAL_GPUS="1", VAPOR_DIST_TIMEOUT="200")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), case["name"],
+                                       str(bed), str(out), str(tmp_path / "figs")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+        assert p.returncode == 0, o
+    assert out.read_text() == case["vapor_text"]
+    assert all("plans" in l for l in logs)
+    assert sorted(os.listdir(d)) == ["s0_r%d.bin" % r for r in range(world)]
+
+
+def test_file_exchange_gives_up_on_a_failed_or_silent_rank(tmp_path, monkeypatch):
+    """A rank that waits for another's scores stops when the launcher has marked the run as failed, or after the timeout."""
+    import numpy as np
+    from vapor_amd import dist
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("VAPOR_DIST_DIR", str(tmp_path))
+    monkeypatch.setenv("VAPOR_DIST_TIMEOUT", "0.2")
+    dist.init_from_env("files")
+    try:
+        assert dist.world() == 2 and dist.rank() == 0 and dist.my_share(5) == [0, 2, 4]
+        with pytest.raises(RuntimeError, match="did not deliver"):
+            dist.gather_results({0: [0.5], 2: [], 4: [1.0, -1.0]}, 5)
+        (tmp_path / "abort").write_text("")
+        monkeypatch.setenv("VAPOR_DIST_TIMEOUT", "60")
+        with pytest.raises(RuntimeError, match="another rank"):
+            dist.gather_results({0: [0.5], 2: [], 4: [1.0, -1.0]}, 5)
+    finally:
+        dist.finalize()
+    assert dist.world() == 1 and dist.rank() == 0

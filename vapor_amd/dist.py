@@ -14,6 +14,7 @@ from typing import Dict, List, Sequence
 import numpy as np
 
 _pg = None
+_files = None           # the "files" backend: {"dir", "rank", "world", "step"}
 
 
 def _device_ordinal() -> int:
@@ -21,6 +22,9 @@ def _device_ordinal() -> int:
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     if lr == 0:
         return 0                       # (a single process never pays the import of torch: 1.5 s of a short run)
+    told = os.environ.get("VAPOR_LOCAL_GPUS")          # (the workflow launcher says how many GPUs it was given)
+    if told and int(told) > 0:
+        return lr % int(told)
     try:
         import torch
         n = torch.cuda.device_count()
@@ -31,9 +35,16 @@ def _device_ordinal() -> int:
 
 def init_from_env(backend: str = None) -> None:
     """Join the process group torchrun describes (no-op for a single process)."""
-    global _pg
+    global _pg, _files
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 or _pg is not None:
+        return
+    if (backend or os.environ.get("VAPOR_DIST_BACKEND")) == "files":
+        # Ranks that the workflow launcher started itself on one node (several per GPU: host-side parallelism).  Their only
+        # exchange is the gather of a few kilobytes of scores per rank at the end of a run: a file per rank in a directory
+        # of the launcher's, no process group - and no import of torch, which costs such a run more than its scoring.
+        _files = {"dir": os.environ["VAPOR_DIST_DIR"], "rank": int(os.environ.get("RANK", "0")), "world": world, "step": 0}
+        _pg = "files"
         return
     import torch
     import torch.distributed as dist
@@ -54,7 +65,10 @@ def init_from_env(backend: str = None) -> None:
 
 
 def finalize() -> None:
-    global _pg
+    global _pg, _files
+    if _pg == "files":
+        _pg = _files = None            # (the directory is the launcher's)
+        return
     if _pg is not None:
         import torch.distributed as dist
         if dist.is_initialized():
@@ -65,6 +79,8 @@ def finalize() -> None:
 def world() -> int:
     if _pg is None:
         return 1
+    if _pg == "files":
+        return _files["world"]
     import torch.distributed as dist
     return dist.get_world_size()
 
@@ -72,8 +88,40 @@ def world() -> int:
 def rank() -> int:
     if _pg is None:
         return 0
+    if _pg == "files":
+        return _files["rank"]
     import torch.distributed as dist
     return dist.get_rank()
+
+
+def _gather_through_files(flat: np.ndarray, extra: Dict[int, object]):
+    """Every rank's (vector, objects) through the launcher's directory: written under a temporary name and renamed, so a
+    reader sees a whole file or none; a rank that waits gives up when the launcher has marked the run as failed (a rank
+    ended badly) or after VAPOR_DIST_TIMEOUT seconds."""
+    import pickle
+    import time
+    d, me, nw = _files["dir"], _files["rank"], _files["world"]
+    step = _files["step"]
+    _files["step"] += 1
+    tmp = os.path.join(d, "s%d_r%d.tmp" % (step, me))
+    with open(tmp, "wb") as f:
+        pickle.dump((np.ascontiguousarray(flat, dtype=np.float64), extra), f, protocol=4)
+    os.replace(tmp, os.path.join(d, "s%d_r%d.bin" % (step, me)))
+    out = []
+    deadline = time.monotonic() + float(os.environ.get("VAPOR_DIST_TIMEOUT", "86400"))
+    for r in range(nw):
+        path = os.path.join(d, "s%d_r%d.bin" % (step, r))
+        pause = 0.0005
+        while not os.path.exists(path):
+            if os.path.exists(os.path.join(d, "abort")):
+                raise RuntimeError("vapor_amd.dist: another rank of this run failed")
+            if time.monotonic() > deadline:
+                raise RuntimeError("vapor_amd.dist: rank %d did not deliver its scores" % r)
+            time.sleep(pause)
+            pause = min(pause * 2, 0.05)
+        with open(path, "rb") as f:
+            out.append(pickle.load(f))
+    return out
 
 
 def partition(costs: Sequence[float], n_parts: int) -> List[List[int]]:
@@ -138,6 +186,16 @@ def gather_results(local: Dict[int, object], n_items: int, costs: Sequence[float
         for t in range(n_items):
             v = local[t]
             out[t] = v if isinstance(v, BaseException) or v is None else [float(x) for x in v]
+        return out
+    if _pg == "files":
+        shares = partition([1.0] * n_items if costs is None else costs, _files["world"])
+        flat, extra = pack_records(local, shares[_files["rank"]])
+        all_extra: Dict[int, object] = {}
+        got = _gather_through_files(flat, extra)
+        for _v, e in got:
+            all_extra.update(e)
+        for r, (v, _e) in enumerate(got):
+            unpack_records(v, shares[r], all_extra, out)
         return out
     import torch
     import torch.distributed as dist

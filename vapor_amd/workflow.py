@@ -232,6 +232,40 @@ def _count_records(path: str) -> int:
         return 0
 
 
+def _run_local_ranks(gpus: int, world: int, argv: List[str]) -> int:
+    """`world` processes of `python -m vapor_amd.cli argv` on this node, rank r on GPU r modulo `gpus`; returns the first
+    non-zero exit code (the others are told to stop waiting for that rank's scores, then ended)."""
+    import shutil
+    import tempfile
+    import time
+    d = tempfile.mkdtemp(prefix="vapor_ranks_")
+    procs = []
+    try:
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world),
+                       VAPOR_DIST_BACKEND="files", VAPOR_DIST_DIR=d, VAPOR_LOCAL_GPUS=str(max(gpus, 1)))
+            procs.append(subprocess.Popen([sys.executable, "-m", "vapor_amd.cli"] + argv, env=env))
+        rc = 0
+        left = set(range(world))
+        while left:
+            for r in sorted(left):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                left.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    open(os.path.join(d, "abort"), "w").close()
+            if left:
+                time.sleep(0.01)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main(argv: List[str] = None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     gpus, prefix, index, per_gpu = 1, None, True, "auto"
@@ -261,10 +295,14 @@ def main(argv: List[str] = None) -> int:
         per_gpu = auto_ranks_per_gpu(_count_records(opt("--sv-input")), gpus, pipeline._usable_cores())
         if per_gpu > 1:
             print("vapor_amd.workflow: %d ranks per GPU (--ranks-per-gpu to choose)" % per_gpu, file=sys.stderr)
-    if gpus * per_gpu > 1:
-        # one rank per GPU over RCCL, or several per GPU (LOCAL_RANK modulo the GPUs; gloo between them): a whole
-        # `vapor` run waits for the host side - BAM decompression, CIGAR walks, the per-locus Python - far longer
-        # than for the kernels, so ranks that share a GPU scale it until the GPU is busy
+    if per_gpu > 1 and os.environ.get("VAPOR_LAUNCHER", "files") != "torchrun":
+        # several ranks per GPU (LOCAL_RANK modulo the GPUs): a whole `vapor` run waits for the host side - BAM
+        # decompression, CIGAR walks, the per-locus Python - far longer than for the kernels, so ranks that share a GPU scale
+        # it until the GPU is busy.  They are started here and hand their scores over through a directory (vapor_amd.dist,
+        # the "files" backend): no torch.distributed.run and no process group, whose imports cost 2.5 s per launch.
+        rc = _run_local_ranks(gpus, gpus * per_gpu, argv)
+    elif gpus * per_gpu > 1:
+        # one rank per GPU over RCCL (or, VAPOR_LAUNCHER=torchrun, several per GPU with gloo between them)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus * per_gpu),
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29513"),
                "-m", "vapor_amd.cli"] + argv
