@@ -382,12 +382,12 @@ def test_inprocess_bam_reader_equals_memory_backend(tmp_path):
 
 
 def test_workflow_chooses_ranks_per_gpu_from_input_and_cores(tmp_path):
-    """The launcher's default for --ranks-per-gpu: one rank per four cores of the host's quota, four at most, 10 000
-    records per rank at least - so small and medium inputs still run in the calling process."""
+    """The launcher's default for --ranks-per-gpu: one rank per four cores of the host's quota, four at most, 3 000
+    records per rank at least - so small inputs still run in the calling process."""
     from vapor_amd import workflow
     f = workflow.auto_ranks_per_gpu
-    assert f(19, 1, 16) == 1 and f(9999, 1, 64) == 1 and f(20000, 1, 16) == 2 and f(40000, 1, 16) == 4 and f(10 ** 6, 1, 16) == 4
-    assert f(50000, 1, 8) == 2 and f(50000, 1, 3) == 1 and f(200000, 8, 128) == 2 and f(10 ** 6, 8, 128) == 4 and f(10 ** 6, 8, 16) == 1
+    assert f(19, 1, 16) == 1 and f(2999, 1, 64) == 1 and f(6000, 1, 16) == 2 and f(12000, 1, 16) == 4 and f(10 ** 6, 1, 16) == 4
+    assert f(50000, 1, 8) == 2 and f(50000, 1, 3) == 1 and f(50000, 8, 128) == 2 and f(10 ** 6, 8, 128) == 4 and f(10 ** 6, 8, 16) == 1
     assert f(0, 1, 16) == 1 and f(10 ** 6, 0, 16) == 4
     bed = tmp_path / "x.bed"
     bed.write_text("#chr\tstart\n" + "".join("c\t%d\t%d\tDEL\n" % (i, i + 9) for i in range(7)) + "\n\n")

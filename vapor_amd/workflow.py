@@ -217,11 +217,11 @@ def merge_tables(tables: Sequence[str], prefix: str, index: bool = True) -> str:
 def auto_ranks_per_gpu(n_records: int, gpus: int, cores: int) -> int:
     """Ranks per GPU when the caller does not say: a whole run waits for the host side (the interpreter's share of every
     locus, BAM decompression) far longer than for the kernels, and that share does not thread - so ranks share a GPU, one per
-    four cores of the host's quota, four at most (13 500 instead of 6 400 loci/s from files on a 16-core box), but only
-    where every rank gets 10 000 records at least: the launch through torch.distributed.run and the ranks' own start cost
-    2.5 s more than a run in the calling process, which four ranks win back at about 30 000 records."""
+    four cores of the host's quota, four at most (12 000 loci from files on a 16-core box: 2.0 s instead of 2.9 s, scored at
+    11 800-13 500 instead of 6 400 loci/s), but only where every rank gets 3 000 records at least: each rank pays the start
+    of an interpreter and of a device context."""
     gpus = max(1, gpus)
-    return max(1, min(4, cores // (4 * gpus), n_records // (10000 * gpus)))
+    return max(1, min(4, cores // (4 * gpus), n_records // (3000 * gpus)))
 
 
 def _count_records(path: str) -> int:
