@@ -43,13 +43,18 @@ if "--files" in args:
     for r in ([1, "auto"] if ranks == "auto" else sorted({1, ranks})):
         out = os.path.join(tmp, "out%s.vapor" % r)
         t0 = time.perf_counter()
-        p = subprocess.run([sys.executable, "-m", "vapor_amd.workflow", "--gpus", "1", "--ranks-per-gpu", str(r), "--prefix",
+        prof = ["-m", "cProfile", "-o", os.path.join(tmp, "wf%s.prof" % r)] if os.environ.get("VAPOR_BENCH_CPROFILE") else []
+        p = subprocess.run([sys.executable] + prof + ["-m", "vapor_amd.workflow", "--gpus", "1", "--ranks-per-gpu", str(r), "--prefix",
                             os.path.join(tmp, "o%s" % r), "bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam,
                             "--output-path", tmp + "/figs", "--output-file", out, "--no-figures"], env=env, cwd=ROOT,
                            capture_output=True, text=True)
         wall = time.perf_counter() - t0
         line = [l for l in p.stderr.splitlines() if "loci/s" in l]
         print("ranks=%s rc=%d wall %.1fs  %s" % (r, p.returncode, wall, line[-1] if line else p.stderr[-400:]), flush=True)
+        if prof:                                     # the launcher process as a whole (one rank: the run itself)
+            st = pstats.Stats(prof[3])
+            st.sort_stats("tottime").print_stats(18)
+            st.sort_stats("cumulative").print_stats(45)
     a, b = open(os.path.join(tmp, "out1.vapor")).read(), open(os.path.join(tmp, "out%s.vapor" % ranks)).read()
     print("tables identical:", a == b, " rows:", a.count("\n"))
     sys.exit(0)

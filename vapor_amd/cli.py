@@ -360,8 +360,7 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
         # strings, read extraction, tables - runs while the other waits for its uploads and kernels; on the device the two
         # contexts' streams overlap as well.  Results are taken in chunk order.
         from concurrent.futures import ThreadPoolExecutor
-        engines = pipeline.get_engines(min(in_flight, len(starts)))
-        with ThreadPoolExecutor(max_workers=len(engines)) as pool:
+        with ThreadPoolExecutor(max_workers=min(in_flight, len(starts))) as pool:
             import threading
             slot = {}
             lock = threading.Lock()
@@ -369,7 +368,7 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
             def work(a):
                 with lock:
                     k = slot.setdefault(threading.get_ident(), len(slot))
-                return one_chunk(a, engines[k])
+                return one_chunk(a, pipeline.engine_slot(k))
             done = list(pool.map(work, starts))
     else:
         done = [one_chunk(a) for a in starts]

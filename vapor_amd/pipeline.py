@@ -50,6 +50,36 @@ def get_engines(n: int) -> list:
     return [first] + _more_engines[:n - 1]
 
 
+_engine_lock = None
+
+
+def engine_slot(k: int):
+    """The engine of the k-th thread that scores chunks, made on that thread's first call (the second context of a run comes
+    up while the first chunk is already being prepared on the first): get_engines(k + 1)[k]."""
+    global _engine_lock
+    if _engine_lock is None:
+        import threading
+        _engine_lock = threading.Lock()
+    with _engine_lock:
+        first = get_engine()
+    from .engine import Engine
+    if k == 0 or not isinstance(first, Engine):
+        return first
+    with _engine_lock:
+        if len(_more_engines) >= k:
+            return _more_engines[k - 1]
+    from .dist import _device_ordinal
+    made = Engine(_device_ordinal())                   # (outside the lock: the other threads' first calls go on)
+    with _engine_lock:
+        while len(_more_engines) < k - 1:              # (slots are taken in order; a gap is filled by whoever comes)
+            _more_engines.append(Engine(_device_ordinal()))
+        if len(_more_engines) >= k:                    # another thread was faster
+            made.close()
+            return _more_engines[k - 1]
+        _more_engines.append(made)
+        return made
+
+
 class _SeqTable:
     """Deduplicating builder of the sequence list of one device batch."""
 
