@@ -59,13 +59,18 @@ if "--files" in args:
     print("tables identical:", a == b, " rows:", a.count("\n"))
     sys.exit(0)
 
-if ranks > 1 and "--worker" not in args:
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
-                        "127.0.0.1", "--master-port", "29517", os.path.abspath(__file__)] + args + ["--worker"], env=env, cwd=ROOT,
-                       capture_output=True, text=True)
-    print([l for l in p.stdout.splitlines() if "loci/s" in l] or p.stderr[-1500:])
-    sys.exit(p.returncode)
+if ranks != "auto" and ranks > 1 and "--worker" not in args:
+    # the ranks as vapor_amd.workflow starts them: processes of this node that hand their scores over through files
+    d = tempfile.mkdtemp(prefix="vapor_ranks_")
+    procs = []
+    for r in range(ranks):
+        env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", RANK=str(r), WORLD_SIZE=str(ranks), LOCAL_RANK=str(r),
+                   LOCAL_WORLD_SIZE=str(ranks), VAPOR_DIST_BACKEND="files", VAPOR_DIST_DIR=d, VAPOR_LOCAL_GPUS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args + ["--worker"], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate() for p in procs]
+    print([l for l in outs[0][0].splitlines() if "loci/s" in l] or outs[0][1][-1500:])
+    sys.exit(max(p.returncode for p in procs))
 
 seqio.set_backend(seqio.MemorySamtools(w))
 bed_info = cli.bed_info_readin(bed, tmp)
