@@ -92,6 +92,7 @@ def write_bed_gz_with_index(path: str, lines: Sequence[str], index: bool = True)
         open(path + ".tbi", "wb").close()            # the WDL touches an empty index in that case
         return
     names: List[str] = []
+    seen = set()
     bins: List[Dict[int, List[List[int]]]] = []
     linear: List[List[int]] = []
     pos = 0
@@ -102,8 +103,9 @@ def write_bed_gz_with_index(path: str, lines: Sequence[str], index: bool = True)
             pos += n
             continue
         if not names or names[-1] != f[0]:
-            if f[0] in names:
+            if f[0] in seen:
                 raise ValueError("rows are not grouped by contig: " + f[0])
+            seen.add(f[0])
             names.append(f[0]); bins.append({}); linear.append([])
         beg, end = int(_num(f[1])), int(_num(f[2]))
         if end <= beg:
@@ -123,7 +125,7 @@ def write_bed_gz_with_index(path: str, lines: Sequence[str], index: bool = True)
         pos += n
     nm = b"".join(x.encode() + b"\0" for x in names)
     # format 0x10000 = UCSC/BED coordinates (0-based, half-open); columns 1, 2, 3; comment char '#'; skip 0
-    raw = b"TBI\x01" + struct.pack("<iiiiiiii", len(names), 0x10000, 1, 2, 3, ord("#"), 0, len(nm)) + nm
+    raw = bytearray(b"TBI\x01" + struct.pack("<iiiiiiii", len(names), 0x10000, 1, 2, 3, ord("#"), 0, len(nm)) + nm)
     for t in range(len(names)):
         lin, last = linear[t], 0
         for w in range(len(lin)):
@@ -133,8 +135,8 @@ def write_bed_gz_with_index(path: str, lines: Sequence[str], index: bool = True)
         raw += struct.pack("<i", len(bins[t]))
         for b, ch in sorted(bins[t].items()):
             raw += struct.pack("<Ii", b, len(ch)) + b"".join(struct.pack("<QQ", s, e) for s, e in ch)
-        raw += struct.pack("<i", len(lin)) + b"".join(struct.pack("<Q", v) for v in lin)
-    write_bgzf(path + ".tbi", raw)
+        raw += struct.pack("<i", len(lin)) + struct.pack("<%dQ" % len(lin), *lin)
+    write_bgzf(path + ".tbi", bytes(raw))
 
 
 def read_bgzf(path: str) -> bytes:
