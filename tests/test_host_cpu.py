@@ -139,6 +139,76 @@ def _vcf_world(case):
     return synth.world_from_json(_VCF_WORLDS[case["world_of"]])
 
 
+def test_vcf_parser_drops_the_duplicates_the_reference_drops(tmp_path):
+    """cli.vcf_list_readin answers the reference's `x not in out[T]` (vapor_vali/vapor:127-202: a scan of the bucket's list
+    per record) from sets beside the lists: the buckets and the record keys of a VCF with repeated records of every type
+    equal those of the scans written out - including the repeats the reference never drops (an insertion's probe has three
+    fields, its entries four)."""
+    from vapor_amd import simple_function as SF
+    rows = []
+    rng = np.random.default_rng(8)
+    for t in range(400):
+        c = "chr%d" % rng.integers(1, 4)
+        a = int(rng.integers(1, 40)) * 100
+        b = a + int(rng.integers(1, 5)) * 50
+        kind = t % 7
+        if kind == 0:
+            info = "SVTYPE=DEL;END=%d" % b
+        elif kind == 1:
+            info = "SVTYPE=INV;END=%d" % b
+        elif kind == 2:
+            info = "SVTYPE=INS;END=%d;SVLEN=%d" % (a + 1, int(rng.integers(1, 3)) * 100)
+        elif kind == 3:
+            info = "SVTYPE=DUP;END=%d" % b
+        elif kind == 4:
+            info = "SVTYPE=DISDUP;END=%d;insert_point=%s:%d" % (b, c, b + 1000)
+        elif kind == 5:
+            info = "SVTYPE=DEL_INV;END=%d;del=%s:%d-%d;inv=%s:%d-%d" % (b + 200, c, a, b, c, b, b + 200)
+        else:
+            info = "SVTYPE=CX;END=%d;Other=ab/ab_b/b^_%s:%d:%d:%d" % (b + 100, c, a, b, b + 100)
+        rows.append("%s\t%d\tid%d\tN\t<X>\t.\tPASS\t%s" % (c, a, t, info))
+    vcf = tmp_path / "dups.vcf"
+    vcf.write_text("\n".join(rows) + "\n")
+    got, got_keys = cli.vcf_list_readin(str(vcf))
+    # the scans, written out
+    exp, exp_keys = {}, {}
+    for rec, line in enumerate(rows):
+        pin = line.split()
+        t = SF.svtype_extract(pin)
+        pos = SF.chr_start_end_extract(pin)
+        if t == "DEL" or t == "INV":
+            exp.setdefault(t, [])
+            if pos not in exp[t]:
+                exp[t].append(pos); exp_keys[rec] = ":".join([str(i) for i in pos] + [t])
+        elif t == "INS":
+            n = int(SF.sv_len_extract(pin))
+            exp.setdefault("INS", [])
+            if n > 0 and pos not in exp["INS"]:
+                exp["INS"].append(pos[:2] + [n, SF.sv_seq_extract(pin)]); exp_keys[rec] = ":".join([str(i) for i in pos[:2] + [n]] + ["INS"])
+        elif t == "DUP":
+            exp.setdefault("TANDUP", [])
+            if pos not in exp["TANDUP"]:
+                exp["TANDUP"].append(pos); exp_keys[rec] = ":".join([str(i) for i in pos] + ["TANDUP"])
+        elif t == "DISDUP":
+            ip = SF.sv_insert_point_define(pin)
+            exp.setdefault("DISDUP", [])
+            if pos not in exp["DISDUP"]:
+                exp["DISDUP"].append(pos + ip); exp_keys[rec] = ":".join([str(i) for i in pos + ip] + ["DISDUP"])
+        elif t == "DEL_INV":
+            info = cli.del_inv_interprete(pin)
+            exp.setdefault("DEL_INV", [])
+            if not info == "error" and info not in exp["DEL_INV"]:
+                exp["DEL_INV"].append(info); exp_keys[rec] = ":".join(["_".join([str(i) for i in j]) for j in info] + ["DEL_INV"])
+        else:
+            o = [i for i in pin[7].split(";") if i[:6] == "Other="][0].split("=")[1].split("_")
+            item = ["_".join(i.split("/")) for i in o[:2]] + o[2].split(":")
+            exp.setdefault("Other", [])
+            if item not in exp["Other"]:
+                exp["Other"].append(item); exp_keys[rec] = ":".join([str(i) for i in item + ["CANNOT_CLASSIFY"]])
+    assert got == exp and got_keys == exp_keys
+    assert len(exp["DEL"]) < 58 and len(exp["INS"]) == 57            # deletions repeat and are dropped; insertions never are
+
+
 @pytest.mark.parametrize("case", [c for c in VCF if not c["header"]], ids=lambda c: c["name"])
 def test_vcf_records_and_table(fake, case, tmp_path):
     """`vapor vcf` on header-less input (where the reference's record numbering is consistent):

@@ -97,6 +97,22 @@ def vcf_list_readin(file_in):
     out = {}
     rec_hash = {}
     rec = -1
+    # `x not in out[T]` of the reference scans the bucket's list (every record against every earlier one of its type: minutes
+    # on a call set of 10^5); the same test from a set of the entries as tuples beside each list
+    seen = {}
+
+    def key(x):
+        return tuple(key(i) if isinstance(i, list) else i for i in x)
+
+    def new(bucket, probe, item=None):
+        """`probe not in out[bucket]`, and if so the item (default: the probe) appended."""
+        ks = seen.setdefault(bucket, set())
+        if key(probe) in ks:
+            return False
+        item = probe if item is None else item
+        out[bucket].append(item)
+        ks.add(key(item))
+        return True
     with open(file_in) as fin:
         for line in fin:
             rec += 1
@@ -109,44 +125,37 @@ def vcf_list_readin(file_in):
 
             if t in ['del', 'DEL', 'deletion']:
                 out.setdefault('DEL', [])
-                if pos not in out['DEL']:
-                    out['DEL'].append(pos)
+                if new('DEL', pos):
                     rec_hash[rec] = ':'.join([str(i) for i in pos] + ['DEL'])
             elif t in ['inv', 'INV', 'inversion']:
                 out.setdefault('INV', [])
-                if pos not in out['INV']:
-                    out['INV'].append(pos)
+                if new('INV', pos):
                     rec_hash[rec] = ':'.join([str(i) for i in pos] + ['INV'])
             elif t in ['ins', 'INS', 'insertion', 'LINE1', 'SVA', 'ALU', 'HERVK']:
                 sv_len = int(SF.sv_len_extract(pin))
                 seq = SF.sv_seq_extract(pin)
                 if sv_len > 0:
                     out.setdefault('INS', [])
-                    if pos not in out['INS']:
-                        out['INS'].append(pos[:2] + [sv_len, seq])
+                    if new('INS', pos, pos[:2] + [sv_len, seq]):     # (the probe has three fields, the entries four: never a duplicate)
                         rec_hash[rec] = ':'.join([str(i) for i in pos[:2] + [sv_len]] + ['INS'])
             elif t in ['disdup', 'DISDUP', 'dis-dup']:
                 ip = SF.sv_insert_point_define(pin)
                 out.setdefault('DISDUP', [])
-                if pos not in out['DISDUP']:
-                    out['DISDUP'].append(pos + ip)
+                if new('DISDUP', pos, pos + ip):
                     rec_hash[rec] = ':'.join([str(i) for i in pos + ip] + ['DISDUP'])
             elif t in ['DEL_INV', 'del_inv']:
                 out.setdefault('DEL_INV', [])
                 info = del_inv_interprete(pin)
-                if not info == 'error' and info not in out['DEL_INV']:
-                    out['DEL_INV'].append(info)
+                if not info == 'error' and new('DEL_INV', info):
                     rec_hash[rec] = ':'.join(['_'.join([str(i) for i in j]) for j in info] + ['DEL_INV'])
             elif t in ['DUP_INV', 'dup_inv']:
                 out.setdefault('DUP_INV', [])
                 info = dup_inv_interprete(pin)
-                if not info == 'error' and info not in out['DUP_INV']:
-                    out['DUP_INV'].append(info)
+                if not info == 'error' and new('DUP_INV', info):
                     rec_hash[rec] = ':'.join([str(i) for i in info + ['DUP_INV']])
             elif t in ['tandup', 'TANDUP', 'DUP']:
                 out.setdefault('TANDUP', [])
-                if pos not in out['TANDUP']:
-                    out['TANDUP'].append(pos)
+                if new('TANDUP', pos):
                     rec_hash[rec] = ':'.join([str(i) for i in pos] + ['TANDUP'])
             elif t in ['CNV', 'CSV', 'CPX']:
                 continue
@@ -160,8 +169,7 @@ def vcf_list_readin(file_in):
                 o = info[0].split('=')[1].split('_')
                 item = ['_'.join(i.split('/')) for i in o[:2]] + o[2].split(':')
                 out.setdefault('Other', [])
-                if item not in out['Other']:
-                    out['Other'].append(item)
+                if new('Other', item):
                     rec_hash[rec] = ':'.join([str(i) for i in item + ['CANNOT_CLASSIFY']])
     return [out, rec_hash]
 

@@ -307,6 +307,7 @@ def vcf_vapor_modify(vcf_input, vcf_rec_hash_new, header_offset_compat=False):
             print(joined, file=fo)
             prev = cur
         print('\t'.join(header), file=fo)
+        kept = set(keep)                  # (the reference asks its list per record: 15 s of scans on 60 000 records)
         for k1 in sorted(info.keys()):
-            if k1 in keep:
+            if k1 in kept:
                 print('\t'.join([str(i) for i in info[k1]]), file=fo)
