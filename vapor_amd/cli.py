@@ -276,6 +276,7 @@ def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
 def svelter_readin(file_in):
     """vapor_vali/vapor:255-268: {ref structure: {alt structure: [[chrom, bp, bp, ...], ...]}}."""
     out = {}
+    seen = {}                       # (the reference scans the list of a structure pair per record; a set of its entries beside it)
     with open(file_in) as fin:
         fin.readline()
         for line in fin:
@@ -283,8 +284,11 @@ def svelter_readin(file_in):
             r = '_'.join(pin[4].split('/'))
             a = '_'.join(pin[5].split('/'))
             lst = out.setdefault(r, {}).setdefault(a, [])
-            if pin[3].split(':') not in lst:
-                lst.append(pin[3].split(':'))
+            ks = seen.setdefault((r, a), set())
+            item = pin[3].split(':')
+            if tuple(item) not in ks:
+                ks.add(tuple(item))
+                lst.append(item)
     return out
 
 
