@@ -464,6 +464,21 @@ def test_workflow_chooses_ranks_per_gpu_from_input_and_cores(tmp_path):
     assert workflow._count_records(str(bed)) == 7 and workflow._count_records(str(tmp_path / "none.bed")) == 0
 
 
+def test_workflow_launcher_reports_a_failed_rank(tmp_path):
+    """The launcher's own ranks (several per GPU): a run whose ranks end badly - here the input does not exist, which every
+    rank finds out before it touches a device - returns their exit code, leaves no rank behind and removes its directory."""
+    import glob
+    import tempfile
+    from vapor_amd import workflow
+    before = set(glob.glob(os.path.join(tempfile.gettempdir(), "vapor_ranks_*")))
+    rc = workflow.main(["--ranks-per-gpu", "2", "--prefix", str(tmp_path / "s"), "bed", "--sv-input", str(tmp_path / "missing.bed"),
+                        "--reference", "ref.fa", "--pacbio-input", "x.bam", "--output-path", str(tmp_path / "figs"),
+                        "--output-file", str(tmp_path / "out.vapor"), "--no-figures"])
+    assert rc != 0
+    assert set(glob.glob(os.path.join(tempfile.gettempdir(), "vapor_ranks_*"))) == before
+    assert not (tmp_path / "s.bed.gz").exists()
+
+
 def test_workflow_sorted_bgzipped_indexed_table(fake, tmp_path):
     """§8f-4: the node launcher's gather side - the CLI's table, version-sorted, block-gzipped and tabix-indexed
     (what the reference's WDL does with sort -V | bgzip | tabix -p bed)."""
