@@ -432,6 +432,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     if not args.no_figures:
         from . import figures
         figure_fn = figures.make_event_figure_1
+        figures.warm()                  # (the drawing processes start while the input is parsed and the first batch scored)
     vdist.init_from_env()
     out_path = SF.path_modify(args.output_path)
     SF.path_mkdir(out_path)

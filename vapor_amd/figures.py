@@ -200,6 +200,35 @@ def wait() -> None:
         raise _first_error.pop()
 
 
+def _warm() -> int:
+    """In a worker: matplotlib imported and the kept figure of the usual layout made, before the first figure arrives."""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    if not _canvas:
+        fig = plt.figure()
+        axes, lines = [], []
+        for pos, title in zip(POSITIONS, TITLES):
+            ax = plt.subplot(pos)
+            (ln,) = ax.plot([], [], '+', color='r')
+            ax.set_title(title)
+            ax.grid(False)
+            axes.append(ax)
+            lines.append(ln)
+        _canvas.update(layout=tuple(zip(POSITIONS, TITLES)), fig=fig, axes=axes, lines=lines)
+    return 0
+
+
+def warm() -> None:
+    """Starts the worker processes and lets each import matplotlib now (half a second each, a second of a run's start when it
+    waited for the first batch's figures); nothing waits for them."""
+    from . import hostpool
+    pool = hostpool.get()
+    if pool is not None:
+        for _ in range(pool.n):
+            pool.submit("vapor_amd.figures", "_warm")
+
+
 def shutdown() -> None:
     from . import hostpool
     try:
