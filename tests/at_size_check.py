@@ -23,7 +23,9 @@ def twin_rows(rec):
     orc.build()
     twin = orc.build_twin()
     out = tempfile.mktemp(suffix=".json")
-    env = dict(os.environ, VAPOR_HIP_LIB=twin, VAPOR_QC_SEED=str(rec["qc_seed"]), PYTHONPATH=ROOT, VAPOR_HOST_PROCS="0")
+    # (PYTHONPATH prepended, not replaced: the driver's hook that records which native libraries a process loads rides on it)
+    env = dict(os.environ, VAPOR_HIP_LIB=twin, VAPOR_ALLOW_TWIN="1", VAPOR_QC_SEED=str(rec["qc_seed"]),
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), VAPOR_HOST_PROCS="0")
     n = rec["base_loci"] if rec["config"] == "cfg5" else rec["base_loci"]
     cmd = [sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), rec["config"], "--loci", str(n), "--base", str(rec["base_loci"]),
            "--out", out, "--all-rows"]

@@ -53,3 +53,43 @@ def test_pair_struct_layout_matches_header():
     from vapor_amd import _lib
     assert _lib.PAIR_DTYPE.itemsize == 20
     assert [_lib.PAIR_DTYPE.fields[k][1] for k in ("seq1", "seq2", "off2", "k", "flags")] == [0, 4, 8, 12, 16]
+
+
+def test_the_cpu_twin_says_what_it_is_and_the_loader_refuses_it(monkeypatch):
+    """the CPU twin of the C ABI (oracle/, test infrastructure) reports the build flag "cpu-twin"; the
+    product loader refuses it - also when VAPOR_HIP_LIB names it - unless VAPOR_ALLOW_TWIN=1 is set beside it, which only
+    tests/at_size_check.py does."""
+    import pytest
+    from oracle import oracle as orc
+    from vapor_amd import _lib
+    twin = orc.build_twin()
+    raw = ctypes.CDLL(twin)
+    raw.vapor_build_flags.restype = ctypes.c_char_p
+    assert raw.vapor_build_flags() == b"cpu-twin"
+    monkeypatch.delenv("VAPOR_HIP_LIB", raising=False)
+    monkeypatch.delenv("VAPOR_ALLOW_TWIN", raising=False)
+    with pytest.raises(RuntimeError, match="CPU twin"):
+        _lib.checked(ctypes.CDLL(twin), twin)
+    monkeypatch.setenv("VAPOR_HIP_LIB", twin)
+    with pytest.raises(RuntimeError, match="CPU twin"):
+        _lib.checked(ctypes.CDLL(twin), twin)
+    monkeypatch.setenv("VAPOR_ALLOW_TWIN", "1")
+    assert _lib.checked(ctypes.CDLL(twin), twin).vapor_abi_version() == _lib.ABI_VERSION
+
+
+def test_a_stale_library_gets_the_rebuild_message(tmp_path):
+    """a library without the newer symbols (or another ABI version) fails with the rebuild message, not with an
+    'undefined symbol' from the binding."""
+    import subprocess
+    import pytest
+    from vapor_amd import _lib
+    src = tmp_path / "stale.c"
+    src.write_text('int vapor_abi_version(void) { return 1; }\nconst char* vapor_build_flags(void) { return ""; }\n')
+    so = str(tmp_path / "libstale.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", so, str(src)])
+    with pytest.raises(RuntimeError, match="rebuild with"):
+        _lib.checked(ctypes.CDLL(so), so)
+    src.write_text('int vapor_abi_version(void) { return %d; }\nconst char* vapor_build_flags(void) { return ""; }\n' % _lib.ABI_VERSION)
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", so + "2", str(src)])
+    with pytest.raises(RuntimeError, match="rebuild with"):          # right version, symbols missing
+        _lib.checked(ctypes.CDLL(so + "2"), so + "2")

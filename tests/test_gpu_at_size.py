@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("cfg,loci,base", [("cfg4", 180, 60), ("cfg5", 60, 20)])
 def test_at_size_runner_and_twin_check(cfg, loci, base, tmp_path):
     out = str(tmp_path / "at_size.json")
-    env = dict(os.environ, PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))   # (prepended: the driver's hook stays)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), cfg, "--loci", str(loci), "--base", str(base), "--out", out],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -153,3 +153,47 @@ def test_bed_cli_chunks_in_flight_gpu(in_flight, tmp_path, monkeypatch):
     finally:
         seqio.set_backend(None)
         pipeline.set_engine(None)
+
+
+def test_bed_cli_figures_with_chunks_in_flight_gpu(tmp_path, monkeypatch):
+    """with figures on (the CLI's default) and more loci than --chunk, two chunks are in flight, each on its
+    own thread and library context - the figure pass of a chunk must run on that chunk's context too (it used the default
+    one: two threads inside one vapor_ctx).  The table and every PNG equal those of the one-chunk-at-a-time run."""
+    import hashlib
+    import os
+    from vapor_amd import cli, figures, pipeline, seqio, synth
+    case = [c for c in LOCUS if c["name"] == "bed_small_mix"][0]
+    monkeypatch.setenv("VAPOR_HOST_PROCS", "2")
+    got = {}
+    for in_flight in ("1", "2"):
+        monkeypatch.setenv("VAPOR_CHUNKS_IN_FLIGHT", in_flight)
+        pipeline.set_engine(None)
+        seqio.set_backend(seqio.MemorySamtools(synth.world_from_json(case["world"])))
+        engines_used = []
+        real = figures.figure_specs
+
+        def spy(reqs, engine=None, _real=real, _seen=engines_used):
+            _seen.append(engine)
+            return _real(reqs, engine)
+        monkeypatch.setattr(figures, "figure_specs", spy)
+        try:
+            d = tmp_path / ("run" + in_flight)
+            d.mkdir()
+            bed = d / "in.bed"
+            bed.write_text(case["bed"])
+            out = d / "out.vapor"
+            rc = cli.main(["bed", "--sv-input", str(bed), "--reference", "ref.fa", "--pacbio-input", "x.bam", "--chunk", "3",
+                           "--output-path", str(d / "figs"), "--output-file", str(out)])
+            assert rc == 0
+            assert out.read_text() == case["vapor_text"]
+            pngs = {f: hashlib.sha256(open(os.path.join(d, "figs", f), "rb").read()).hexdigest()
+                    for f in sorted(os.listdir(d / "figs")) if f.endswith(".png")}
+            got[in_flight] = pngs
+            assert engines_used and all(e is not None for e in engines_used)       # the chunk's engine, never the default by omission
+            if in_flight == "2":
+                assert len({id(e) for e in engines_used}) == 2                      # both contexts drew their own chunk's figures
+        finally:
+            monkeypatch.setattr(figures, "figure_specs", real)
+            seqio.set_backend(None)
+            pipeline.set_engine(None)
+    assert got["1"] and got["1"] == got["2"]

@@ -39,7 +39,7 @@ if "--files" in args:
     t0 = time.perf_counter()
     fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
     print("files in %.1fs (%.1f MB BAM)" % (time.perf_counter() - t0, os.path.getsize(bam) / 1e6), flush=True)
-    env = dict(os.environ, PYTHONPATH=ROOT, VAPOR_TIMING="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), VAPOR_TIMING="1", OMP_NUM_THREADS="1")
     for r in ([1, "auto"] if ranks == "auto" else sorted({1, ranks})):
         out = os.path.join(tmp, "out%s.vapor" % r)
         t0 = time.perf_counter()
@@ -64,7 +64,7 @@ if ranks != "auto" and ranks > 1 and "--worker" not in args:
     d = tempfile.mkdtemp(prefix="vapor_ranks_")
     procs = []
     for r in range(ranks):
-        env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", RANK=str(r), WORLD_SIZE=str(ranks), LOCAL_RANK=str(r),
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1", RANK=str(r), WORLD_SIZE=str(ranks), LOCAL_RANK=str(r),
                    LOCAL_WORLD_SIZE=str(ranks), VAPOR_DIST_BACKEND="files", VAPOR_DIST_DIR=d, VAPOR_LOCAL_GPUS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args + ["--worker"], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))

@@ -11,7 +11,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VAPOR_HIP_LIB: developer builds of the same library (tools/phase_timing.py); never a different backend
+# VAPOR_HIP_LIB: developer builds of the same library (tools/phase_timing.py).  The CPU twin of the C ABI (oracle/, test
+# infrastructure) reports the build flag "cpu-twin" and is refused unless VAPOR_ALLOW_TWIN=1 is set as well, which only
+# tests/at_size_check.py does (a child process that replays rows of a GPU run on the oracle): a stray VAPOR_HIP_LIB can
+# never turn a product run into a CPU run that passes the loader's checks.
 SO_PATH = os.environ.get("VAPOR_HIP_LIB") or os.path.join(_HERE, "libvapor_hip.so")
 
 PAIR_DTYPE = np.dtype([("seq1", "<i4"), ("seq2", "<i4"), ("off2", "<i4"), ("k", "<i4"), ("flags", "<u4")])
@@ -83,17 +86,36 @@ def load() -> ctypes.CDLL:
         raise RuntimeError("%s is missing - the HIP extension has not been built "
                            "(run `python -m vapor_amd.build`); there is no CPU fallback" % lib_path)
     _share_torch_hip_runtime()
-    lib = bind(ctypes.CDLL(lib_path))
-    ver, flags = lib.vapor_abi_version(), lib.vapor_build_flags().decode()
-    dev_ok = bool(os.environ.get("VAPOR_HIP_LIB"))        # developer tools name their library explicitly
-    if ver != ABI_VERSION and not (dev_ok and ver == ABI_VERSION + ABI_DEV_OFFSET):
-        raise RuntimeError("%s reports ABI version %d, build flags %r: this package binds version %d of the product build "
-                           "(a developer build loads only through VAPOR_HIP_LIB); rebuild with `python -m vapor_amd.build --force`"
-                           % (lib_path, ver, flags, ABI_VERSION))
-    if flags and not dev_ok:
-        raise RuntimeError("%s carries developer switches (%s)" % (lib_path, flags))
+    lib = checked(ctypes.CDLL(lib_path), lib_path)
     _lib = lib
     return _lib
+
+
+def checked(raw: ctypes.CDLL, lib_path: str) -> ctypes.CDLL:
+    """Version and build flags first, on the raw handle (a stale library lacks newer symbols: bind() would die with an
+    'undefined symbol' before the rebuild message could appear), then the binding."""
+    stale = ("%s is a stale or foreign build (%%s): this package binds ABI version %d of the product build; rebuild with "
+             "`python -m vapor_amd.build --force`" % (lib_path, ABI_VERSION))
+    try:
+        raw.vapor_abi_version.restype = ctypes.c_int
+        raw.vapor_build_flags.restype = ctypes.c_char_p
+        ver, flags = raw.vapor_abi_version(), raw.vapor_build_flags().decode()
+    except AttributeError as e:
+        raise RuntimeError(stale % e) from e
+    dev_ok = bool(os.environ.get("VAPOR_HIP_LIB"))        # developer tools name their library explicitly
+    if ver != ABI_VERSION and not (dev_ok and ver == ABI_VERSION + ABI_DEV_OFFSET):
+        raise RuntimeError(stale % ("reports ABI version %d, build flags %r; a developer build loads only through VAPOR_HIP_LIB"
+                                    % (ver, flags)))
+    if "cpu-twin" in flags.split(","):
+        if not (dev_ok and os.environ.get("VAPOR_ALLOW_TWIN") == "1"):
+            raise RuntimeError("%s is the CPU twin of the C ABI (oracle/: test infrastructure), not the HIP library; there is "
+                               "no CPU fallback (tests set VAPOR_ALLOW_TWIN=1 beside VAPOR_HIP_LIB)" % lib_path)
+    elif flags and not dev_ok:
+        raise RuntimeError("%s carries developer switches (%s)" % (lib_path, flags))
+    try:
+        return bind(raw)
+    except AttributeError as e:
+        raise RuntimeError(stale % e) from e
 
 
 def bind(L: ctypes.CDLL) -> ctypes.CDLL:
@@ -159,7 +181,7 @@ def load_holding_gil():
     chunk's thread each time, and the hand-over costs more than the call (two chunks of a run are scored on two threads)."""
     global _held
     if _held is None:
-        load()
+        load()                                  # (version and build flags of SO_PATH are checked there)
         h = ctypes.PyDLL(SO_PATH)
         vp = ctypes.c_void_p
         h.vapor_chop_records.argtypes = [ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp]

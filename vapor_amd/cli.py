@@ -353,6 +353,17 @@ def score_jobs(jobs: List[Job], chunk: int, figure_fn=None) -> List[object]:
         gc.set_threshold(*gc_was)
 
 
+def _chunk_threads_ok() -> bool:
+    """Chunks are scored on several threads only with a read backend whose handles are per thread - the rule of
+    pipeline._prefetch_threads: the Python BGZF reader (VAPOR_BAM_NATIVE=0) shares one file object and block cache between
+    seek() and read(), the samtools hybrid and VAPOR_MEMORY_CHOP=records write one module-level result array."""
+    from . import seqio
+    be = seqio.get_backend()
+    if not getattr(be, "threads_ok", False) or os.environ.get("VAPOR_BAM_NATIVE", "1") == "0":
+        return False
+    return os.environ.get("VAPOR_MEMORY_CHOP", "") != "records"
+
+
 def _score_jobs(jobs, chunk, figure_fn, t0):
     import time
     mine = vdist.my_share(len(jobs))
@@ -366,6 +377,8 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
 
     starts = list(range(0, len(mine), max(chunk, 1)))
     in_flight = max(1, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "2")))
+    if in_flight >= 2 and not _chunk_threads_ok():
+        in_flight = 1
     if len(starts) >= 2 and in_flight >= 2:
         # Two chunks in flight (the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage): each on a thread
         # with a library context of its own (one host thread per context), so that the host preparation of one chunk - allele

@@ -164,26 +164,38 @@ def make_event_figure_1(req) -> None:
 # loci.  pipeline._answer calls `make_event_figure_1.batch`, pipeline.run_batch `make_event_figure_1.wait` before it
 # returns: when a batch is done its PNGs are on disk.
 # ------------------------------------------------------------------------------------------
+import threading
+
 _pending: list = []
+_plock = threading.Lock()                     # _pending / _first_error: the chunk threads of cli.score_jobs hand figures in together
+_render_lock = threading.Lock()               # the kept figure of render() is one per process
 _CHUNK = 64                                   # figures per device pass (their dots pass through host memory)
 
 
-def make_figures(reqs) -> None:
-    """make_event_figure_1 for many requests: batched dot plots, drawing handed to the worker processes of
-    vapor_amd.hostpool (or done here when there are none: VAPOR_HOST_PROCS=0, a single core)."""
+def make_figures(reqs, engine=None) -> None:
+    """make_event_figure_1 for many requests: batched dot plots (on `engine`: the calling thread's library context),
+    drawing handed to the worker processes of vapor_amd.hostpool (or done here when there are none: VAPOR_HOST_PROCS=0, a
+    single core)."""
     from . import hostpool
     pool = hostpool.get()
     for a in range(0, len(reqs), _CHUNK):
-        for spec in figure_specs(reqs[a:a + _CHUNK]):
+        for spec in figure_specs(reqs[a:a + _CHUNK], engine):
             if spec is None:
                 continue
             if pool is None:
-                render(spec)
+                with _render_lock:
+                    render(spec)
             else:
                 # (a few figures per worker in flight: their dots wait in memory, half a megabyte a figure)
-                while len(_pending) >= 4 * pool.n:
-                    _settle(_pending.pop(0))
-                _pending.append((pool.submit("vapor_amd.figures", "render", spec), spec))
+                while True:
+                    with _plock:
+                        old = _pending.pop(0) if len(_pending) >= 4 * pool.n else None
+                    if old is None:
+                        break
+                    _settle(old)
+                item = (pool.submit("vapor_amd.figures", "render", spec), spec)
+                with _plock:
+                    _pending.append(item)
 
 
 _first_error: list = []
@@ -196,20 +208,25 @@ def _settle(item) -> None:
         try:
             r.result()
         except hostpool.WorkerLost:
-            render(spec)                # (the worker is gone: drawn here)
+            with _render_lock:
+                render(spec)            # (the worker is gone: drawn here)
     except Exception as e:              # noqa: BLE001 - the first one is raised by wait() once all are in
-        if not _first_error:
-            _first_error.append(e)
+        with _plock:
+            if not _first_error:
+                _first_error.append(e)
 
 
 def wait() -> None:
-    """Returns when every figure handed out so far is on disk; raises what a drawing raised."""
-    global _pending
-    todo, _pending = _pending, []
+    """Returns when every figure handed out so far (by any thread) is on disk; raises what a drawing raised."""
+    with _plock:
+        todo = _pending[:]
+        del _pending[:]
     for item in todo:
         _settle(item)
-    if _first_error:
-        raise _first_error.pop()
+    with _plock:
+        err = _first_error.pop() if _first_error else None
+    if err is not None:
+        raise err
 
 
 def _warm() -> int:

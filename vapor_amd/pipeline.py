@@ -15,17 +15,21 @@ from . import _lib as L
 from . import repeat_qc
 from .drivers import Figure, Score, Window
 
+import threading
+
 _engine = None
+_engine_lock = threading.RLock()      # made at import: the chunk threads of cli.score_jobs reach engine_slot() together
 
 
 def get_engine():
     """Process-wide default engine on the current device (LOCAL_RANK or 0)."""
     global _engine
-    if _engine is None:
-        from .dist import _device_ordinal
-        from .engine import Engine
-        _engine = Engine(_device_ordinal())
-    return _engine
+    with _engine_lock:
+        if _engine is None:
+            from .dist import _device_ordinal
+            from .engine import Engine
+            _engine = Engine(_device_ordinal())
+        return _engine
 
 
 def set_engine(e) -> None:
@@ -50,18 +54,10 @@ def get_engines(n: int) -> list:
     return [first] + _more_engines[:n - 1]
 
 
-_engine_lock = None
-
-
 def engine_slot(k: int):
     """The engine of the k-th thread that scores chunks, made on that thread's first call (the second context of a run comes
     up while the first chunk is already being prepared on the first): get_engines(k + 1)[k]."""
-    global _engine_lock
-    if _engine_lock is None:
-        import threading
-        _engine_lock = threading.Lock()
-    with _engine_lock:
-        first = get_engine()
+    first = get_engine()
     from .engine import Engine
     if k == 0 or not isinstance(first, Engine):
         return first
@@ -384,7 +380,7 @@ def _answer(engine, reqs: Sequence[object], figure_fn) -> List[object]:
         figs = [r for r in reqs if isinstance(r, Figure)]
         batch = getattr(figure_fn, "batch", None)      # (figures.make_event_figure_1: one device pass, drawing in worker processes)
         if figs and batch is not None:
-            batch(figs)
+            batch(figs, engine)             # (the chunk's own engine: a library context serves one host thread)
         else:
             for r in figs:
                 figure_fn(r)
