@@ -134,12 +134,15 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--passes-per-step", type=int, default=0, help="0: sized by a probe so that the timed region lasts >= --min-seconds")
-    ap.add_argument("--min-seconds", type=float, default=1.2)
+    # (>= 6 s: the driver samples the GPU's busy state every 5 s - a 1.2 s timed region, as in rounds 1-3, fell between samples)
+    ap.add_argument("--min-seconds", type=float, default=6.5)
     ap.add_argument("--plans", type=int, default=0, help="plans in flight (0 = two when a join launch is one workgroup per CU, else one)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inclusive rate and the cfg3 sub-record")
     ap.add_argument("--sub", default="cfg3", help="workload of the sub-record ('' = none)")
+    ap.add_argument("--strong-loci", type=int, default=10000, help="N > 1: records of the cfg4 VCF sharded over the ranks (0 = skip)")
+    ap.add_argument("--strong-base", type=int, default=300, help="distinct loci of that world (tiled up to --strong-loci)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -277,18 +280,22 @@ def main() -> None:
     src_id = kernel_source_id()
     traffic = util = None
     traffic_source = binds_source = None
-    tj = _load_json("r03_%s_traffic.json" % args.workload)
-    if tj and dom in tj:
-        traffic_source = {"file": "profiles/r03_%s_traffic.json" % args.workload, "measured_on_source": tj.get("source_id"),
-                          "this_source": src_id, "live": False}
-        if tj.get("source_id") == src_id:
-            traffic = int(tj[dom]["bytes"])
-    uj = _load_json("r03_%s_util.json" % args.workload)
-    if uj and dom in uj:
-        binds_source = {"file": "profiles/r03_%s_util.json" % args.workload, "measured_on_source": uj.get("source_id"),
-                        "this_source": src_id, "live": False}
-        if uj.get("source_id") == src_id:
-            util = uj[dom]
+    for rnd in ("r04", "r03"):                       # the newest round's counter summaries that exist for this workload
+        tj = _load_json("%s_%s_traffic.json" % (rnd, args.workload))
+        if tj and dom in tj:
+            traffic_source = {"file": "profiles/%s_%s_traffic.json" % (rnd, args.workload), "measured_on_source": tj.get("source_id"),
+                              "this_source": src_id, "live": False}
+            if tj.get("source_id") == src_id:
+                traffic = int(tj[dom]["bytes"])
+            break
+    for rnd in ("r04", "r03"):
+        uj = _load_json("%s_%s_util.json" % (rnd, args.workload))
+        if uj and dom in uj:
+            binds_source = {"file": "profiles/%s_%s_util.json" % (rnd, args.workload), "measured_on_source": uj.get("source_id"),
+                            "this_source": src_id, "live": False}
+            if uj.get("source_id") == src_id:
+                util = uj[dom]
+            break
 
     extras = {}
     cpu = None
@@ -300,6 +307,16 @@ def main() -> None:
                 extras["sub"] = sub_record(eng, wl, args.sub, torch, cpu_seconds=0.0 if args.no_cpu else min(args.cpu_seconds, 10.0))
         if not args.no_cpu:
             cpu = cpu_baseline(w, st, n_pairs, args.cpu_seconds)
+    strong = None
+    if world > 1:
+        # N > 1: the CPU baseline on rank 0 after the timed region (the other ranks wait at the next barrier), and the
+        # fixed-size workload north_star's multi-GPU configurations describe: configs[3]'s 10 000-record VCF sharded over
+        # the ranks by estimated cost, scored through the product drivers, one gather of the scores (strong scaling)
+        if rank == 0 and not args.no_cpu:
+            cpu = cpu_baseline(w, st, n_pairs, args.cpu_seconds)
+        barrier()
+        if args.strong_loci > 0:
+            strong = strong_record(eng, dist, backend, world, rank, args.strong_loci, args.strong_base, barrier, torch)
 
     if rank == 0:
         out = {
@@ -322,6 +339,9 @@ def main() -> None:
                                    % (args.workload, w.n_loci, spec["reads_per_locus"], spec["read_len"],
                                       spec["allele_len"], "/".join(sorted(set(w.svtypes)))),
                        "pairs_per_pass_per_gpu": n_pairs, "passes_per_step": inner, "plans_in_flight": n_plans,
+                       # (N > 1: the per-locus records of all passes of a step travel in ONE all-gather per step since round 3;
+                       # rounds 1-2 gathered behind every pass - their SCALE / BENCH multi-GPU lines are not comparable with these)
+                       "gathers_per_step": (1 if dist is not None else 0),
                        "parallelism": "loci sharded over %d GPU(s)" % world},
             "timed_region_s": round(elapsed, 4),
             "ms_per_pass": round(elapsed / n_passes * 1e3, 5),
@@ -331,7 +351,10 @@ def main() -> None:
             "loci_with_scores": int(np.isfinite(np.asarray(last_rec).reshape(-1, 8)[:, 0]).sum()),
             "kernel_ms": {"join": round(avg["join_ms"], 4), "clean": round(avg["clean_ms"], 4), "finish": round(avg["finish_ms"], 4),
                           "device_total": round(avg["total_ms"], 4), "join_launches": launches,
-                          "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)}},
+                          "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)},
+                          "note": "join / clean / finish are HIP-event INTERVALS inside the two-plan overlap (the two plans' kernels "
+                                  "share the CUs and their intervals overlap: their sum over the passes exceeds the step), not serial "
+                                  "costs; `alone` is each kernel by itself on an otherwise idle device"},
             "upload_pack_s": round(res.upload_s, 4),
             # `achieved` / `peak` / `frac`: SURVEY 8d's algorithmic bytes per launch over the dominant kernel's live
             # HIP-event duration, against the HBM roof the task names.  `bound` says which roof the kernel really sits
@@ -351,6 +374,8 @@ def main() -> None:
                          "binds": util, "binds_source": binds_source},
             "cpu_baseline": cpu,
         }
+        if strong is not None:
+            out["strong"] = strong
         out.update(extras)
         if "pipeline" in extras and "value" in extras["pipeline"]:
             out["pipeline_value"] = extras["pipeline"]["value"]    # the drivers end to end, one process (host-bound)
@@ -389,6 +414,83 @@ def spawn_ranks(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def strong_record(eng, dist, backend, world, rank, n_loci, base, barrier, torch):
+    """Strong scaling on the workload BASELINE.json configs[3] names: ONE `vapor vcf` call set of `n_loci` records (DEL / INV /
+    INS and a third complex records; 40 reads of 15 kb per locus; a tiled in-memory world every rank builds from the same
+    seed) sharded over the ranks by estimated cost (cli.job_cost, greedy LPT), each rank scoring its share through the
+    reference-named drivers on its own GPU, one all-gather of the score vectors (vapor_amd.dist over this process group:
+    RCCL when every rank owns a GPU), rank 0 writing the rows.  Reported: loci/s over the slowest rank's wall time, every
+    rank's busy time, and the table's sha256 against the same run on rank 0 alone."""
+    import contextlib
+    import hashlib
+    import io
+    import tempfile
+    from vapor_amd import cli, pipeline, seqio
+    from vapor_amd import dist as vdist
+    from vapor_amd import workload as wl
+    os.environ.setdefault("VAPOR_QC_SEED", "7")
+    try:
+        t0 = time.perf_counter()
+        big, text, n_records = wl.at_size_input("cfg4", n_loci, base)
+        t_world = time.perf_counter() - t0
+        tmp = tempfile.mkdtemp(prefix="vapor_strong_r%d_" % rank)
+        src = os.path.join(tmp, "in.vcf")
+        open(src, "w").write(text)
+        seqio.set_backend(seqio.MemorySamtools(big))
+        pipeline.set_engine(eng)
+
+        def run():
+            with contextlib.redirect_stdout(io.StringIO()):
+                vcf_list, _rec_hash = cli.vcf_list_readin(src)
+                jobs = cli.vcf_jobs(vcf_list, 3, "x.bam", "ref.fa", tmp + "/", "s")
+                scores = cli.score_jobs(jobs, 2048, None)
+                rows = cli.output_rows([[j.key] for j in jobs], scores)[0]
+            return jobs, rows
+        vdist.adopt_process_group(backend)
+        try:
+            run()                                        # (warm: allocators, the second context of the chunk threads)
+            barrier()
+            t0 = time.perf_counter()
+            jobs, rows = run()
+            t_mine = time.perf_counter() - t0
+            busy = dict(cli.last_timing)
+            barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            vdist.release_process_group()
+        dev = torch.device("cuda") if backend == "nccl" else torch.device("cpu")
+        mine = torch.tensor([elapsed, t_mine, busy.get("score_s", 0.0), busy.get("gather_s", 0.0), float(busy.get("loci", 0)),
+                             float(busy.get("cost", 0.0))], dtype=torch.float64, device=dev)
+        allv = torch.empty(world * 6, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.cpu().numpy().reshape(world, 6)
+        sha = hashlib.sha256("\n".join(rows).encode()).hexdigest()
+        out = None
+        if rank == 0:
+            t0 = time.perf_counter()
+            _j, rows1 = run()                            # the same call set on this rank alone (vapor_amd.dist sees one process)
+            t_one = time.perf_counter() - t0
+            sha1 = hashlib.sha256("\n".join(rows1).encode()).hexdigest()
+            wall = float(allv[:, 0].max())
+            out = {"workload": "cfg4: `vapor vcf` call set of %d records (DEL / INV / INS, a third complex: DUP_INV, DISDUP, DEL_INV, Other=), "
+                               "40 reads of 15 kb per locus, %d distinct loci tiled; in-memory world, figures off" % (n_records, base),
+                   "scaling": "strong", "value": round(n_records / wall, 1), "unit": "loci/s", "seconds": round(wall, 4),
+                   "ranks": world, "backend": backend, "shares": "greedy LPT on cli.job_cost",
+                   "per_rank": [{"loci": int(r[4]), "estimated_cost_us": round(float(r[5]), 1), "busy_s": round(float(r[2]), 4),
+                                 "gather_s": round(float(r[3]), 4), "wall_s": round(float(r[1]), 4)} for r in allv],
+                   "busy_spread": round(float(allv[:, 2].max() / max(allv[:, 2].mean(), 1e-12)), 3),
+                   "one_rank": {"value": round(n_records / t_one, 1), "seconds": round(t_one, 4)},
+                   "speedup_over_one_rank": round(t_one / wall, 3),
+                   "rows_sha256": sha, "rows_sha256_one_rank": sha1, "tables_equal": sha == sha1,
+                   "world_build_s": round(t_world, 1)}
+        seqio.set_backend(None)
+        barrier()
+        return out
+    except Exception as e:      # noqa: BLE001 - a side record must not take the headline down
+        import traceback
+        return {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-1200:]}
 
 
 def inclusive_rate(eng, w, wl, reps: int = 6):

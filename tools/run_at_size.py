@@ -26,61 +26,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from vapor_amd import cli, seqio, synth
 
-# the complex records of a VCF that reach a scorer in the reference (the defects it dies of - str > int for a DISDUP with
-# spanning reads, SF:1801; blocks >= 100 bp apart, SF:1585 - are pinned by tests/golden/locus_complex.json.gz, not run here)
-CX = [dict(type="DUP_INV", a=200, gap=1400), dict(type="DUP_INV", a=260, gap=1900), dict(type="DUP_INV", a=180, gap=-1300),
-      dict(type="DUP_INV", a=320, gap=10400), dict(type="DUP_INV", a=280, xchrom=1000),
-      dict(type="DISDUP", a=300, gap=11000), dict(type="DISDUP", a=260, xchrom=900), dict(type="DISDUP", a=260, xchrom=15000),
-      dict(type="DEL_INV", a=300, b=420), dict(type="DEL_INV", a=350, b=300, order="inv,del"), dict(type="DEL_INV", a=700, b=9600),
-      dict(type="OTHER", a=420, b=520, other=("ab/ab", "b/b^")), dict(type="OTHER", a=380, b=460, other=("ab/ab", "a/ab")),
-      dict(type="OTHER", a=300, b=2400, other=("ab/ab", "aba/ab")), dict(type="OTHER", a=400, b=500, other=("ab/ab", "ba^/ab"))]
-
-SPEC = {
-    "cfg4": dict(mode="vcf", loci=10000, base=300, n_reads=40, read_len=15000, seed=404),
-    "cfg5": dict(mode="bed", loci=50000, base=250, n_reads=60, read_len=30000, seed=505),
-}
-
-
-def base_world(cfg, base):
-    sp = SPEC[cfg]
-    if cfg == "cfg5":
-        w = synth.make_world(seed=sp["seed"], n_loci=base, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), span_range=(50, 11000),
-                             read_len=sp["read_len"], n_reads=sp["n_reads"])
-        return w, None
-    n_cx = base // 3                                         # a third complex records
-    w = synth.make_world(seed=sp["seed"], n_loci=base - n_cx, svtypes=("DEL", "INV", "INS", "DEL"), span_range=(60, 11000),
-                         read_len=sp["read_len"], n_reads=sp["n_reads"])
-    rng = np.random.default_rng(sp["seed"] + 1)
-    specs = []
-    for t in range(n_cx):
-        s = dict(CX[t % len(CX)])
-        s["a"] = int(s["a"] * rng.uniform(0.9, 1.3))         # sizes vary from record to record
-        specs.append(s)
-    cx = synth.make_complex_world(sp["seed"] + 2, specs, n_reads=sp["n_reads"])
-    return w, cx
-
-
-def tile(w, n_total, text_of):
-    """Alias contigs `<name>_t<k>` sharing the base strings and record lists; returns the tiled world and its input text."""
-    base_names = list(w.contigs)
-    per = len(w.loci)
-    big = synth.SynthWorld()
-    lines = []
-    k = 0
-    while len(big.loci) < n_total:
-        sub = synth.SynthWorld()
-        for c in base_names:
-            big.contigs["%s.t%d" % (c, k)] = w.contigs[c]
-            big.reads["%s.t%d" % (c, k)] = w.reads.get(c, [])
-        for l in w.loci[:n_total - len(big.loci)]:
-            extra = dict(l.extra) if l.extra else None
-            if extra and "insert_chrom" in extra:
-                extra["insert_chrom"] = "%s.t%d" % (extra["insert_chrom"], k)
-            sub.loci.append(synth.Locus("%s.t%d" % (l.chrom, k), l.svtype, l.start, l.end, "%s.t%d" % (l.svid, k), l.ins_seq, extra))
-        big.loci += sub.loci
-        lines.append(text_of(sub))
-        k += 1
-    return big, "".join(lines), per
+from vapor_amd.workload import AT_SIZE as SPEC, at_size_base_world as base_world, at_size_tile as tile  # noqa: E402
 
 
 def main():
@@ -92,22 +38,12 @@ def main():
     os.environ.setdefault("VAPOR_QC_SEED", "7")
     os.environ["VAPOR_TIMING"] = "1"
     t0 = time.perf_counter()
-    w, cx = base_world(cfg, base)
+    from vapor_amd.workload import at_size_input
+    big, text, n_records = at_size_input(cfg, n_total, base)
     t_world = time.perf_counter() - t0
     tmp = tempfile.mkdtemp(prefix="vapor_at_size_")
-    if cfg == "cfg5":
-        big, text, per = tile(w, n_total, synth.bed_text)
-        src = os.path.join(tmp, "in.bed")
-    else:
-        n_cx_total = n_total // 3
-        b1, t1, _ = tile(w, n_total - n_cx_total, lambda s: synth.vcf_text(s, header=False))
-        b2, t2, _ = tile(cx, n_cx_total, lambda s: synth.complex_vcf_text(s, header=False))
-        big = b1
-        big.contigs.update(b2.contigs); big.reads.update(b2.reads); big.loci += b2.loci
-        text = t1 + t2
-        src = os.path.join(tmp, "in.vcf")
+    src = os.path.join(tmp, "in.bed" if cfg == "cfg5" else "in.vcf")
     open(src, "w").write(text)
-    n_records = text.count("\n")
     seqio.set_backend(seqio.MemorySamtools(big))
     result = os.path.join(tmp, "out.vapor") if cfg == "cfg5" else src + ".vapor"
     argv = [sp["mode"], "--sv-input", src, "--reference", "ref.fa", "--pacbio-input", "x.bam", "--output-path", os.path.join(tmp, "figs"),

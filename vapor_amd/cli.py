@@ -180,11 +180,46 @@ def vcf_list_readin(file_in):
 
 class Job:
     """One output row: how to score it (a driver generator factory, or fixed scores) and how to
-    write it."""
-    __slots__ = ("key", "make", "fixed", "row_prefix", "label")
+    write it.  `cost`: what the locus is expected to take (microseconds, `job_cost`), for the shares of the ranks."""
+    __slots__ = ("key", "make", "fixed", "row_prefix", "label", "cost")
 
-    def __init__(self, key, make=None, fixed=None, row_prefix=None, label=None):
+    def __init__(self, key, make=None, fixed=None, row_prefix=None, label=None, cost=None):
         self.key, self.make, self.fixed, self.row_prefix, self.label = key, make, fixed, row_prefix, label
+        self.cost = cost if cost is not None else (COST_FIXED_US if make is None else COST_HOST_US)
+
+
+# What a locus costs, for the ranks' shares (SURVEY.md 8e: greedy longest-processing-time on the estimated cost, not round-robin
+# by index - spans run from 50 bp to 21 kb windows, vapor_vali/vapor:334-367).  Three terms, priced on one MI355X box with its
+# host (tools/fit_job_cost.py, profiles/r04_job_cost_fit.json): the per-locus interpreter work; what scales with the bases
+# handled (reads extracted, trimmed, staged, uploaded and packed; windows read and uploaded); and the device term SURVEY 8e
+# names, n_reads x Lr x (La_ref + La_alt) nominal cells, at the rate the kernels go through them.
+COST_FIXED_US = 0.5            # a row without device work (an SV below 50 bp in vcf mode)
+COST_HOST_US = 45.0            # generator protocol, extraction call, tables, row
+COST_PER_KBASE_US = 1.6        # per 1 000 bases of reads and windows handled
+COST_PER_GCELL_US = 0.25       # per 1e9 nominal read-bp x window-bp cells (cfg2: 8.0e11 cells per 0.178 ms pass)
+_READS_KEPT = 20               # minimize_pacbio_read_list keeps at most 20 reads (SF:1091-1102)
+
+
+def job_cost(svtype: str, span: int, extra: int = 0) -> float:
+    """Expected cost of one locus in microseconds from its type and span alone (windows as the drivers cut them, SURVEY.md
+    3.2): `span` = end - start (INS: the inserted length; complex types: the whole region), `extra` = the duplicated block of
+    DISDUP / DUP_INV.  An estimate for balancing shares - nothing depends on its accuracy but the ranks' idle time."""
+    span = max(int(span), 0)
+    f = min(500, span) if span > 0 else 500
+    short = span < drivers.default_max_sv_test
+    if svtype == 'DEL':
+        lr, la = 2 * f, ((span + 2 * f) + 2 * f if short else 4 * f)
+    elif svtype == 'INV':
+        lr, la = (span + 2 * f, 2 * (span + 2 * f)) if short else (2 * f, 4 * f)
+    elif svtype == 'TANDUP':
+        lr, la = (2 * span + 2 * f, (span + 2 * f) + (2 * span + 2 * f)) if short else (2 * f, 4 * f)
+    elif svtype == 'INS':
+        lr, la = span + 2 * f, (2 * f + (span if span < 5000 else 0)) + (span + 2 * f)
+    else:                                   # DISDUP, DUP_INV, DEL_INV, Other: the whole region when it is short
+        lr, la = (span + extra + 2 * f, (span + 2 * f) + (span + extra + 2 * f)) if short else (2 * f, 4 * f)
+    bases = _READS_KEPT * lr + la
+    cells = _READS_KEPT * lr * la
+    return COST_HOST_US + COST_PER_KBASE_US * bases / 1e3 + COST_PER_GCELL_US * cells / 1e9
 
 
 def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> List[Job]:
@@ -207,7 +242,7 @@ def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
             fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
             jobs.append(Job(key, (lambda p=plt_li, a=ins_pos, s=ins_seq, f=fig:
                                   drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, f, '+')),
-                            row_prefix=x[3], label=x))
+                            row_prefix=x[3], label=x, cost=job_cost('INS', len(ins_seq))))
             continue
         elif tag in ['a/aa', 'aa/a', 'aa/aa', 'DUP', 'TANDUP']:
             key = ':'.join([str(i) for i in x[:-3]] + ['TANDUP'])
@@ -218,7 +253,7 @@ def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
         plt_li += 1
         fig = out_path + sample_name + '.' + name + '.' + key.replace(':', '__') + '.png'
         jobs.append(Job(key, (lambda p=plt_li, f=fn, info=x[:-3], g=fig: f(num_reads_cff, p, bam_in, ref, info, g)),
-                        row_prefix=x[3], label=x))
+                        row_prefix=x[3], label=x, cost=job_cost(name, x[2] - x[1])))
     return jobs
 
 
@@ -242,35 +277,67 @@ def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
                 key = ':'.join([str(i) for i in y] + [x])
                 fn = drivers.vapor_simple_del if x == 'DEL' else drivers.vapor_simple_inv
                 fig = out_path + sample_name + '.' + x + '.' + key.replace(':', '__') + '.png'
-                jobs.append(Job(key, (lambda p=plt_li, f=fn, info=y, g=fig: f(num_reads_cff, p, bam_in, ref, info, g))))
+                jobs.append(Job(key, (lambda p=plt_li, f=fn, info=y, g=fig: f(num_reads_cff, p, bam_in, ref, info, g)),
+                                cost=job_cost(x, y[2] - y[1])))
             elif x == 'INS':
                 key = ':'.join([str(i) for i in y[:3] + ['INS']])
                 ins_pos = '_'.join([str(i) for i in y[:2]])
                 ins_seq = y[-1] if len(y) == 4 else ''.join(['X' for _ in range(y[2])])
                 fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, a=ins_pos, s=ins_seq, g=fig:
-                                      drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, '+'))))
+                                      drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, '+')),
+                                cost=job_cost('INS', len(ins_seq))))
             elif x == 'DISDUP':
                 key = ':'.join([str(i) for i in y + ['DISDUP']])
                 fig = out_path + sample_name + '.DISDUP.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
-                                      drivers.vapor_simple_disdup(num_reads_cff, p, bam_in, ref, info, g))))
+                                      drivers.vapor_simple_disdup(num_reads_cff, p, bam_in, ref, info, g)),
+                                cost=_dup_cost('DISDUP', y)))
             elif x == 'DEL_INV':
                 key = ':'.join(['_'.join([str(i) for i in j]) for j in y] + ['DEL_INV'])
                 fig = out_path + sample_name + '.DEL_INV.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
-                                      drivers.vapor_del_inv(num_reads_cff, p, bam_in, ref, info, g))))
+                                      drivers.vapor_del_inv(num_reads_cff, p, bam_in, ref, info, g)),
+                                cost=job_cost('DEL_INV', _num(y[-1][2]) - _num(y[0][1]))))
             elif x == 'DUP_INV':
                 key = ':'.join([str(i) for i in y + ['DUP_INV']])
                 fig = out_path + sample_name + '.DUP_INV.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
-                                      drivers.vapor_dup_inv(num_reads_cff, p, bam_in, ref, info, g))))
+                                      drivers.vapor_dup_inv(num_reads_cff, p, bam_in, ref, info, g)),
+                                cost=_dup_cost('DUP_INV', y)))
             elif x == 'Other':
                 key = ':'.join([str(i) for i in y + ['CANNOT_CLASSIFY']])
                 fig = out_path + sample_name + '.CANNOT_CLASSIFY.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, info=y, g=fig:
-                                      drivers.vapor_cannot_classify(num_reads_cff, p, bam_in, ref, info, g))))
+                                      drivers.vapor_cannot_classify(num_reads_cff, p, bam_in, ref, info, g)),
+                                cost=_other_cost(y)))
     return jobs
+
+
+def _num(v) -> int:
+    try:
+        return int(v)
+    except (TypeError, ValueError):
+        return 0
+
+
+def _dup_cost(svtype, y) -> float:
+    """DISDUP / DUP_INV record [chrom, s, e, ins_chrom, ins_pos]: the region the drivers cut when block and insert point
+    share a contig, the block itself otherwise."""
+    s0, e0 = _num(y[1]), _num(y[2])
+    if len(y) > 4 and y[0] == y[3]:
+        bp = sorted([s0, e0, _num(y[4])])
+        return job_cost(svtype, bp[-1] - bp[0], e0 - s0)
+    return job_cost(svtype, e0 - s0)
+
+
+def _other_cost(info) -> float:
+    """`Other=` / SVelter record [ref structure, alt structure, chrom, bp, bp, ...]: the span of its numeric fields, once per
+    alt allele."""
+    nums = [int(v) for v in info[2:] if str(v).isdigit()]
+    span = (max(nums) - min(nums)) if len(nums) >= 2 else 0
+    n_alt = max(1, len([a for a in str(info[1]).split('_') if a and a not in str(info[0]).split('_')]))
+    return n_alt * job_cost('Other', span)
 
 
 def svelter_readin(file_in):
@@ -305,7 +372,8 @@ def svelter_jobs(sv_hash, num_reads_cff, bam_in, ref, out_path, sample_name) -> 
                 info = [k1, k2] + k3
                 print(info)
                 jobs.append(Job(key, (lambda p=plt_li, i=info, g=fig:
-                                      drivers.vapor_cannot_classify(num_reads_cff, p, bam_in, ref, i, g))))
+                                      drivers.vapor_cannot_classify(num_reads_cff, p, bam_in, ref, i, g)),
+                                cost=_other_cost(info)))
     return jobs
 
 
@@ -364,9 +432,14 @@ def _chunk_threads_ok() -> bool:
     return os.environ.get("VAPOR_MEMORY_CHOP", "") != "records"
 
 
+last_timing: dict = {}          # of the most recent score_jobs: seconds scoring this rank's share, seconds in the gather
+
+
 def _score_jobs(jobs, chunk, figure_fn, t0):
     import time
-    mine = vdist.my_share(len(jobs))
+    # shares by estimated cost (greedy longest-processing-time), the same list on every rank
+    costs = [float(j.cost) for j in jobs]
+    mine = vdist.my_share(len(jobs), costs)
     local: dict = {}
 
     def one_chunk(a, engine=None):
@@ -403,7 +476,9 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
         for t in part:
             if jobs[t].make is None:
                 local[t] = jobs[t].fixed
-    allres = vdist.gather_results(local, len(jobs))
+    t1 = time.perf_counter()
+    allres = vdist.gather_results(local, len(jobs), costs)
+    last_timing.update(score_s=t1 - t0, gather_s=time.perf_counter() - t1, loci=len(mine), cost=sum(costs[t] for t in mine))
     if os.environ.get("VAPOR_TIMING") and vdist.rank() == 0:
         dt = time.perf_counter() - t0
         print("vapor_amd.cli: scored %d loci on %d rank(s) in %.3f s -> %.1f loci/s" % (len(jobs), vdist.world(), dt, len(jobs) / dt),

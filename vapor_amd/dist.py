@@ -64,6 +64,18 @@ def init_from_env(backend: str = None) -> None:
     _pg = backend
 
 
+def adopt_process_group(backend: str) -> None:
+    """Use the torch.distributed process group the caller has already initialised (bench.py's ranks) for the gather."""
+    global _pg
+    _pg = backend
+
+
+def release_process_group() -> None:
+    """Forget an adopted group without destroying it (it is the caller's)."""
+    global _pg
+    _pg = None
+
+
 def finalize() -> None:
     global _pg, _files
     if _pg == "files":

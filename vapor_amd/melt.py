@@ -9,7 +9,7 @@ from . import simple_function as SF
 
 
 def run(prefix, out_path, sample_name, bam_in, ref, num_reads_cff, chunk, figure_fn) -> None:
-    from .cli import Job, output_rows, score_jobs
+    from .cli import Job, job_cost, output_rows, score_jobs
     from . import dist as vdist
     jobs = []
     plt_li = 0
@@ -29,7 +29,8 @@ def run(prefix, out_path, sample_name, bam_in, ref, num_reads_cff, chunk, figure
                 plt_li += 1
                 fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, a=key, s=ins_seq, g=fig, q=pol:
-                                      drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, q))))
+                                      drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, q)),
+                                cost=job_cost('INS', len(ins_seq))))
     scores = score_jobs(jobs, chunk, figure_fn)
     if vdist.rank() == 0:
         SF.write_output_initiate(prefix + '.vapor')
