@@ -353,9 +353,12 @@ def gen_window(m):
     m.qual_check_repetitive_region = qc
     m.X_means_cluster_reformat = xm
 
+    XM_SEEDS = (7, 8, 1234)
+
     def add(name, seq):
         del trace[:]
         xm_calls[0] = 0
+        np.random.seed(XM_SEEDS[0])         # (sklearn's KMeans and scipy's kmeans draw from numpy's global generator, SF:860-881)
         r = call(m.window_size_refine, seq)
         c = {"name": name, "seq": seq, "qc_trace": [list(t) for t in trace], "xmeans_calls": xm_calls[0]}
         if "error" in r:
@@ -364,6 +367,17 @@ def gen_window(m):
             w, q = r["ok"]
             c["window_size"] = w
             c["qc"] = q
+        if xm_calls[0] > 0:
+            # the X-means branch is unseeded in the reference, but many of its outcomes do not depend on
+            # the draws (BIC keeps one cluster).  The reference's answer under several seeds: equal answers = pinned in fact.
+            by_seed = {str(XM_SEEDS[0]): jsonable(r)}
+            for sd in XM_SEEDS[1:]:
+                np.random.seed(sd)
+                by_seed[str(sd)] = jsonable(call(m.window_size_refine, seq))
+            c["xmeans_by_seed"] = by_seed
+            vals = list(by_seed.values())
+            c["xmeans_seed_independent"] = bool(all("ok" in v for v in vals) and all(v == vals[0] for v in vals))
+            c["xmeans_reference_raises"] = sorted({v["error"] for v in vals if "error" in v})
         cases.append(c)
 
     for n in (60, 500, 1500, 4000):
@@ -384,11 +398,22 @@ def gen_window(m):
     add("inverted_repeat", synth.random_dna(rng, 200) + unit + synth.random_dna(rng, 100) + synth.revcomp(unit) + synth.random_dna(rng, 200))
     add("homopolymer", "A" * 300)
     add("dinuc", "AC" * 200)
+    # alt windows of tandem duplications as vapor_simple_tandup_Vapor builds them (SF:1755: ref[:f] + mid + mid + ref[-f:]):
+    # the windows of the product that meet this branch
+    for mid_len, flank in ((150, 150), (300, 300), (600, 500), (1000, 500), (2000, 500), (3500, 500), (5000, 500), (8000, 500)):
+        gg = synth.random_dna(rng, mid_len + 2 * flank)
+        mid = gg[flank:-flank]
+        add("tandup_alt_%d" % mid_len, gg[:flank] + mid + mid + gg[-flank:])
+    gg = synth.random_dna(rng, 1600)
+    add("tandup_alt_triple_500", gg[:500] + gg[500:1000] * 3 + gg[-500:])
     m.qual_check_repetitive_region = orig_qc
     m.X_means_cluster_reformat = orig_xm
     dump("window.json.gz", {"source": "window_size_refine SF:2030-2046, qual_check SF:1154-1171",
-                            "note": "cases with xmeans_calls>0 depend on unseeded KMeans (SURVEY §8a-Q): "
-                                    "only qc_trace is pinned for them", "cases": cases})
+                            "note": "cases with xmeans_calls>0 pass through the reference's unseeded X-means (SURVEY §8a-Q); they were run "
+                                    "under numpy seeds %s: where all answers agree (xmeans_seed_independent) the answer is pinned, "
+                                    "elsewhere only qc_trace is (xmeans_reference_raises: what the reference raised - scipy.std, "
+                                    "SF:878, is gone from current SciPy, so every split into more than one cluster ends there)" % (XM_SEEDS,),
+                            "cases": cases})
 
 
 # ---------------------------------------------------------------------------
@@ -511,6 +536,9 @@ def run_bed(m, cli, world, tmp, num_reads_cff=3):
         else:
             continue
         rec = {"bed_row": x, "key": key, "scores": sc}
+        if getattr(m, "_xm_counter", None) is not None:
+            rec["xmeans_calls"] = m._xm_counter[0]          # X-means calls of this locus (window_size_refine's repeat check)
+            m._xm_counter[0] = 0
         if "ok" in sc:
             res = m.result_organize_ins([key, sc["ok"]])
             m.write_output_main(out_name, res[0].split(":") + [x[3]] + res[1:])
@@ -532,19 +560,38 @@ def gen_locus(m):
         ("bed_hom_ref", dict(seed=75, n_loci=4, svtypes=("DEL", "TANDUP", "INV", "INS"), span_range=(300, 900), read_len=3200, n_reads=8, alt_fraction=0.0)),
         ("bed_many_reads", dict(seed=76, n_loci=2, svtypes=("DEL", "INV"), span_range=(300, 700), read_len=2000, n_reads=30)),
     ]
+    # a tandem-duplication-only world whose alt windows all meet the X-means branch of the repeat check
+    specs.append(("bed_tandup_band", dict(seed=78, n_loci=6, svtypes=("TANDUP",), span_range=(150, 3000), read_len=7200, n_reads=8)))
+    calls, xm_orig = _count_xmeans(m)
+    m._xm_counter = calls
     for name, kw in specs:
         w = synth.make_world(**kw)
         m.os = ShimOS(w)
+        calls[0] = 0
+        np.random.seed(7)                 # (the reference's X-means draws from numpy's global generator, SF:860-881)
         per_locus, text = run_bed(m, cli, w, tmp)
+        case = {"name": name, "world": world_to_json(w), "bed": synth.bed_text(w), "per_locus": per_locus, "vapor_text": text}
+        if any(p.get("xmeans_calls") for p in per_locus):
+            # the same run under other seeds: equal tables = the rows do not depend on the draws (pinned end to end)
+            same = True
+            for sd in (8, 1234):
+                np.random.seed(sd)
+                calls[0] = 0
+                pl2, text2 = run_bed(m, cli, w, tmp)
+                same = same and text2 == text and jsonable([p["scores"] for p in pl2]) == jsonable([p["scores"] for p in per_locus])
+            case["xmeans_seed_independent"] = bool(same)
         m.os = os
-        out_cases.append({"name": name, "world": world_to_json(w), "bed": synth.bed_text(w),
-                          "per_locus": per_locus, "vapor_text": text})
+        out_cases.append(case)
         print("  %s: %s" % (name, [len(p["scores"].get("ok", [])) if "ok" in p["scores"] else p["scores"] for p in per_locus]))
     # long-span fallbacks (>= 10 kb): junction windows only, 1 kb reads
     w = synth.make_world(seed=77, n_loci=3, svtypes=("DEL", "INV", "TANDUP"), span_range=(10050, 10400), read_len=1500, n_reads=8)
     m.os = ShimOS(w)
+    calls[0] = 0
+    np.random.seed(7)
     per_locus, text = run_bed(m, cli, w, tmp)
     m.os = os
+    m._xm_counter = None
+    m.X_means_cluster_reformat = xm_orig
     out_cases.append({"name": "bed_long_span", "world": world_to_json(w), "bed": synth.bed_text(w),
                       "per_locus": per_locus, "vapor_text": text})
     print("  bed_long_span: %s" % [p["scores"] for p in per_locus])

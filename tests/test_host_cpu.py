@@ -39,18 +39,51 @@ def test_io_helpers(case):
 
 
 @pytest.mark.parametrize("case", load_golden("window.json.gz")["cases"], ids=lambda c: c["name"])
-def test_window_size_refine(fake, case):
+def test_window_size_refine(fake, case, monkeypatch):
+    """window_size_refine (SF:2030-2046) against the reference's answers.  The windows that pass through its X-means branch
+    (unseeded sklearn / scipy draws, SF:856-887) were run by the reference under several numpy seeds when the fixture was
+    made: where every seed gave the same answer (`xmeans_seed_independent`: BIC keeps one cluster - all tandem-duplication alt
+    windows are of that kind) the answer is pinned and the product must give it whatever its own seed; where the reference
+    itself raises on this SciPy (`scipy.std`, SF:878, is gone: every split into more than one cluster ends there) the product
+    goes on as the reference did on the SciPy it was written for - a stated deviation, recorded here."""
     from vapor_amd import simple_function as SF
-    if case["xmeans_calls"] > 0:
-        pytest.skip("depends on unseeded KMeans in the reference (parity unpinned, SURVEY 8a-Q)")
+    if case["xmeans_calls"] > 0 and not case["xmeans_seed_independent"]:
+        assert case["xmeans_reference_raises"] == ["AttributeError"] and case.get("error") == "AttributeError"
+        answers = []
+        for seed in ("7", "8"):
+            monkeypatch.setenv("VAPOR_QC_SEED", seed)
+            got = SF.window_size_refine(case["seq"])
+            assert got[0] in (10, 20, 30, 40) and 0.0 < float(got[1][0]) <= 1.0 and len(got[1][1]) >= 1
+            # the integer part of the check is the reference's (its qc_trace): the diagonal share of the first self plot
+            if got[0] == 10:
+                assert float(got[1][0]) == case["qc_trace"][0][1] / case["qc_trace"][0][0]
+            answers.append(got)
+        monkeypatch.setenv("VAPOR_QC_SEED", "7")
+        assert SF.window_size_refine(case["seq"]) == answers[0]          # (the same seed, the same answer)
+        return
     if "error" in case:
         with pytest.raises(Exception):
             SF.window_size_refine(case["seq"])
         return
-    got = SF.window_size_refine(case["seq"])
-    assert got[0] == case["window_size"]
-    if case["window_size"] != "Error":
-        assert float(got[1][0]) == float(case["qc"][0]) and [float(v) for v in got[1][1]] == [float(v) for v in case["qc"][1]]
+    for seed in ((None,) if case["xmeans_calls"] == 0 else ("7", "8", None)):
+        if seed is None:
+            monkeypatch.delenv("VAPOR_QC_SEED", raising=False)
+        else:
+            monkeypatch.setenv("VAPOR_QC_SEED", seed)
+        got = SF.window_size_refine(case["seq"])
+        assert got[0] == case["window_size"]
+        if case["window_size"] != "Error":
+            assert float(got[1][0]) == float(case["qc"][0]) and [float(v) for v in got[1][1]] == [float(v) for v in case["qc"][1]]
+
+
+def test_window_fixture_pins_the_xmeans_outcomes_that_are_pinnable():
+    """at most three of the windows that meet the X-means branch stay unpinned (the ones where the
+    reference itself raises), and every tandem-duplication alt window is pinned."""
+    cases = load_golden("window.json.gz")["cases"]
+    xm = [c for c in cases if c["xmeans_calls"] > 0]
+    assert len(xm) >= 18
+    assert sorted(c["name"] for c in xm if not c["xmeans_seed_independent"]) == ["N_100_ok", "inverted_repeat", "tandem_500x2"]
+    assert all(c["xmeans_seed_independent"] for c in xm if c["name"].startswith("tandup_alt_"))
 
 
 @pytest.mark.parametrize("case", load_golden("scorers.json.gz")["cases"], ids=lambda c: c["name"])
@@ -83,19 +116,39 @@ def test_bed_cli_rows(fake, case, tmp_path):
     args = ["bed", "--sv-input", str(bed), "--reference", "ref.fa", "--pacbio-input", "x.bam",
             "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]
     if ref_failed:
-        # the reference died inside the unseeded X-means branch (scipy.std); rows before it must agree
-        try:
-            cli.main(args)
-        except Exception:
-            return
+        # The reference died inside its X-means branch for these loci (`scipy.std`, SF:878, is gone from current SciPy; the
+        # fixture's generator catches the exception per locus and goes on).  The product clusters as the reference did on the
+        # SciPy it was written for and scores the locus: its table is the reference's plus one row per such locus.
+        assert all(p["scores"]["error"] == "AttributeError" and p.get("xmeans_calls", 1) > 0 for p in ref_failed)
+        assert cli.main(args) == 0
         got = out.read_text().splitlines()
         exp = case["vapor_text"].splitlines()
-        assert got[:len(exp)][:1] == exp[:1]
+        failed = {tuple(p["key"].split(":")) for p in ref_failed}
+        assert [ln for ln in got if tuple(ln.split("\t")[:4]) not in failed] == exp
+        assert len(got) == len(exp) + len(failed)
         return
-    assert cli.main(args) == 0
-    assert out.read_text() == case["vapor_text"]
+    for seed in (("7", "8") if case.get("xmeans_seed_independent") else (None,)):
+        # (loci whose windows meet the reference's unseeded X-means: the fixture's rows were the same under every seed the
+        # reference was run with, so the product must give them whatever its own seed - every TANDUP row is of that kind)
+        if seed is not None:
+            os.environ["VAPOR_QC_SEED"] = seed
+        try:
+            assert cli.main(args) == 0
+        finally:
+            os.environ.pop("VAPOR_QC_SEED", None)
+        assert out.read_text() == case["vapor_text"]
     n_loci = len(case["per_locus"])
     assert len(fake.batches) < 4 * n_loci or n_loci < 3     # batched, not one plan per read
+
+
+def test_tandup_rows_are_pinned_end_to_end():
+    """tandem-duplication loci whose alt window enters the X-means band have pinned final rows - the
+    reference gives the same table under every seed it was run with (tests/golden/locus_bed.json.gz)."""
+    cases = {c["name"]: c for c in LOCUS}
+    band = cases["bed_tandup_band"]
+    assert band["xmeans_seed_independent"] is True
+    assert all(p["xmeans_calls"] >= 1 and len(p["scores"]["ok"]) >= 4 for p in band["per_locus"])
+    assert band["vapor_text"].count("TANDUP") == 6 and "\tNA" not in band["vapor_text"]
 
 
 def test_driver_functions_match_reference_per_locus(fake):

@@ -1,8 +1,8 @@
 """Prices cli.job_cost's three terms on the GPU box: worlds of ONE type and ONE span each go through
 the product path (cli.bed_jobs -> score_jobs, in-memory world, one process, figures off), the time per locus is measured
-(best of three) and fitted by least squares to
+(best of three) and fitted by non-negative least squares (on relative errors) to
 
-    host_us + per_kbase_us * (20 * Lr + La) / 1000 + per_gcell_us * 20 * Lr * La / 1e9
+    host_us + per_kbase_us * (20 * Lr + La) / 1000 + per_gcell_us * 20 * Lr * La / 1e9 + xmeans_us * [tandem duplication]
 
 with Lr / La the windows cli.job_cost derives from type and span.  Writes profiles-style JSON to --out (default
 gpurun_out/r04_job_cost_fit.json): the measurements, the fitted coefficients, the constants cli.py carries, and how evenly
@@ -25,14 +25,14 @@ from vapor_amd import cli, dist, seqio, synth
 
 def windows(svtype, span):
     """(Lr, La_ref + La_alt) exactly as cli.job_cost cuts them (kept in step by tests/test_dist_gloo.py)."""
-    saved = (cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US)
+    saved = (cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US, cli.COST_XMEANS_US)
     try:
-        cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US = 0.0, 1.0, 0.0
+        cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US, cli.COST_XMEANS_US = 0.0, 1.0, 0.0, 0.0
         bases = cli.job_cost(svtype, span) * 1e3            # 20 * Lr + La
         cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US = 0.0, 1.0
         cells = cli.job_cost(svtype, span) * 1e9            # 20 * Lr * La
     finally:
-        cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US = saved
+        cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US, cli.COST_XMEANS_US = saved
     return bases, cells
 
 
@@ -73,11 +73,13 @@ def main():
         b, c = windows(t, span)
         rows.append({"type": t, "span": span, "us_per_locus": round(us, 2), "bases": b, "cells": c, "loci_with_scores": scored})
         print(rows[-1], flush=True)
-    A = np.array([[1.0, r["bases"] / 1e3, r["cells"] / 1e9] for r in rows])
+    # four non-negative terms: the three of every locus, and what the X-means of a tandem duplication's alt window adds
+    from scipy.optimize import nnls
+    A = np.array([[1.0, r["bases"] / 1e3, r["cells"] / 1e9, 1.0 if r["type"] == "TANDUP" else 0.0] for r in rows])
     y = np.array([r["us_per_locus"] for r in rows])
-    coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+    coef, _res = nnls(A / y[:, None], np.ones(len(y)))       # (relative errors: a 30 us locus counts like a 700 us one)
     pred = A @ coef
-    carried = np.array([cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US])
+    carried = np.array([cli.COST_HOST_US, cli.COST_PER_KBASE_US, cli.COST_PER_GCELL_US, cli.COST_XMEANS_US])
     # how evenly the shares of a mixed world come out: true time = measured, estimate = fitted / carried / unit costs
     rng = np.random.default_rng(3)
     pick = rng.integers(0, len(rows), size=4000)
@@ -89,8 +91,9 @@ def main():
         return round(max(loads) / (sum(loads) / nw), 4)
     rec = {"measurements": rows,
            "fit": {"host_us": round(float(coef[0]), 2), "per_kbase_us": round(float(coef[1]), 3), "per_gcell_us": round(float(coef[2]), 3),
+                   "xmeans_us": round(float(coef[3]), 1),
                    "max_rel_error": round(float(np.max(np.abs(pred - y) / y)), 3)},
-           "carried_by_cli": {"host_us": cli.COST_HOST_US, "per_kbase_us": cli.COST_PER_KBASE_US, "per_gcell_us": cli.COST_PER_GCELL_US,
+           "carried_by_cli": {"host_us": cli.COST_HOST_US, "per_kbase_us": cli.COST_PER_KBASE_US, "per_gcell_us": cli.COST_PER_GCELL_US, "xmeans_us": cli.COST_XMEANS_US,
                               "max_rel_error": round(float(np.max(np.abs(A @ carried - y) / y)), 3)},
            "share_spread_max_over_mean": {str(nw): {"fitted": spread(pred[pick], nw), "carried": spread((A @ carried)[pick], nw),
                                                     "by_count": spread(np.ones(len(pick)), nw)} for nw in (2, 4, 8)},

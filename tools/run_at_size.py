@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from vapor_amd import cli, seqio, synth
+from vapor_amd import cli, pipeline, seqio, synth
 
 from vapor_amd.workload import AT_SIZE as SPEC, at_size_base_world as base_world, at_size_tile as tile  # noqa: E402
 
@@ -78,6 +78,9 @@ def main():
            "loci_per_s": round(n_records / dt, 1), "world_seconds": round(t_world, 1), "peak_host_rss_mb": round(rss_mb, 1),
            "rows_sha256": hashlib.sha256("\n".join(body).encode()).hexdigest(), "qc_seed": os.environ["VAPOR_QC_SEED"],
            "sample": [[t, body[t]] for t in pick], "rc": rc,
+           # windows that met the reference's unseeded X-means: `one_cluster` outcomes are the reference's
+           # answer under any seed; `sizes_decide` counts the windows where the cluster sizes could change the window size at all
+           "xmeans_windows": dict(pipeline.qc_counts),
            "note": "one process, one GPU, in-memory world, figures off; tiles repeat the base loci under alias contig names"}
     json.dump(rec, open(out, "w"))
     print(json.dumps({k: v for k, v in rec.items() if k != "sample"}), flush=True)

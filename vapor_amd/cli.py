@@ -194,9 +194,12 @@ class Job:
 # handled (reads extracted, trimmed, staged, uploaded and packed; windows read and uploaded); and the device term SURVEY 8e
 # names, n_reads x Lr x (La_ref + La_alt) nominal cells, at the rate the kernels go through them.
 COST_FIXED_US = 0.5            # a row without device work (an SV below 50 bp in vcf mode)
-COST_HOST_US = 45.0            # generator protocol, extraction call, tables, row
-COST_PER_KBASE_US = 1.6        # per 1 000 bases of reads and windows handled
-COST_PER_GCELL_US = 0.25       # per 1e9 nominal read-bp x window-bp cells (cfg2: 8.0e11 cells per 0.178 ms pass)
+COST_HOST_US = 40.0            # generator protocol, extraction call, tables, row (fit: 39-48)
+COST_PER_KBASE_US = 0.35       # per 1 000 bases of reads and windows handled (fit: 0.27-0.64)
+COST_PER_GCELL_US = 0.25       # per 1e9 nominal read-bp x window-bp cells: the kernels' own rate (cfg2: 8.0e11 cells per 0.178 ms
+                               # pass); too small beside the host terms for the fit to see
+COST_XMEANS_US = 500.0         # a tandem duplication's alt window always meets the X-means branch of the repeat check
+                               # (sklearn / scipy on the host workers: 290-1 360 us per locus measured, by no simple rule of the span)
 _READS_KEPT = 20               # minimize_pacbio_read_list keeps at most 20 reads (SF:1091-1102)
 
 
@@ -219,7 +222,8 @@ def job_cost(svtype: str, span: int, extra: int = 0) -> float:
         lr, la = (span + extra + 2 * f, (span + 2 * f) + (span + extra + 2 * f)) if short else (2 * f, 4 * f)
     bases = _READS_KEPT * lr + la
     cells = _READS_KEPT * lr * la
-    return COST_HOST_US + COST_PER_KBASE_US * bases / 1e3 + COST_PER_GCELL_US * cells / 1e9
+    xmeans = COST_XMEANS_US if (svtype == 'TANDUP' and short) else 0.0
+    return COST_HOST_US + COST_PER_KBASE_US * bases / 1e3 + COST_PER_GCELL_US * cells / 1e9 + xmeans
 
 
 def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> List[Job]:
@@ -427,7 +431,7 @@ def _chunk_threads_ok() -> bool:
     seek() and read(), the samtools hybrid and VAPOR_MEMORY_CHOP=records write one module-level result array."""
     from . import seqio
     be = seqio.get_backend()
-    if not getattr(be, "threads_ok", False) or os.environ.get("VAPOR_BAM_NATIVE", "1") == "0":
+    if not getattr(be, "chunk_threads_ok", False) or os.environ.get("VAPOR_BAM_NATIVE", "1") == "0":
         return False
     return os.environ.get("VAPOR_MEMORY_CHOP", "") != "records"
 

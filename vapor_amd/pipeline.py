@@ -110,6 +110,14 @@ def _raise_for_status(st_row) -> None:
 # window_size_refine for many sequences at once
 # ------------------------------------------------------------------------------------------
 
+# Windows that met the X-means branch of the repeat check since the process started (SF:1165-1167), by outcome: `one_cluster`
+# - BIC keeps one cluster, the reference's answer whatever its unseeded draws; `split` - more than one cluster: seed-dependent
+# in the reference (and on current SciPy it raises there, SF:878); `sizes_decide` - of either kind, the windows whose diagonal
+# share is at most 0.4, i.e. the only ones where the cluster sizes can change the window size at all (SF:2038).
+qc_counts = {"band": 0, "one_cluster": 0, "split": 0, "sizes_decide": 0, "raised": 0}
+_qc_lock = threading.Lock()
+
+
 def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> List[list]:
     """window_size_refine (SF:2030-2046) for every sequence; returns [[w, qc] | ['Error','Error']].
     Exceptions the reference would raise for one sequence are returned in its slot.
@@ -191,7 +199,14 @@ def refine_windows(engine, seqs: Sequence[str], region_QC_Cff: float = 0.4) -> L
                     if isinstance(got, BaseException):
                         raise got
                     qc = [float(diag[w]), got]
+                    with _qc_lock:
+                        qc_counts["band"] += 1
+                        qc_counts["one_cluster" if len(got) == 1 else "split"] += 1
+                        qc_counts["sizes_decide"] += int(not qc[0] > region_QC_Cff)
                 except Exception as e:          # noqa: BLE001 - e.g. the clustering libraries' own errors
+                    with _qc_lock:
+                        qc_counts["band"] += 1
+                        qc_counts["raised"] += 1
                     out[t] = e
                     continue
             else:

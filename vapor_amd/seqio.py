@@ -111,6 +111,7 @@ class InProcessBam(SamtoolsHybrid):
     the trimming code as fields, not as text to be split again.  The default backend."""
 
     threads_ok = True                  # pipeline.run_batch may start loci on several threads (native chop, positioned reads)
+    chunk_threads_ok = True            # cli.score_jobs may score several chunks at once, a thread each
 
     def __init__(self) -> None:        # noqa: D401 - does not require the samtools binary
         self.exe = None
@@ -192,6 +193,10 @@ class InProcessBam(SamtoolsHybrid):
 
 
 class MemorySamtools:
+    # cli.score_jobs may score several chunks at once, a thread each: the native chop writes to arrays of the call's own
+    # (not with VAPOR_MEMORY_CHOP=records: that path's CIGAR walk answers into one module-level array, see cli._chunk_threads_ok)
+    chunk_threads_ok = True
+
     """Answers faidx/view from a `SynthWorld`; file names are ignored."""
 
     def __init__(self, world) -> None:
