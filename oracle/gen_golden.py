@@ -1036,10 +1036,80 @@ def gen_figures(m):
                              "world": world_to_json(w), "bed": synth.bed_text(w), "cases": calls})
 
 
+# ---------------------------------------------------------------------------
+def parser_digest(obj) -> str:
+    """sha256 of the canonical JSON of a parser's result (dict keys in insertion order: first-seen order is part of the result)."""
+    return hashlib.sha256(json.dumps(jsonable(obj), separators=(",", ":")).encode()).hexdigest()
+
+
+def parser_inputs():
+    """The reference's own parser fixtures: vapor_test/vapor_test.{vcf,bed} and simulate/Structural_Variants_*."""
+    import glob
+    base = os.path.dirname(os.path.dirname(REF_SF))
+    files = [os.path.join(base, "vapor_test", "vapor_test.vcf"), os.path.join(base, "vapor_test", "vapor_test.bed")]
+    for d in ("Structural_Variants_het", "Structural_Variants_homo"):
+        files += sorted(glob.glob(os.path.join(base, "simulate", d, "*.vcf"))) + sorted(glob.glob(os.path.join(base, "simulate", d, "*.bed")))
+    return base, files
+
+
+def bed_five_columns(text: str) -> str:
+    """`chr start end TYPE` rows re-expressed as `chr start end SVID TYPE` (the 4-column form of the shipped files no longer
+    parses: bed_info_readin reads pin[4], vapor_vali/vapor:31); 5-column rows stay as they are."""
+    out = []
+    for n, line in enumerate(text.splitlines()):
+        f = line.split()
+        out.append("\t".join(f[:3] + ["sv%d" % (n + 1), f[3]]) if len(f) == 4 else line)
+    return "\n".join(out) + "\n"
+
+
+def gen_parsers(m):
+    """The reference's vcf_list_readin / bed_info_readin (vapor_vali/vapor:22-50, 127-202) on its own fixture files: per file
+    the digest of what it returns (or the exception it raises), for the whole file and for its first 300 lines - the slices,
+    and the two small vapor_test files whole, travel as fixture inputs so that the comparison also runs where the reference
+    is not mounted."""
+    cli = load_cli(m)
+    base, files = parser_inputs()
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_parsers_")
+    cases = []
+
+    def run(kind, text):
+        path = os.path.join(tmp, "in." + kind)
+        open(path, "w").write(text)
+        if kind == "vcf":
+            r = call(cli["vcf_list_readin"], path)
+        else:
+            r = call(cli["bed_info_readin"], path, os.path.join(tmp, "figs") + "/")
+        if "error" in r:
+            return {"error": r["error"]}
+        res = r["ok"]
+        if kind == "vcf":
+            return {"digest": parser_digest([res[0], sorted(res[1].items())]), "buckets": {k: len(v) for k, v in res[0].items()},
+                    "records_keyed": len(res[1])}
+        return {"digest": parser_digest(res), "rows": len(res)}
+
+    for f in files:
+        rel = os.path.relpath(f, base)
+        kind = "vcf" if f.endswith(".vcf") else "bed"
+        text = open(f).read()
+        small = len(text) < 20000
+        head = text if small else "".join(text.splitlines(True)[:300])
+        c = {"file": rel, "kind": kind, "input_sha256": hashlib.sha256(text.encode()).hexdigest(), "lines": text.count("\n"),
+             "whole": run(kind, text), "slice_lines": head.count("\n"), "slice": run(kind, head), "slice_text": head}
+        if kind == "bed":
+            c["whole_5col"] = run(kind, bed_five_columns(text))
+            c["slice_5col"] = run(kind, bed_five_columns(head))
+        cases.append(c)
+        print("  %s: %s" % (rel, {k: v for k, v in c["whole"].items() if k != "digest"}))
+    dump("parsers.json.gz", {"source": "vcf_list_readin / bed_info_readin, vapor_vali/vapor:22-50, 127-202, on vapor_test/ and simulate/Structural_Variants_*",
+                             "note": "digest = sha256 of the canonical JSON of the returned structure (vcf: [buckets in first-seen order, sorted "
+                                     "record-index map]); *_5col: 4-column BED rows re-expressed as chr start end SVID TYPE",
+                             "cases": cases})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = load_reference()
-    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt", "complex", "deep", "figures"]
+    which = sys.argv[1:] or ["kmerhits", "cleaners", "scorers", "window", "genotype", "io", "locus", "vcf", "other", "config1", "melt", "complex", "deep", "figures", "parsers"]
     for w in which:
         print("== " + w)
         globals()["gen_" + w](m)
