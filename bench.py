@@ -63,7 +63,7 @@ class Resident:
     def __init__(self, eng, w, wl, n_plans, torch, dist, world, coll_stream):
         self.w, self.torch, self.dist, self.world, self.coll = w, torch, dist, world, coll_stream
         t0 = time.perf_counter()
-        self.ss = eng.seqset(w.seqs)
+        self.ss = w.upload(eng)
         self.upload_s = time.perf_counter() - t0
         self.plans, self.rec = [], []
         for _ in range(n_plans):
@@ -506,7 +506,7 @@ def inclusive_rate(eng, w, wl, reps: int = 6):
     times, parts = [], np.zeros(4)
     for r in range(reps + 1):
         t0 = time.perf_counter()
-        ss = eng.seqset(w.seqs)
+        ss = w.upload(eng)
         t1 = time.perf_counter()
         pw = eng.plan(ss, selfp)
         stw = pw.run()
@@ -573,7 +573,7 @@ def sub_record(eng, wl, name, torch, passes: int = 12, cpu_seconds: float = 0.0)
     (the clean and finish kernels of one pass overlap the other plan's join), and one plan alone for comparison."""
     spec = wl.WORKLOADS[name]
     w = wl.make_workload(name, seed=3000, **spec)
-    ss = eng.seqset(w.seqs)
+    ss = w.upload(eng)
     plans = []
     for _ in range(2):
         p = eng.plan(ss, w.pairs)

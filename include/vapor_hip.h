@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VAPOR_ABI_VERSION 2
+#define VAPOR_ABI_VERSION 3
 /* A developer build of the library (-DVAPOR_DEV_BUILD: timing stamps, A/B variants, non-default tuning constants)
  * reports VAPOR_ABI_VERSION + VAPOR_ABI_DEV_OFFSET and lists what it carries in vapor_build_flags(); the product
  * build reports VAPOR_ABI_VERSION and "".  A loader that accepts only VAPOR_ABI_VERSION can never run an
@@ -114,6 +114,36 @@ int vapor_seqset_create(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* blob, con
 /* the same from one pointer per sequence (no concatenated copy on the caller's side): seq[s] points at len[s] bytes */
 int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len,
                              const uint8_t* flags, int32_t* seq_info, vapor_seqset** out);
+/*
+ * Derived sequences: alleles the reference builds by string surgery on a window it has already read - a deletion's
+ * ref_seq[:f] + ref_seq[-f:] (SF:1712), a tandem duplication's ref[:f] + mid + mid + ref[-f:] (SF:1755), an inversion's
+ * ref[:f] + reverse(complementary(mid)) + ref[-f:] (SF:1907), an insertion's flank + ins_seq + flank (SF:1872), the block
+ * structures of the complex types (SF:1557-1665), and the str.upper() twins of abs_dis_m1b (SF:183-184) - described instead of
+ * uploaded: derived sequence d (index n_seqs + d of the set) is the concatenation of its segments
+ * segs[seg_first[d] .. seg_first[d+1]), each a slice parent[off : off + len] of one of the n_seqs sequences given as bytes,
+ * reverse-complemented when VAPOR_SEG_REVCOMP is set, the whole upper-cased when derived_flags[d] has VAPOR_SEQ_UPPER.  The
+ * device assembles the bit planes from the parents' (derive_kernel); no byte of a derived sequence crosses the link.
+ * complementary() DROPS every character outside ATGCN / atgcn (SF:471-478), which a descriptor cannot express: a
+ * reverse-complemented segment whose parent holds such a character (an IUPAC code, an X) is refused with VAPOR_E_ARG and the
+ * caller uploads that allele as bytes.  seq_info has 2 * (n_seqs + n_derived) entries.
+ * A plan over such a set joins every read ONCE against a reference window and the alleles derived from it: the k-mers of a
+ * derived allele are those of its parent's slices plus the few that span a junction or lie in inserted bytes, so one table
+ * (the parent followed by those stretches) and one probe per read give the dots of all of them (remap_kernel).
+ */
+typedef struct vapor_segment {
+    int32_t parent; /* 0 .. n_seqs-1 */
+    int32_t off, len;
+    uint32_t flags; /* VAPOR_SEG_* */
+} vapor_segment;
+#define VAPOR_SEG_REVCOMP 1u
+#define VAPOR_MAX_SEGMENTS 16 /* per derived sequence */
+int vapor_seqset_create_derived(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len,
+                                const uint8_t* flags, int32_t n_derived, const int32_t* seg_first, const vapor_segment* segs,
+                                const uint8_t* derived_flags, int32_t* seq_info, vapor_seqset** out);
+/* The packed planes of one sequence as they lie in HBM (for tests and callers that want to check a derived sequence against
+ * the same text uploaded as bytes): ceil(len / 32) chunks, per chunk 2 words of the 2-bit plane into p2, 1 word of the
+ * "not upper-case ACGT" plane into e1, 4 words of the 4-bit symbol plane into x4 (any of the three may be NULL). */
+int vapor_seqset_planes(vapor_seqset* set, int32_t seq, uint32_t* p2, uint32_t* e1, uint32_t* x4);
 int vapor_seqset_destroy(vapor_seqset* set);
 
 /* ---- plans: a batch of dot plots resident on the device ---------------------------------- */
@@ -129,8 +159,9 @@ int vapor_plan_destroy(vapor_plan* plan);
  */
 int vapor_plan_run(vapor_plan* plan, int64_t* stats);
 /* device time of the kernels of the last vapor_plan_run, measured with HIP events on the
- * library's stream: ms[0] = join kernels, ms[1] = clean kernel, ms[2] = whole run incl. copies,
- * ms[3] = number of join launches, ms[4] = number of retried pairs, ms[5] = finish kernel */
+ * library's stream: ms[0] = join kernels (incl. the remap of shared joins), ms[1] = clean kernel, ms[2] = whole run incl. copies,
+ * ms[3] = number of join launches, ms[4] = number of retried pairs, ms[5] = finish kernel, ms[6] = pairs served by a shared
+ * join, ms[7] = joins that serve them */
 int vapor_plan_timings(vapor_plan* plan, double* ms, int32_t n);
 /* run records the join of the last run wrote per pair (n_pairs int64): the device keeps runs of consecutive
  * dots (j+t, i+t) / (j-t, i+t) as one record; stats[0] stays the number of dots */

@@ -75,6 +75,7 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     if (!c || !name) return fail(VAPOR_E_ARG, "vapor_set_param: null argument");
     if (!strcmp(name, "reads_per_task") || !strcmp(name, "join_tasks") || !strcmp(name, "max_pair_cap"))
         return v >= 1 ? VAPOR_OK : fail(VAPOR_E_ARG, "parameter out of range");
+    if (!strcmp(name, "shared_join")) return VAPOR_OK;
     return fail(VAPOR_E_ARG, std::string("unknown parameter ") + name);
 }
 extern "C" int vapor_set_stream(vapor_ctx* c, void*) { return c ? VAPOR_OK : fail(VAPOR_E_ARG, "null context"); }
@@ -109,6 +110,80 @@ extern "C" int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n, const uint8_t
     for (int32_t i = 0; i < n; ++i)
         if (len[i] > 0 && !seq[i]) return fail(VAPOR_E_ARG, "vapor_seqset_create_ptrs: null sequence");
     return seqset_make(n, [&](int32_t i) { return seq[i]; }, len, flags, info, out);
+}
+// derived sequences (include/vapor_hip.h): materialised here the way the reference builds them - slices, reverse(complementary())
+// of slices (SF:471-478; a character complementary() would drop is refused, as the HIP library refuses it), str.upper()
+extern "C" int vapor_seqset_create_derived(vapor_ctx* ctx, int32_t n, const uint8_t* const* seq, const int32_t* len,
+                                           const uint8_t* flags, int32_t n_derived, const int32_t* seg_first,
+                                           const vapor_segment* segs, const uint8_t* derived_flags, int32_t* info, vapor_seqset** out)
+{
+    if (!ctx || !out || n < 0 || n_derived < 0 || (n && (!seq || !len)) || (n_derived && (!seg_first || !segs)))
+        return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: null argument");
+    for (int32_t i = 0; i < n; ++i)
+        if (len[i] > 0 && !seq[i]) return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: null sequence");
+    std::vector<std::string> text((size_t)n_derived);
+    for (int32_t d = 0; d < n_derived; ++d) {
+        if (seg_first[d + 1] < seg_first[d] || seg_first[d + 1] - seg_first[d] > VAPOR_MAX_SEGMENTS)
+            return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: bad segment count");
+        for (int32_t g = seg_first[d]; g < seg_first[d + 1]; ++g) {
+            const vapor_segment& x = segs[g];
+            if (x.parent < 0 || x.parent >= n || x.off < 0 || x.len < 0 || (int64_t)x.off + x.len > len[x.parent])
+                return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: segment outside its parent");
+            std::string piece(reinterpret_cast<const char*>(seq[x.parent]) + x.off, (size_t)x.len);
+            if (flags && (flags[x.parent] & VAPOR_SEQ_UPPER))
+                for (char& ch : piece) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+            if (x.flags & VAPOR_SEG_REVCOMP) {
+                // (the library looks at the whole parent, not the slice: the same rule here)
+                for (int32_t t = 0; t < len[x.parent]; ++t)
+                    if (!strchr("ATGCNatgcn", seq[x.parent][t]) || seq[x.parent][t] == 0)
+                        return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: a reverse-complemented segment's parent holds characters complementary() drops");
+                std::string r(piece.rbegin(), piece.rend());
+                for (char& ch : r) {
+                    switch (ch) {
+                    case 'A': ch = 'T'; break; case 'T': ch = 'A'; break; case 'C': ch = 'G'; break; case 'G': ch = 'C'; break;
+                    case 'a': ch = 't'; break; case 't': ch = 'a'; break; case 'c': ch = 'g'; break; case 'g': ch = 'c'; break;
+                    default: break;
+                    }
+                }
+                piece = r;
+            }
+            text[(size_t)d] += piece;
+        }
+    }
+    std::vector<const uint8_t*> ptr((size_t)(n + n_derived));
+    std::vector<int32_t> ln((size_t)(n + n_derived));
+    std::vector<uint8_t> fl((size_t)(n + n_derived), 0);
+    for (int32_t i = 0; i < n; ++i) { ptr[(size_t)i] = seq[i]; ln[(size_t)i] = len[i]; fl[(size_t)i] = flags ? flags[i] : 0; }
+    for (int32_t d = 0; d < n_derived; ++d) {
+        ptr[(size_t)(n + d)] = reinterpret_cast<const uint8_t*>(text[(size_t)d].data());
+        ln[(size_t)(n + d)] = (int32_t)text[(size_t)d].size();
+        fl[(size_t)(n + d)] = derived_flags ? derived_flags[d] : 0;
+    }
+    return seqset_make(n + n_derived, [&](int32_t i) { return ptr[(size_t)i]; }, ln.data(), fl.data(), info, out);
+}
+// the planes the HIP library's pack_kernel writes, restated from the text (symbol codes: 0-3 ACGT, 4-7 acgt, 8 N and folded
+// IUPAC, 9 n and folded lower-case IUPAC, 15 anything else; include/vapor_hip.h)
+extern "C" int vapor_seqset_planes(vapor_seqset* s, int32_t seq, uint32_t* p2, uint32_t* e1, uint32_t* x4)
+{
+    if (!s || seq < 0 || (size_t)seq >= s->seq.size()) return fail(VAPOR_E_ARG, "vapor_seqset_planes: no such sequence");
+    const std::string& q = s->seq[(size_t)seq];
+    const size_t ch = (q.size() + 31) / 32;
+    if (p2) memset(p2, 0, ch * 8);
+    if (e1) memset(e1, 0, ch * 4);
+    if (x4) memset(x4, 0, ch * 16);
+    for (size_t t = 0; t < q.size(); ++t) {
+        const unsigned char c = (unsigned char)q[t];
+        const bool lower = c >= 'a' && c <= 'z';
+        const unsigned char u = lower ? (unsigned char)(c - 32) : c;
+        uint32_t code = 15u;
+        if (u == 'A') code = 0; else if (u == 'C') code = 1; else if (u == 'G') code = 2; else if (u == 'T') code = 3;
+        else if (strchr("NRYSWKMBDHV", u) && u) code = 8;
+        if (lower && code != 15u) code = code < 4 ? code + 4 : 9;
+        if (x4) x4[t >> 3] |= code << ((t & 7) * 4);
+        if (p2) p2[t >> 4] |= (code < 8 ? (code & 3u) : 0u) << ((t & 15) * 2);
+        if (e1 && code >= 4) e1[t >> 5] |= 1u << (t & 31);
+    }
+    return VAPOR_OK;
 }
 extern "C" int vapor_seqset_destroy(vapor_seqset* s) { delete s; return VAPOR_OK; }
 
@@ -235,7 +310,7 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
 {
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
-    for (int i = 0; i < n && i < 6; ++i) ms[i] = 0.0;
+    for (int i = 0; i < n && i < 8; ++i) ms[i] = 0.0;
     return VAPOR_OK;
 }
 extern "C" int vapor_plan_record_counts(vapor_plan* p, int64_t* rec)

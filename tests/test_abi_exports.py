@@ -27,7 +27,7 @@ def test_header_functions_are_exported():
 def test_abi_version_and_error_string():
     from vapor_amd import _lib
     lib = _lib.load()
-    assert lib.vapor_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.vapor_abi_version() == _lib.ABI_VERSION == 3
     assert isinstance(lib.vapor_last_error(), bytes)
 
 

@@ -53,6 +53,16 @@ def test_gpu_parity_bodies_on_the_twin(eng, oracle):
     G.test_device_finish_matches_host_finish(eng, "tiny")
 
 
+def test_derived_sequences_on_the_twin(eng, oracle):
+    """The bodies of tests/test_gpu_derived.py on the twin, which builds a derived sequence the way the reference does
+    (slices, reverse(complementary()), str.upper()) and restates pack_kernel's symbol codes: the descriptors of the test
+    cases say what their texts say, plane for plane; and the dot plots against them are the oracle's."""
+    import test_gpu_derived as D
+    D.check_planes(eng)
+    D.test_revcomp_of_a_window_with_iupac_codes_is_refused(eng)
+    assert D.check_shared_joins(eng, oracle, ks=(10, 30), want_shared=False) == 0      # (the twin joins pair by pair)
+
+
 def test_pipeline_and_cli_on_the_twin(eng, tmp_path):
     """`vapor bed` through pipeline.run_batch with the real Engine on the twin: the reference's table."""
     from conftest import load_golden

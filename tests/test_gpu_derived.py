@@ -1,0 +1,225 @@
+"""Derived sequences (vapor_seqset_create_derived) and the shared joins a plan builds on them, on the GPU.
+
+(1) The planes the device assembles from segment descriptors equal the planes of the same text uploaded as bytes - for every
+    way the reference's drivers build an allele from a window it has read: a deletion's ref[:f] + ref[-f:] (SF:1712), a tandem
+    duplication's ref[:f] + mid + mid + ref[-f:] (SF:1755), an inversion's ref[:f] + reverse(complementary(mid)) + ref[-f:]
+    (SF:1907), an insertion's flank + ins_seq + flank (SF:1872), the block structures of DEL_INV / DUP_INV / DISDUP
+    (SF:1557-1665: 'aba^', 'b^ab', 'aa^', 'bab'), the str.upper() twins of abs_dis_m1b (SF:183-184).
+(2) A plan over such a set joins every read ONCE against a window and the alleles derived from it (remap_kernel): dots and
+    statistics of every pair equal the oracle's dotdata(read, allele[miss:]) and those of the same plan with one join per pair.
+
+The bodies take an engine, so tests/test_cpu_twin.py runs them on the CPU twin as well."""
+import numpy as np
+import pytest
+
+from vapor_amd import _lib as L
+from vapor_amd import seqio, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rc(s):
+    return seqio.reverse(seqio.complementary(s))
+
+
+def allele_cases(rng):
+    """[(name, literals, [(segments, upper, expected text)])]: every derived sequence with the text the reference would build."""
+    out = []
+    g = synth.random_dna(rng, 2400)
+    f = 500
+
+    def soft(s, a, b):
+        return s[:a] + s[a:b].lower() + s[b:]
+    for tag, ref in (("plain", g), ("softmasked", soft(soft(g, 300, 420), 1500, 1530)), ("with_N", g[:800] + "N" * 7 + g[807:1900] + "n" * 3 + g[1903:])):
+        n = len(ref)
+        mid = ref[f:n - f]
+        der = [
+            ([(0, 0, f, 0), (0, n - f, f, 0)], False, ref[:f] + ref[-f:]),                                  # DEL
+            ([(0, 0, f, 0), (0, f, n - 2 * f, 0), (0, f, n - 2 * f, 0), (0, n - f, f, 0)], False, ref[:f] + mid + mid + ref[-f:]),   # TANDUP
+            ([(0, 0, n - f, 0), (0, f, n - 2 * f, 0), (0, n - f, f, 0)], False, ref[:n - f] + mid + ref[-f:]),  # the same, first two merged
+            ([(0, 0, f, 0), (0, f, n - 2 * f, 1), (0, n - f, f, 0)], False, ref[:f] + _rc(mid) + ref[-f:]),  # INV
+            ([(0, 0, f, 0), (1, 0, 333, 0), (0, f, n - f, 0)], False, ref[:f] + "%INS%" + ref[f:]),         # INS (payload = literal 1)
+            ([(0, 0, n, 0)], True, ref.upper()),                                                             # upper twin of the window
+            ([(0, 0, f, 0), (0, n - f, f, 0)], True, (ref[:f] + ref[-f:]).upper()),                           # upper twin of the DEL allele
+        ]
+        a, b = ref[f:f + 400], ref[f + 400:f + 900]
+        pre, post = ref[:f], ref[f + 900:f + 900 + f]
+        A, B = (0, f, 400), (0, f + 400, 500)
+        P, Q = (0, 0, f, 0), (0, f + 900, f, 0)
+        der += [
+            ([P, A + (0,), B + (0,), A + (1,), Q], False, pre + a + b + _rc(a) + post),                     # DUP_INV 'aba^'
+            ([P, B + (1,), A + (0,), B + (0,), Q], False, pre + _rc(b) + a + b + post),                     # DUP_INV 'b^ab'
+            ([P, A + (0,), A + (1,), Q], False, pre + a + _rc(a) + post),                                   # DUP_INV 'aa^'
+            ([P, B + (0,), A + (0,), B + (0,), Q], False, pre + b + a + b + post),                          # DISDUP 'bab'
+            ([P, B + (1,), Q], False, pre + _rc(b) + post),                                                  # DEL_INV: a deleted, b inverted
+            ([(0, 0, f, 0), (0, f + 12, n - f - 12, 0)], False, ref[:f] + ref[f + 12:]),                      # a 12 bp deletion (shorter than a run)
+            ([(0, 0, f, 0), (0, f, 7, 0), (0, f, 7, 0), (0, f + 7, n - f - 7, 0)], False, ref[:f] + ref[f:f + 7] * 2 + ref[f + 7:]),   # 7 bp duplication (< k)
+            ([(1, 0, 333, 0)], False, "%INS%"),                                                              # nothing of the window at all
+            ([(0, 5, 9, 0)], False, ref[5:14]),                                                              # shorter than any k
+        ]
+        ins = synth.random_dna(rng, 333)
+        if tag == "with_N":
+            ins = ins[:100] + "NN" + ins[102:]
+        out.append((tag, [ref, ins], [(sg, up, txt.replace("%INS%", ins.upper() if up else ins)) for sg, up, txt in der]))
+    return out
+
+
+def check_planes(eng):
+    rng = np.random.default_rng(808)
+    for tag, lits, der in allele_cases(rng):
+        ss = eng.seqset(lits, derived=[([(p, o, n, bool(rc)) for p, o, n, rc in sg], up) for sg, up, _t in der])
+        ref = eng.seqset(lits + [t for _sg, _u, t in der])
+        try:
+            assert ss.n == ref.n == len(lits) + len(der)
+            assert ss.lens.tolist() == ref.lens.tolist(), tag
+            assert ss.n_exc.tolist() == ref.n_exc.tolist() and ss.n_invalid.tolist() == ref.n_invalid.tolist(), tag
+            for t in range(ss.n):
+                for a, b, what in zip(ss.planes(t), ref.planes(t), ("p2", "e1", "x4")):
+                    assert np.array_equal(a, b), (tag, t, what)
+        finally:
+            ss.close()
+            ref.close()
+
+
+def test_derived_planes_equal_the_planes_of_the_same_text(eng):
+    check_planes(eng)
+
+
+def test_revcomp_of_a_window_with_iupac_codes_is_refused(eng):
+    """complementary() drops what is not ATGCN / atgcn (SF:471-478): a descriptor cannot say that, so the library refuses a
+    reverse-complemented slice of such a window (the caller uploads the allele as bytes) - and takes forward slices of it."""
+    from vapor_amd._lib import VaporHipError
+    w = "ACGTACGTRACGTTTGACCAGGTTAACCAGT" * 3
+    with pytest.raises(VaporHipError) as ei:
+        eng.seqset([w], derived=[([(0, 3, 40, True)], False)])
+    assert ei.value.code == L.E_ARG
+    ss = eng.seqset([w], derived=[([(0, 3, 40, False)], False)])
+    ref = eng.seqset([w[3:43]])
+    assert all(np.array_equal(a, b) for a, b in zip(ss.planes(1), ref.planes(0)))
+    ss.close(); ref.close()
+    for bad in ([(1, 0, 4, False)], [(0, 0, len(w) + 1, False)], [(0, -1, 4, False)]):
+        with pytest.raises(VaporHipError):
+            eng.seqset([w], derived=[(bad, False)])
+
+
+def _plots(eng, ss, pairs):
+    plan = eng.plan(ss, pairs)
+    try:
+        st = plan.run().copy()
+        hits, _f, off = plan.fetch_hits(range(plan.n), want_flags=False)
+        tm = plan.timings()
+    finally:
+        plan.close()
+    dots = []
+    for t in range(len(off) - 1):
+        h = hits[off[t]:off[t + 1]]
+        dots.append(h[np.lexsort((h[:, 1], h[:, 0]))])
+    return st, dots, tm
+
+
+def check_shared_joins(eng, oracle, ks=(10, 20, 30, 40), want_shared=True):
+    rng = np.random.default_rng(909)
+    total_served = 0
+    for tag, lits, der in allele_cases(rng):
+        ref = lits[0]
+        n_lit = len(lits)
+        # reads from the window and from the alleles (PacBio-like errors), one with an N, one with a lower-case stretch
+        reads = []
+        for src in (ref, der[0][2], der[1][2], der[3][2], der[4][2], der[7][2], der[12][2]):
+            r, _ = synth.mutate(rng, src[:1800], 0.01, 0.05, 0.03)
+            reads.append(r)
+        reads.append(reads[1][:300] + "N" + reads[1][301:])
+        reads.append(reads[2][:200] + reads[2][200:260].lower() + reads[2][260:])
+        reads.append(ref[:1500])                                 # a perfect read: long runs
+        seqs = lits + reads
+        first_read = n_lit
+        first_der = n_lit + len(reads)
+        # a group shares the joins of its window and at most three derived alleles: the alleles in threes (every structure
+        # gets its turn), the two upper-cased twins as a group of their own
+        plain = [d for d in range(len(der)) if not der[d][1]]
+        chunks = [plain[a:a + 3] for a in range(0, len(plain), 3)] + [[5, 6]]
+        for k in ks:
+            for ch in chunks:
+                sub = [der[d] for d in ch]
+                derived = [([(p, o, n, bool(rc)) for p, o, n, rc in sg], up) for sg, up, _t in sub]
+                texts = seqs + [t for _sg, _u, t in sub]              # the text of every sequence of the set, by index
+                upper = sub[0][1]
+                rows = []
+                for r in range(len(reads)):
+                    miss = (0, 37, 0, 5)[r % 4]
+                    for a in ([] if upper else [0]) + [first_der + d for d in range(len(sub))]:
+                        rows.append((first_read + r, a, miss, k, L.PF_C1 if upper else (L.PF_C1 | L.PF_C2 | L.PF_DIR)))
+                pairs = eng.make_pairs(rows)
+                ss = eng.seqset(seqs, derived=derived)
+                try:
+                    st, dots, tm = _plots(eng, ss, pairs)
+                    eng.set_param("shared_join", 0)
+                    try:
+                        ss0 = eng.seqset(seqs, derived=derived)
+                        st0, dots0, tm0 = _plots(eng, ss0, pairs)
+                        ss0.close()
+                    finally:
+                        eng.set_param("shared_join", 1)
+                finally:
+                    ss.close()
+                assert tm0["shared_joins"] == 0
+                if want_shared and len(rows) // len(reads) >= 2 and min(len(t) for _s, _u, t in sub) >= k + 40:
+                    assert tm["shared_joins"] > 0 and tm["pairs_served_by_shared_joins"] >= 2 * tm["shared_joins"], (tag, k, ch, tm)
+                total_served += tm["pairs_served_by_shared_joins"]
+                assert np.array_equal(st, st0), (tag, k, ch, np.argwhere(st != st0)[:5])
+                for t, (s1, s2, off2, kk, _fl) in enumerate(rows):
+                    assert np.array_equal(dots[t], dots0[t]), (tag, k, ch, t)
+                    exp = oracle.dotdata_array(kk, texts[s1], texts[s2][off2:])
+                    assert np.array_equal(dots[t], exp.reshape(-1, 2)), (tag, k, ch, t, len(dots[t]), len(exp))
+                    assert st[t, 0] == len(exp)
+    return total_served
+
+
+def test_shared_joins_give_the_dots_of_separate_joins(eng, oracle):
+    assert check_shared_joins(eng, oracle) > 1000
+
+
+def test_shared_joins_through_the_loci_path(eng):
+    """The bench shapes with derived alt windows: per-locus records of run_loci equal those of the same batch with every
+    sequence uploaded as bytes (one join per pair), for DEL / TANDUP / INV / INS - and the plan shares its joins."""
+    from vapor_amd import workload as wl
+    spec = dict(wl.WORKLOADS["tiny"])
+    spec["n_loci"] = 16
+    w = wl.make_workload("tiny", seed=4242, **spec)
+    assert w.derived and w.n_lit < len(w.seqs)
+    recs = []
+    for shared in (True, False):
+        ss = w.upload(eng) if shared else eng.seqset(w.seqs)
+        plan = eng.plan(ss, w.pairs)
+        plan.set_reads(wl.read_table(w), w.n_loci)
+        recs.append((plan.run_loci(want_scores=True).copy(), plan.read_scores.copy(), plan.run().copy(), plan.timings()))
+        # the asynchronous steps give the same records
+        plan.run_loci()
+        plan.run_loci_async(); plan.run_loci_async()
+        again = plan.sync().copy()
+        assert np.array_equal(np.isnan(again), np.isnan(recs[-1][0])) and np.array_equal(again[~np.isnan(again)], recs[-1][0][~np.isnan(recs[-1][0])])
+        plan.close(); ss.close()
+    (a, sa, sta, ta), (b, sb, stb, tb) = recs
+    assert ta["shared_joins"] == len(w.pairs) // 2 and ta["pairs_served_by_shared_joins"] == len(w.pairs) and tb["shared_joins"] == 0
+    assert np.array_equal(sta, stb)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    assert np.array_equal(np.isnan(sa), np.isnan(sb)) and np.array_equal(sa[~np.isnan(sa)], sb[~np.isnan(sb)])
+
+
+def test_shared_join_overflow_is_resized(eng, oracle):
+    """A shared dot plot that outgrows its first slot (a low-complexity window: far more dots than min(n1, n2)) is counted,
+    resized and rerun like any pair; the targets' dots are the oracle's."""
+    unit = "ACGGTCATTG"
+    ref = "TTGACCAGTCCATGGACTAGC" * 10 + unit * 150 + "GGATCCATTGACGTTAGCATC" * 10
+    n = len(ref)
+    alt = ref[:200] + ref[400:]
+    read = (unit * 120)[:1100]
+    ss = eng.seqset([ref, read], derived=[([(0, 0, 200, False), (0, 400, n - 400, False)], False)])
+    pairs = eng.make_pairs([(1, 0, 0, 10, 3), (1, 2, 0, 10, 3)])
+    st, dots, tm = _plots(eng, ss, pairs)
+    ss.close()
+    assert tm["shared_joins"] == 1
+    for t, a in enumerate((ref, alt)):
+        exp = oracle.dotdata_array(10, read, a)
+        assert st[t, 15] == 0 and st[t, 0] == len(exp) and np.array_equal(dots[t], exp.reshape(-1, 2))
+    assert st[0, 0] > 20000

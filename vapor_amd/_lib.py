@@ -20,6 +20,9 @@ SO_PATH = os.environ.get("VAPOR_HIP_LIB") or os.path.join(_HERE, "libvapor_hip.s
 PAIR_DTYPE = np.dtype([("seq1", "<i4"), ("seq2", "<i4"), ("off2", "<i4"), ("k", "<i4"), ("flags", "<u4")])
 READ_DTYPE = np.dtype([("ref_a", "<i4"), ("alt_a", "<i4"), ("ref_b", "<i4"), ("alt_b", "<i4"), ("kind", "<i4"),
                        ("locus", "<i4"), ("len_ref", "<i4"), ("len_alt", "<i4")])
+SEG_DTYPE = np.dtype([("parent", "<i4"), ("off", "<i4"), ("len", "<i4"), ("flags", "<u4")])
+SEG_REVCOMP = 1
+MAX_SEGMENTS = 16
 STATS_STRIDE = 16
 LOCUS_STRIDE = 8
 GT_TABLE_N = 65
@@ -31,12 +34,12 @@ HF_C1_KEPT, HF_C2_DIAG, HF_C2_ANTI = 1, 2, 4
 SEQ_UPPER = 1
 E_HIP, E_OVERFLOW, E_KEYERROR, E_ARG, E_NOMEM = -1, -2, -3, -4, -5
 MAX_SEQ_LEN = 65535
-ABI_VERSION = 2
+ABI_VERSION = 3
 ABI_DEV_OFFSET = 1000000
 
 EXPORTS = [
     "vapor_abi_version", "vapor_build_flags", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
-    "vapor_seqset_create", "vapor_seqset_create_ptrs", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
+    "vapor_seqset_create", "vapor_seqset_create_ptrs", "vapor_seqset_create_derived", "vapor_seqset_planes", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_record_counts", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
     "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync", "vapor_plan_then", "vapor_plan_after",
@@ -134,6 +137,9 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_set_param.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.vapor_seqset_create.argtypes = [vp, ctypes.c_int32, u8p, i64p, i32p, u8p, i32p, ctypes.POINTER(vp)]
     L.vapor_seqset_create_ptrs.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), i32p, u8p, i32p, ctypes.POINTER(vp)]
+    L.vapor_seqset_create_derived.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), i32p, u8p, ctypes.c_int32, i32p, vp, u8p,
+                                              i32p, ctypes.POINTER(vp)]
+    L.vapor_seqset_planes.argtypes = [vp, ctypes.c_int32, vp, vp, vp]
     L.vapor_seqset_destroy.argtypes = [vp]
     L.vapor_plan_create.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.POINTER(vp)]
     L.vapor_plan_destroy.argtypes = [vp]

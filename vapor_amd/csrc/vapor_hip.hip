@@ -91,6 +91,7 @@ struct vapor_ctx {
     int reads_per_task = MAX_READS_PER_TASK;   // upper bound on pairs per join task
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
+    bool shared_join = true;                   // reads scored against a window and alleles derived from it: one join for all
     bool attrs_set = false;
     BlockPool pool;
 };
@@ -140,14 +141,35 @@ static void pool_free(vapor_ctx* c, void* p, bool host)
 static void dfree(vapor_ctx* c, void* p) { pool_free(c, p, false); }
 static void hfree(vapor_ctx* c, void* p) { pool_free(c, p, true); }
 
+// A derived sequence as the caller described it (destination offsets added), and the groups the plan shares joins in.
+struct HSeg { int32_t parent, off, len, dst; bool rc; };
+struct SharePiece {                // a stretch of a member that holds k-mers its parent window does not (for the largest window size)
+    int32_t slot;                  // member slot (1 ..)
+    int32_t a_from, a_to;          // symbols [a_from, a_to) of the member
+    int32_t tile_off;              // where they lie in the shared sequence
+};
+struct ShareGroup {                // a window uploaded as bytes (or its upper-cased twin) and the sequences derived from it
+    int32_t parent = -1;           // the literal sequence
+    bool upper = false;
+    int32_t identity = -1;         // user index of the sequence that IS the window (slot 0), -1: not in the set
+    int32_t t_seq = -1;            // hidden shared sequence: the window followed by the pieces
+    std::vector<int32_t> members;  // user indices of the derived sequences (slot 1 + position), at most 3
+    std::vector<SharePiece> pieces;
+};
+constexpr int SHARE_KMAX = 40;     // the largest window size (pieces carry SHARE_KMAX - 1 symbols of context)
+
 struct vapor_seqset {
     vapor_ctx* ctx = nullptr;
     int device = 0;                // kept here: the set may be destroyed after its context
-    int32_t n = 0;
-    std::vector<SeqDesc> h;        // host copy (with device-computed counts)
+    int32_t n = 0;                 // sequences the caller sees: n_lit given as bytes, then the derived ones
+    int32_t n_lit = 0;
+    std::vector<SeqDesc> h;        // host copy (with device-computed counts); hidden shared sequences behind the caller's
     SeqDesc* d_seqs = nullptr;
     uint32_t *d_p2 = nullptr, *d_e1 = nullptr, *d_x4 = nullptr;
     size_t plane_chunks = 0;
+    std::vector<std::vector<HSeg>> derived;     // per derived sequence (index - n_lit)
+    std::vector<ShareGroup> groups;
+    std::vector<int32_t> group_of, slot_of;     // per caller-visible sequence: its group (-1: none) and slot in it
 };
 
 struct Launch {
@@ -212,6 +234,13 @@ struct vapor_plan {
     bool big_known = false;               // a blocking run has reported how many pairs clean_kernel leaves to clean_big_kernel
     unsigned int n_big = 0;
     double t_finish = 0;
+    // shared joins (remap_kernel): pairs n_pairs .. n_pairs + n_dpairs - 1 of hp are the (read, shared sequence) pairs the
+    // join runs instead of the pairs they serve
+    int64_t n_dpairs = 0, n_served = 0;
+    std::vector<DShare> shares;
+    std::vector<DMap> maps;
+    DShare* d_shares = nullptr;
+    DMap* d_maps = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -312,6 +341,10 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
         c->max_pair_cap = v;
         return VAPOR_OK;
     }
+    if (!strcmp(name, "shared_join")) {
+        c->shared_join = v != 0;
+        return VAPOR_OK;
+    }
     return fail(VAPOR_E_ARG, std::string("unknown parameter ") + name);
 }
 
@@ -329,17 +362,98 @@ extern "C" int vapor_seqset_destroy(vapor_seqset* s)
 }
 
 // Shared by the two entry points: sequence i starts at src(i).
+// The groups a plan shares joins in: every derived sequence goes to the group of the literal that gives it most of its symbols
+// (same upper-casing), a derived sequence that is that literal from end to end (an upper-cased twin) is the group's identity,
+// and the hidden sequence of a group is the window followed by the stretches of its members that hold k-mers the window does
+// not: around every junction of two segments and over every segment that is not a long enough forward or reversed slice of
+// the window itself, with SHARE_KMAX - 1 symbols of context on either side (cut for the largest window size, so that one
+// hidden sequence serves every k; the plan cuts the interval maps for its k).  Returns the hidden sequences' segment lists.
+static void build_share_groups(vapor_seqset* s, const std::vector<uint8_t>& dflags, std::vector<std::vector<HSeg>>* hidden)
+{
+    const int32_t n_lit = s->n_lit, n_der = (int32_t)s->derived.size();
+    s->group_of.assign((size_t)s->n, -1);
+    s->slot_of.assign((size_t)s->n, -1);
+    std::map<std::pair<int32_t, bool>, int32_t> gid;
+    for (int32_t d = 0; d < n_der; ++d) {
+        const auto& sg = s->derived[(size_t)d];
+        const bool up = dflags[(size_t)d] & VAPOR_SEQ_UPPER;
+        // the literal with the largest share of this sequence's symbols (forward or reversed)
+        std::map<int32_t, int64_t> share;
+        for (const HSeg& g : sg) share[g.parent] += g.len;
+        int32_t par = -1; int64_t best = 0;
+        for (auto& kv : share) if (kv.second > best) { best = kv.second; par = kv.first; }
+        if (par < 0) continue;
+        if ((s->h[(size_t)par].flags & VAPOR_SEQ_UPPER) && !up) continue;     // (the literal was upper-cased at upload: not this one's text)
+        auto it = gid.find({par, up});
+        if (it == gid.end()) {
+            it = gid.emplace(std::make_pair(par, up), (int32_t)s->groups.size()).first;
+            ShareGroup g; g.parent = par; g.upper = up;
+            if (!up) { g.identity = par; }
+            s->groups.push_back(g);
+        }
+        ShareGroup& g = s->groups[(size_t)it->second];
+        const bool whole = sg.size() == 1 && sg[0].parent == par && sg[0].off == 0 && sg[0].len == s->h[(size_t)par].len && !sg[0].rc;
+        if (whole && g.identity < 0) { g.identity = n_lit + d; continue; }
+        if (whole && g.identity >= 0 && !up) continue;              // (a plain copy of the literal: nothing to share)
+        if (g.members.size() < 3) g.members.push_back(n_lit + d);
+    }
+    for (size_t q = 0; q < s->groups.size(); ++q) {
+        ShareGroup& g = s->groups[q];
+        if (g.members.empty()) continue;
+        const int32_t n_r = s->h[(size_t)g.parent].len;
+        std::vector<HSeg> t;                                         // the hidden sequence's segments
+        t.push_back(HSeg{g.parent, 0, n_r, 0, false});
+        int64_t t_len = n_r;
+        for (size_t m = 0; m < g.members.size(); ++m) {
+            const auto& sg = s->derived[(size_t)(g.members[m] - n_lit)];
+            const int32_t n_a = s->h[(size_t)g.members[m]].len;
+            // k-mer starts of the member that are k-mers of the window at the largest window size
+            std::vector<std::pair<int32_t, int32_t>> mapped;
+            for (const HSeg& x : sg)
+                if (x.parent == g.parent && x.len >= SHARE_KMAX) mapped.push_back({x.dst, x.dst + x.len - SHARE_KMAX});
+            int32_t u = 0;
+            auto add_piece = [&](int32_t from, int32_t to_start) {       // novel k-mer starts [from, to_start]
+                const int32_t a0 = from, a1 = std::min(n_a, to_start + SHARE_KMAX);
+                if (a1 <= a0) return;
+                g.pieces.push_back(SharePiece{(int32_t)m + 1, a0, a1, (int32_t)t_len});
+                // its symbols as slices of the member's own segments
+                for (const HSeg& x : sg) {
+                    const int32_t lo = std::max(a0, x.dst), hi = std::min(a1, x.dst + x.len);
+                    if (hi <= lo) continue;
+                    HSeg y;
+                    y.parent = x.parent; y.len = hi - lo; y.rc = x.rc; y.dst = (int32_t)t_len + (lo - a0);
+                    y.off = x.rc ? x.off + (x.dst + x.len - hi) : x.off + (lo - x.dst);
+                    t.push_back(y);
+                }
+                t_len += a1 - a0;
+            };
+            for (auto& r : mapped) {                                     // (segments come in order of dst)
+                if (r.first > u) add_piece(u, r.first - 1);
+                u = std::max(u, r.second + 1);
+            }
+            if (u <= n_a - 1) add_piece(u, n_a - 1);
+        }
+        if (t_len > VAPOR_MAX_SEQ_LEN || t_len > (int64_t)2 * n_r + 4096) { g.members.clear(); g.pieces.clear(); continue; }   // not worth sharing
+        g.t_seq = s->n + (int32_t)hidden->size();
+        hidden->push_back(std::move(t));
+        if (g.identity >= 0) { s->group_of[(size_t)g.identity] = (int32_t)q; s->slot_of[(size_t)g.identity] = 0; }
+        for (size_t m = 0; m < g.members.size(); ++m) { s->group_of[(size_t)g.members[m]] = (int32_t)q; s->slot_of[(size_t)g.members[m]] = (int32_t)m + 1; }
+    }
+}
+
 template <typename SRC>
 static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int32_t* len, const uint8_t* flags,
-                              int32_t* seq_info, vapor_seqset** out)
+                              int32_t* seq_info, vapor_seqset** out, int32_t n_derived = 0, const int32_t* seg_first = nullptr,
+                              const vapor_segment* segs = nullptr, const uint8_t* derived_flags = nullptr)
 {
     HIPCHK(hipSetDevice(ctx->device));
     vapor_seqset* s = new (std::nothrow) vapor_seqset();
     if (!s) return fail(VAPOR_E_NOMEM, "out of memory");
     s->ctx = ctx;
     s->device = ctx->device;
-    s->n = n_seqs;
-    s->h.resize((size_t)std::max(n_seqs, 1));
+    s->n = n_seqs + n_derived;
+    s->n_lit = n_seqs;
+    s->h.resize((size_t)std::max(n_seqs + n_derived, 1));
     size_t asc = 0, pl = 0;
     for (int32_t i = 0; i < n_seqs; ++i) {
         if (len[i] < 0) { delete s; return fail(VAPOR_E_ARG, "negative sequence length"); }
@@ -354,6 +468,54 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         pl += ch + VP_PAD_CHUNKS;
         if (pl > 0xFFFFFFF0ull) { delete s; return fail(VAPOR_E_ARG, "sequence set too large"); }
     }
+    // derived sequences (the caller's, then the hidden shared ones): planes behind the literals', assembled by derive_kernel
+    std::vector<std::vector<HSeg>> hidden;
+    std::vector<uint8_t> dfl((size_t)n_derived, 0);
+    size_t der_chunks = 0;
+    if (n_derived > 0) {
+        s->derived.resize((size_t)n_derived);
+        for (int32_t d = 0; d < n_derived; ++d) {
+            const int32_t g0 = seg_first[d], g1 = seg_first[d + 1];
+            if (g1 < g0 || g1 - g0 > VAPOR_MAX_SEGMENTS) { delete s; return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: bad segment count"); }
+            int64_t tot = 0;
+            for (int32_t g = g0; g < g1; ++g) {
+                const vapor_segment& x = segs[g];
+                if (x.parent < 0 || x.parent >= n_seqs || x.off < 0 || x.len < 0 || (int64_t)x.off + x.len > len[x.parent]) {
+                    delete s;
+                    return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: segment outside its parent");
+                }
+                if (x.len == 0) continue;
+                s->derived[(size_t)d].push_back(HSeg{x.parent, x.off, x.len, (int32_t)tot, (x.flags & VAPOR_SEG_REVCOMP) != 0});
+                tot += x.len;
+                if (tot > 0x7FFFFFF0LL) { delete s; return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: sequence too long"); }
+            }
+            dfl[(size_t)d] = derived_flags ? derived_flags[d] : 0;
+            SeqDesc& dd = s->h[(size_t)(n_seqs + d)];
+            memset(&dd, 0, sizeof dd);
+            dd.len = (int32_t)tot;
+            dd.flags = dfl[(size_t)d];
+        }
+        if (ctx->shared_join) build_share_groups(s, dfl, &hidden);
+        s->h.resize((size_t)(n_seqs + n_derived) + hidden.size());
+        for (size_t t = 0; t < hidden.size(); ++t) {
+            SeqDesc& dd = s->h[(size_t)(n_seqs + n_derived) + t];
+            memset(&dd, 0, sizeof dd);
+            int64_t tot = 0;
+            for (const HSeg& x : hidden[t]) tot += x.len;
+            dd.len = (int32_t)tot;
+        }
+        for (const ShareGroup& g : s->groups)
+            if (g.t_seq >= 0 && g.upper) s->h[(size_t)g.t_seq].flags = VAPOR_SEQ_UPPER;
+        for (size_t i = (size_t)n_seqs; i < s->h.size(); ++i) {
+            SeqDesc& dd = s->h[i];
+            const size_t ch = ((size_t)dd.len + 31) / 32;
+            dd.asc0 = (uint32_t)der_chunks;             // (first chunk among the derived sequences' chunks)
+            dd.chunk0 = (uint32_t)pl;
+            der_chunks += ch;
+            pl += ch + VP_PAD_CHUNKS;
+            if (pl > 0xFFFFFFF0ull) { delete s; return fail(VAPOR_E_ARG, "sequence set too large"); }
+        }
+    }
     pl += VP_PAD_CHUNKS + 1;
     s->plane_chunks = pl;
     const size_t n_asc = asc;
@@ -364,8 +526,15 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         if (_e != hipSuccess) { rc = fail(VAPOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); goto done; } \
     } while (0)
     {
-        // staging (ASCII at 32-byte chunks, then the chunk -> sequence map), kept in the context and grown on demand
-        const size_t need = std::max<size_t>(n_asc * 36, 64);
+        // staging (ASCII at 32-byte chunks, then the chunk -> sequence map, then what derive_kernel reads: segment lists, their
+        // offsets, the chunk -> sequence map of the derived sequences), kept in the context and grown on demand
+        const size_t n_dseq = s->h.size() - (size_t)n_seqs;
+        size_t n_seg = 0;
+        for (auto& v : s->derived) n_seg += v.size();
+        for (auto& v : hidden) n_seg += v.size();
+        const size_t der_off = (n_asc * 36 + 63) & ~(size_t)63;
+        const size_t der_bytes = der_chunks ? sizeof(DSeg) * std::max<size_t>(n_seg, 1) + sizeof(int32_t) * (n_dseq + 1) + sizeof(uint32_t) * der_chunks : 0;
+        const size_t need = std::max<size_t>(der_off + der_bytes, 64);
         if (need > ctx->stage_cap) {
             SS_CHK(hipStreamSynchronize(ctx->stream));
             if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -444,10 +613,42 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
                                (uint32_t)n_asc, s->d_p2, s->d_e1, s->d_x4);
             SS_CHK(hipGetLastError());
         }
+        if (der_chunks) {
+            uint8_t* blk = ctx->h_stage + der_off;
+            DSeg* hs = reinterpret_cast<DSeg*>(blk);
+            int32_t* hf = reinterpret_cast<int32_t*>(blk + sizeof(DSeg) * std::max<size_t>(n_seg, 1));
+            uint32_t* hc = reinterpret_cast<uint32_t*>(hf + n_dseq + 1);
+            size_t w = 0;
+            for (size_t t = 0; t < n_dseq; ++t) {
+                const auto& v = t < s->derived.size() ? s->derived[t] : hidden[t - s->derived.size()];
+                hf[t] = (int32_t)w;
+                for (const HSeg& x : v) hs[w++] = DSeg{s->h[(size_t)x.parent].chunk0, x.off, x.len, x.dst, x.rc ? 1u : 0u};
+                const SeqDesc& dd = s->h[(size_t)n_seqs + t];
+                for (size_t c = 0; c < ((size_t)dd.len + 31) / 32; ++c) hc[dd.asc0 + c] = (uint32_t)((size_t)n_seqs + t);
+            }
+            hf[n_dseq] = (int32_t)w;
+            uint8_t* d_blk = ctx->d_stage + der_off;
+            SS_CHK(hipMemcpyAsync(d_blk, blk, der_bytes, hipMemcpyHostToDevice, ctx->stream));
+            const DSeg* dsg = reinterpret_cast<const DSeg*>(d_blk);
+            const int32_t* dsf = reinterpret_cast<const int32_t*>(d_blk + sizeof(DSeg) * std::max<size_t>(n_seg, 1));
+            const uint32_t* dsc = reinterpret_cast<const uint32_t*>(dsf + n_dseq + 1);
+            hipLaunchKernelGGL(derive_kernel, dim3((unsigned)((der_chunks + 255) / 256)), dim3(256), 0, ctx->stream, s->d_seqs, dsc,
+                               (uint32_t)der_chunks, dsf, dsg, n_seqs, s->d_p2, s->d_e1, s->d_x4);
+            SS_CHK(hipGetLastError());
+        }
         SS_CHK(hipMemcpyAsync(s->h.data(), s->d_seqs, sizeof(SeqDesc) * s->h.size(), hipMemcpyDeviceToHost, ctx->stream));
         SS_CHK(hipStreamSynchronize(ctx->stream));
-        if (seq_info)
-            for (int32_t i = 0; i < n_seqs; ++i) {
+        // complementary() drops what is not ATGCN / atgcn (SF:471-478): a reversed slice of a window that holds such a
+        // character is not what the reference would have built
+        for (size_t d = 0; d < s->derived.size() && rc == VAPOR_OK; ++d)
+            for (const HSeg& x : s->derived[d])
+                if (x.rc && s->h[(size_t)x.parent].n_nocomp > 0) {
+                    rc = fail(VAPOR_E_ARG, "vapor_seqset_create_derived: a reverse-complemented segment's parent holds characters complementary() drops "
+                                           "(outside ATGCN/atgcn, SF:471-478); upload that allele as bytes");
+                    break;
+                }
+        if (seq_info && rc == VAPOR_OK)
+            for (int32_t i = 0; i < s->n; ++i) {
                 seq_info[2 * i] = s->h[i].n_exc;
                 seq_info[2 * i + 1] = s->h[i].n_invalid;
             }
@@ -477,6 +678,33 @@ extern "C" int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n_seqs, const ui
     return seqset_create_impl(ctx, n_seqs, [&](int32_t i) { return seq[i]; }, len, flags, seq_info, out);
 }
 
+extern "C" int vapor_seqset_create_derived(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len,
+                                           const uint8_t* flags, int32_t n_derived, const int32_t* seg_first,
+                                           const vapor_segment* segs, const uint8_t* derived_flags, int32_t* seq_info,
+                                           vapor_seqset** out)
+{
+    if (!ctx || !out || n_seqs < 0 || n_derived < 0 || (n_seqs && (!seq || !len)) || (n_derived && (!seg_first || !segs)))
+        return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: null argument");
+    if ((int64_t)n_seqs + n_derived > 0x7FFFFFF0LL) return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: too many sequences");
+    for (int32_t i = 0; i < n_seqs; ++i)
+        if (len[i] > 0 && !seq[i]) return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: null sequence");
+    return seqset_create_impl(ctx, n_seqs, [&](int32_t i) { return seq[i]; }, len, flags, seq_info, out, n_derived, seg_first, segs,
+                              derived_flags);
+}
+
+extern "C" int vapor_seqset_planes(vapor_seqset* s, int32_t seq, uint32_t* p2, uint32_t* e1, uint32_t* x4)
+{
+    if (!s || seq < 0 || seq >= s->n) return fail(VAPOR_E_ARG, "vapor_seqset_planes: no such sequence");
+    HIPCHK(hipSetDevice(s->device));
+    const SeqDesc& d = s->h[(size_t)seq];
+    const size_t ch = ((size_t)d.len + 31) / 32;
+    if (!ch) return VAPOR_OK;
+    if (p2) HIPCHK(hipMemcpy(p2, s->d_p2 + (size_t)d.chunk0 * 2, ch * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (e1) HIPCHK(hipMemcpy(e1, s->d_e1 + (size_t)d.chunk0, ch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (x4) HIPCHK(hipMemcpy(x4, s->d_x4 + (size_t)d.chunk0 * 4, ch * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return VAPOR_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 static void plan_free_device(vapor_plan* p)
 {
@@ -493,6 +721,8 @@ static void plan_free_device(vapor_plan* p)
     p->d_gt = nullptr;
     dfree(p->ctx, p->d_read_scores); p->d_read_scores = nullptr;
     dfree(p->ctx, p->d_loci); p->d_loci = nullptr;
+    dfree(p->ctx, p->d_shares); p->d_shares = nullptr;
+    dfree(p->ctx, p->d_maps); p->d_maps = nullptr;
 }
 
 extern "C" int vapor_plan_destroy(vapor_plan* p)
@@ -597,6 +827,109 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     }
     p->range_words_cap = rw;
     p->hcap_want = (int)std::min<int64_t>(hwant, CLEAN_HCAP_MAX);
+    // Shared joins: a read that is scored against a window AND against alleles derived from it (the usual case: the
+    // reference's dotdata(read, ref) and dotdata(read, alt), SF:185-186) is joined once against the group's hidden sequence -
+    // the window followed by the alleles' own stretches - and remap_kernel cuts that dot plot into the targets'.
+    if (ctx->shared_join && !set->groups.empty() && n_pairs > 0) {
+        struct Cand { int32_t seq1, group, k, slot, pair; };
+        std::vector<Cand> cand;
+        for (int32_t x : order) {
+            const DPair& d = p->hp[(size_t)x];
+            const int32_t g = set->group_of[(size_t)d.seq2];
+            if (g >= 0 && set->groups[(size_t)g].t_seq >= 0) cand.push_back(Cand{d.seq1, g, d.k, set->slot_of[(size_t)d.seq2], x});
+        }
+        std::sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) {
+            if (a.seq1 != b.seq1) return a.seq1 < b.seq1;
+            if (a.group != b.group) return a.group < b.group;
+            if (a.k != b.k) return a.k < b.k;
+            if (a.slot != b.slot) return a.slot < b.slot;
+            return a.pair < b.pair;
+        });
+        std::map<std::pair<int32_t, int32_t>, std::pair<int32_t, int32_t>> maps_of;      // (group, k) -> (first map, maps); n < 0: cannot
+        auto build_maps = [&](int32_t gi, int k) -> std::pair<int32_t, int32_t> {
+            auto it = maps_of.find({gi, k});
+            if (it != maps_of.end()) return it->second;
+            const ShareGroup& g = set->groups[(size_t)gi];
+            const int32_t first = (int32_t)p->maps.size();
+            const int32_t n_r = set->h[(size_t)g.parent].len;
+            bool ok = true;
+            if (n_r >= k) p->maps.push_back(DMap{0, n_r - k, 0, 0, 0});
+            for (size_t m = 0; m < g.members.size() && ok; ++m) {
+                const auto& sg = set->derived[(size_t)(g.members[m] - set->n_lit)];
+                const int32_t n_a = set->h[(size_t)g.members[m]].len;
+                int32_t u = 0;                                   // next k-mer start of the member not yet accounted for
+                auto novel = [&](int32_t from, int32_t to) {     // k-mer starts [from, to] lie in one of the member's own stretches
+                    for (const SharePiece& pc : g.pieces)
+                        if (pc.slot == (int32_t)m + 1 && pc.a_from <= from && to + k <= pc.a_to) {
+                            p->maps.push_back(DMap{pc.tile_off + (from - pc.a_from), pc.tile_off + (to - pc.a_from), from, 0, (uint16_t)(m + 1)});
+                            return;
+                        }
+                    ok = false;
+                };
+                for (const HSeg& x : sg) {
+                    if (x.parent != g.parent || x.len < k) continue;
+                    if (x.dst > u) novel(u, x.dst - 1);
+                    if (!ok) break;
+                    p->maps.push_back(DMap{x.off, x.off + x.len - k, x.rc ? x.dst + x.len - k : x.dst, (uint16_t)(x.rc ? 1 : 0), (uint16_t)(m + 1)});
+                    u = x.dst + x.len - k + 1;
+                }
+                if (ok && u <= n_a - k) novel(u, n_a - k);
+            }
+            std::pair<int32_t, int32_t> res{first, ok ? (int32_t)p->maps.size() - first : -1};
+            if (!ok) p->maps.resize((size_t)first);
+            maps_of[{gi, k}] = res;
+            return res;
+        };
+        auto tiles = [&](int32_t len_a, int k, int m) {
+            const int ta = m != 4 ? tile_pos<JoinCfg, 2>() : tile_pos<JoinCfg, 4>();
+            return std::max(1, (len_a - k + 1 + ta - 1) / ta);
+        };
+        std::vector<uint8_t> served((size_t)n_pairs, 0);
+        for (size_t a = 0; a < cand.size();) {
+            size_t b = a;
+            while (b < cand.size() && cand[b].seq1 == cand[a].seq1 && cand[b].group == cand[a].group && cand[b].k == cand[a].k) ++b;
+            int32_t tgt[4] = {-1, -1, -1, -1};
+            int n_t = 0;
+            for (size_t c = a; c < b; ++c)
+                if (cand[c].slot >= 0 && cand[c].slot < 4 && tgt[cand[c].slot] < 0) { tgt[cand[c].slot] = cand[c].pair; ++n_t; }
+            const Cand c0 = cand[a];
+            a = b;
+            if (n_t < 2) continue;
+            const ShareGroup& g = set->groups[(size_t)c0.group];
+            const SeqDesc& s1 = set->h[(size_t)c0.seq1];
+            const SeqDesc& st = set->h[(size_t)g.t_seq];
+            if (st.len - c0.k + 1 <= 0) continue;
+            const int md = (s1.n_exc > 0 && st.n_exc > 0) ? 4 : (st.n_exc > 0 ? 3 : (s1.n_exc > 0 ? 5 : 2));
+            int sep = 0;
+            for (int t = 0; t < 4; ++t)
+                if (tgt[t] >= 0) sep += tiles(p->hp[(size_t)tgt[t]].len2, c0.k, mode[(size_t)tgt[t]]);
+            if (tiles(st.len, c0.k, md) >= sep) continue;           // (a shared sequence of more tiles than its targets together: no gain)
+            const auto mp = build_maps(c0.group, c0.k);
+            if (mp.second <= 0) continue;
+            DPair d;
+            memset(&d, 0, sizeof d);
+            d.seq1 = c0.seq1; d.seq2 = g.t_seq; d.off2 = 0; d.k = c0.k; d.flags = 0;
+            d.len1 = s1.len; d.len2 = st.len;
+            const int64_t n1 = s1.len, n2 = st.len;
+            d.cap = (uint32_t)std::min<int64_t>(std::min(n1, n2) + ((n1 * n2) >> 17) + 1024, ctx->max_pair_cap);
+            DShare sh;
+            memset(&sh, 0, sizeof sh);
+            sh.dpair = (int32_t)p->hp.size();
+            sh.map_first = mp.first; sh.n_maps = mp.second;
+            for (int t = 0; t < 4; ++t) { sh.target[t] = tgt[t]; if (tgt[t] >= 0) { served[(size_t)tgt[t]] = 1; ++p->n_served; } }
+            p->hp.push_back(d);
+            mode.push_back((uint8_t)md);
+            p->shares.push_back(sh);
+        }
+        p->n_dpairs = (int64_t)p->shares.size();
+        if (p->n_dpairs) {
+            std::vector<int32_t> kept;
+            kept.reserve(order.size());
+            for (int32_t x : order) if (!served[(size_t)x]) kept.push_back(x);
+            for (int64_t t = 0; t < p->n_dpairs; ++t) kept.push_back((int32_t)(n_pairs + t));
+            order.swap(kept);
+        }
+    }
     // Sort by (mode, k, allele): one launch per (mode, k); inside a launch the sorted pair list is
     // cut into contiguous, cost-balanced ranges (tasks).  A workgroup rebuilds its allele hash table
     // only where the allele changes inside its range.
@@ -694,6 +1027,13 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     if (rc == VAPOR_OK) chk(hipMemsetAsync(p->d_overflow, 0, 4 * sizeof(unsigned int), ctx->stream), "memset overflow");
     chk(dmalloc(ctx, (void**)&p->d_big_list, sizeof(int32_t) * p->hp.size()), "hipMalloc big list");
     chk(hmalloc(ctx, (void**)&p->h_overflow, 2 * sizeof(unsigned int)), "hipHostMalloc overflow");
+    if (p->n_dpairs) {
+        chk(dmalloc(ctx, (void**)&p->d_shares, sizeof(DShare) * p->shares.size()), "hipMalloc shares");
+        chk(dmalloc(ctx, (void**)&p->d_maps, sizeof(DMap) * std::max<size_t>(p->maps.size(), 1)), "hipMalloc maps");
+        if (rc == VAPOR_OK) chk(hipMemcpyAsync(p->d_shares, p->shares.data(), sizeof(DShare) * p->shares.size(), hipMemcpyHostToDevice, ctx->stream), "copy shares");
+        if (rc == VAPOR_OK && !p->maps.empty())
+            chk(hipMemcpyAsync(p->d_maps, p->maps.data(), sizeof(DMap) * p->maps.size(), hipMemcpyHostToDevice, ctx->stream), "copy maps");
+    }
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
     chk(hipEventCreate(&p->ev_t0), "hipEventCreate");
@@ -825,6 +1165,11 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
         first = false;
         HIPCHK(hipGetLastError());
     }
+    if (p->n_dpairs) {
+        hipLaunchKernelGGL(remap_kernel, dim3((unsigned)p->n_dpairs), dim3(256), 0, st, (const DPair*)p->d_pairs, (const DShare*)p->d_shares,
+                           (const DMap*)p->d_maps, p->d_hits, p->d_nhits, p->d_overflow);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(ev[1], st));
     // (the clean kernels overwrite the statistics the previous step's finish kernel reads on its own stream)
     if (before_clean) HIPCHK(hipStreamWaitEvent(st, before_clean, 0));
@@ -885,6 +1230,16 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
                 ++grow;
             }
         }
+        if (p->n_dpairs) {
+            // the shared dot plots: their record counts are the low halves of the join's packed counters
+            std::vector<unsigned long long> dc((size_t)p->n_dpairs);
+            HIPCHK(hipMemcpy(dc.data(), p->d_nhits + p->n_pairs, sizeof(unsigned long long) * dc.size(), hipMemcpyDeviceToHost));
+            for (int64_t t = 0; t < p->n_dpairs; ++t) {
+                DPair& d = p->hp[(size_t)(p->n_pairs + t)];
+                const uint32_t need = (uint32_t)dc[(size_t)t];
+                if (need > d.cap && (int64_t)need <= p->ctx->max_pair_cap) { d.cap = need; ++grow; }
+            }
+        }
         if (!grow) break;
         p->n_retried += (int)grow;
         rc = plan_alloc_hits(p);
@@ -907,8 +1262,9 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
 {
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
-    double v[6] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish};
-    for (int i = 0; i < n && i < 6; ++i) ms[i] = v[i];
+    double v[8] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish,
+                   (double)p->n_served, (double)p->n_dpairs};
+    for (int i = 0; i < n && i < 8; ++i) ms[i] = v[i];
     return VAPOR_OK;
 }
 

@@ -40,7 +40,8 @@ struct SeqDesc {       // 32 B
     int32_t n_invalid; // symbols outside invert_base's alphabet (after IUPAC folding)
     uint32_t asc0;     // first 32-byte chunk in the ASCII staging blob (pack only)
     uint32_t flags;
-    uint32_t pad[2];
+    int32_t n_nocomp;  // symbols complementary() would DROP (SF:471-478: anything outside ATGCN / atgcn); bytes only
+    uint32_t pad;
 };
 
 struct DPair {         // 40 B
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ a
     uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     bool upper = sd.flags & 1u;
     uint32_t o2[2] = {0, 0}, oe = 0, o4[4] = {0, 0, 0, 0};
-    int nexc = 0, ninv = 0;
+    int nexc = 0, ninv = 0, nnoc = 0;
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         uint32_t ch = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
@@ -127,8 +128,73 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ a
         o2[t >> 4] |= ((code < 8u) ? (code & 3u) : 0u) << ((t & 15) * 2);
         if (real && code >= 4u) { oe |= 1u << t; ++nexc; }
         if (real && code == 15u) ++ninv;
+        // (an IUPAC code folds to N's symbol for the k-mers, but complementary() keeps an N and drops an R)
+        if (real && code >= 8u && !(ch == 'N' || ch == 'n')) ++nnoc;
     }
     size_t pc = (size_t)sd.chunk0 + local;
+    p2[pc * 2] = o2[0];
+    p2[pc * 2 + 1] = o2[1];
+    e1[pc] = oe;
+    uint4 o;
+    o.x = o4[0]; o.y = o4[1]; o.z = o4[2]; o.w = o4[3];
+    reinterpret_cast<uint4*>(x4)[pc] = o;
+    if (nexc) atomicAdd(&seqs[s].n_exc, nexc);
+    if (ninv) atomicAdd(&seqs[s].n_invalid, ninv);
+    if (nnoc) atomicAdd(&seqs[s].n_nocomp, nnoc);
+}
+
+// ------------------------------------------------------------------------------------------
+// derived sequences: bit planes assembled on the device from slices of sequences that were uploaded as bytes
+// ------------------------------------------------------------------------------------------
+// An allele the reference builds by string surgery on a window it has read - ref[:f] + ref[-f:] (SF:1712), ref[:f] + mid + mid
+// + ref[-f:] (SF:1755), ref[:f] + reverse(complementary(mid)) + ref[-f:] (SF:1907), flank + ins_seq + flank (SF:1872), the
+// str.upper() twins of abs_dis_m1b (SF:183-184) - travels as a list of segments; this kernel writes its three planes from the
+// parents' 4-bit plane (which holds everything: case, N, folded IUPAC, invalid).  One thread per 32-symbol chunk.
+struct DSeg {          // 20 B: dst symbols [dst, dst + len) of the derived sequence = parent[off .. off + len), reversed and
+    uint32_t chunk0;   // complemented when rc; chunk0 = the parent's first plane chunk
+    int32_t off, len, dst;
+    uint32_t rc;
+};
+
+__device__ __forceinline__ uint32_t comp_code(uint32_t c)
+{
+    // invert_base (SF:19-20): A<->T, C<->G in either case; N / n (and what folds to them) and invalid symbols keep their code
+    return c < 8u ? (c ^ 3u) : c;
+}
+
+__global__ __launch_bounds__(256) void derive_kernel(SeqDesc* seqs, const uint32_t* __restrict__ chunk_seq, uint32_t n_chunks,
+                                                    const int32_t* __restrict__ seg_first, const DSeg* __restrict__ segs,
+                                                    int first_derived, uint32_t* __restrict__ p2, uint32_t* __restrict__ e1,
+                                                    uint32_t* __restrict__ x4)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;       // chunk among the derived sequences' chunks
+    if (c >= n_chunks) return;
+    const uint32_t s = chunk_seq[c];                               // sequence index (>= first_derived)
+    const SeqDesc sd = seqs[s];
+    const uint32_t local = c - sd.asc0;                            // (asc0 of a derived sequence: its first chunk in chunk_seq)
+    const int base = (int)local * 32;
+    const int valid = min(32, sd.len - base);
+    const bool upper = sd.flags & 1u;
+    int g = seg_first[s - first_derived];
+    const int g_end = seg_first[s - first_derived + 1];
+    while (g + 1 < g_end && segs[g + 1].dst <= base) ++g;           // the segment that holds symbol `base`
+    DSeg sg = segs[g];
+    uint32_t o2[2] = {0, 0}, oe = 0, o4[4] = {0, 0, 0, 0};
+    int nexc = 0, ninv = 0;
+    for (int t = 0; t < valid; ++t) {
+        const int pos = base + t;
+        while (pos >= sg.dst + sg.len && g + 1 < g_end) sg = segs[++g];
+        const int rel = pos - sg.dst;
+        const uint32_t src = (uint32_t)(sg.rc ? sg.off + sg.len - 1 - rel : sg.off + rel);
+        uint32_t code = (x4[((size_t)sg.chunk0 << 2) + (src >> 3)] >> ((src & 7u) * 4u)) & 15u;
+        if (sg.rc) code = comp_code(code);
+        if (upper) code = (code >= 4u && code < 8u) ? code - 4u : (code == 9u ? 8u : code);
+        o4[t >> 3] |= code << ((t & 7) * 4);
+        o2[t >> 4] |= ((code < 8u) ? (code & 3u) : 0u) << ((t & 15) * 2);
+        if (code >= 4u) { oe |= 1u << t; ++nexc; }
+        if (code == 15u) ++ninv;
+    }
+    const size_t pc = (size_t)sd.chunk0 + local;
     p2[pc * 2] = o2[0];
     p2[pc * 2 + 1] = o2[1];
     e1[pc] = oe;
@@ -2060,6 +2126,97 @@ __global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
         clean_pair<false, CLEAN_PER_MAX>(p, lds, sh, pr, (int)(uint32_t)cnt, (int)(uint32_t)(cnt >> 32), pr.len2,
                           min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap), recs_all, hflags_all, stats,
                           range_words_cap, groups_cap, 0, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// shared joins: one probe per read for a window and the alleles derived from it
+// ------------------------------------------------------------------------------------------
+// The reference fills dotdata(read, ref) and dotdata(read, alt) separately (SF:185-186, 242-243, 278-279), and alt is ref with a
+// stretch removed, doubled, reversed or inserted (SF:1712, 1755, 1907, 1872): nine k-mers in ten are the same on both sides.
+// For such pairs the plan joins the read ONCE against a hidden sequence T = ref followed by the few stretches of the derived
+// alleles that hold k-mers ref does not (junctions, inserted bytes) - join_kernel as it is - and this kernel turns the records
+// of that one dot plot into the records of every target pair: a k-mer start e of T maps to position j of target `slot` through
+// the interval maps of the (window, k) group,
+//     e in [lo, hi]  ->  j = base + (e - lo)          (a forward slice of the window, or a stretch of the allele itself)
+//                        j = base - (e - lo), strands swapped   (a reverse-complemented slice: dotdata searches both strands,
+//                                                                so the k-mer that matched the read's forward strand there
+//                                                                matches its reverse complement here)
+// and a run of dots is cut to the part of it that lies inside an interval (runs are consecutive e AND consecutive i, so the cut
+// part is a run again; a reversed slice turns a same-strand run into a reverse-complement run, which the record format has).
+// K-mer starts of T that belong to no interval (the k-1 positions that straddle two stretches) are dots of nothing and are
+// dropped here.  Every dot of every target is produced exactly once: a k-mer start of an allele lies inside exactly one of its
+// slices or inside exactly one of its own stretches in T.  One workgroup per read.
+struct DMap {          // 16 B
+    int32_t lo, hi;    // k-mer starts of the shared sequence, inclusive
+    int32_t base;      // position in the target at e == lo
+    uint16_t flip;     // 1: reverse-complemented slice (j decreases with e, strands swap)
+    uint16_t slot;     // which target of the share
+};
+struct DShare {        // 32 B
+    int32_t dpair;     // the (read, T) pair the join ran
+    int32_t map_first, n_maps;
+    int32_t target[4]; // pair index per slot, -1: this read has no pair against that allele
+    int32_t pad;
+};
+
+__global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pairs, const DShare* __restrict__ shares,
+                                                   const DMap* __restrict__ maps, unsigned long long* hits,
+                                                   unsigned long long* n_hits, unsigned int* __restrict__ overflow)
+{
+    __shared__ uint32_t c_rec[4], c_dots[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const DShare sh = shares[blockIdx.x];
+    const DPair dp = pairs[sh.dpair];
+    const unsigned long long cnt = n_hits[sh.dpair];
+    uint32_t nrec = (uint32_t)cnt;
+    if (nrec > dp.cap) {
+        // the shared plot outgrew its slot: its count stays in n_hits for the host (a blocking run resizes and reruns; an
+        // asynchronous step reports through the sticky counter), the targets get what fits
+        if (tid == 0) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
+        nrec = dp.cap;
+    }
+    if (tid < 4) { c_rec[tid] = 0u; c_dots[tid] = 0u; }
+    __syncthreads();
+    const unsigned long long* src = hits + dp.hit_off;
+    for (uint32_t h0 = 0; h0 < nrec; h0 += 256) {
+        const uint32_t h = h0 + (uint32_t)tid;
+        const bool have = h < nrec;
+        const unsigned long long r = have ? src[h] : 0ull;
+        const int e0 = VREC_J(r), i0 = VREC_I(r), len = have ? VREC_LEN(r) : 0;
+        const int sd = VREC_RC(r) ? -1 : 1;                       // e(t) = e0 + sd * t, i(t) = i0 + t
+        for (int m = 0; m < sh.n_maps; ++m) {
+            const DMap mp = maps[sh.map_first + m];
+            const int tp = shares[blockIdx.x].target[mp.slot];   // (a scalar load: indexing the register copy would cost a private array)
+            if (tp < 0) continue;                                  // (uniform: the whole workgroup reads the same map)
+            const DPair tg = pairs[tp];
+            // t with lo <= e(t) <= hi
+            int a = sd > 0 ? mp.lo - e0 : e0 - mp.hi, b = sd > 0 ? mp.hi - e0 : e0 - mp.lo;
+            a = max(a, 0); b = min(b, len - 1);
+            // j(t) = jl + dj * (t - a) in the target's full coordinates; only j >= off2 counts (the allele[miss_bp:] slice)
+            const int dj = (mp.flip ? -1 : 1) * sd;
+            int ja = mp.base + (mp.flip ? -1 : 1) * (e0 + sd * a - mp.lo);
+            if (dj > 0) { const int skip = max(0, tg.off2 - ja); a += skip; ja += skip; }
+            else b = min(b, a + (ja - tg.off2));
+            const int n = b - a + 1;
+            const bool emit = have && n > 0;
+            const unsigned long long mask = __ballot(emit);
+            if (!mask) continue;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int dots = wave_sum_i32(emit ? n : 0);
+            uint32_t base = 0;
+            if (lane == 0) { base = atomicAdd(&c_rec[mp.slot], (uint32_t)__popcll(mask)); atomicAdd(&c_dots[mp.slot], (uint32_t)dots); }
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t slot = base + rank;
+            if (emit && slot < tg.cap)
+                hits[tg.hit_off + slot] = (unsigned long long)(uint32_t)(i0 + a) | ((unsigned long long)(uint32_t)(ja - tg.off2) << 16) |
+                                          ((unsigned long long)n << 32) | ((unsigned long long)(dj < 0 ? 1u : 0u) << 48);
+        }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int tp = shares[blockIdx.x].target[tid];
+        if (tp >= 0) n_hits[tp] = (unsigned long long)c_rec[tid] | ((unsigned long long)c_dots[tid] << 32);
     }
 }
 

@@ -37,8 +37,12 @@ class SeqSet:
     """Sequences packed on the device.  `n_exc[s]` = symbols outside upper-case ACGT,
     `n_invalid[s]` = symbols outside invert_base's alphabet after IUPAC folding."""
 
-    def __init__(self, engine: "Engine", seqs: Sequence, upper: Optional[Sequence[bool]] = None):
+    def __init__(self, engine: "Engine", seqs: Sequence, upper: Optional[Sequence[bool]] = None, derived=None):
+        """`derived`: sequences described instead of uploaded (include/vapor_hip.h, vapor_seqset_create_derived) - a list of
+        (segments, upper) with segments = [(parent index into `seqs`, off, len, revcomp), ...]; derived sequence d is index
+        len(seqs) + d of the set.  The device assembles their planes from the parents'."""
         self.engine = engine
+        self.n_lit = len(seqs)
         self.n = len(seqs)
         n1 = max(self.n, 1)
         # One pointer per sequence, no concatenated copy: an ASCII str is handed over as it lies in memory (CPython
@@ -79,17 +83,51 @@ class SeqSet:
         flags = np.zeros(n1, dtype=np.uint8)
         if upper is not None:
             flags[:self.n] = np.asarray(upper, dtype=bool).astype(np.uint8) * L.SEQ_UPPER
-        info = np.zeros(2 * n1, dtype=np.int32)
         h = ctypes.c_void_p()
         lib = L.load()
-        L.check(lib.vapor_seqset_create_ptrs(engine._ctx, self.n, ptrs,
-                                             L.ptr(self.lens if self.n else np.zeros(1, np.int32), ctypes.c_int32),
-                                             L.ptr(flags, ctypes.c_uint8), L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+        lens = self.lens if self.n else np.zeros(1, np.int32)
+        if derived:
+            nd = len(derived)
+            if isinstance(derived, tuple) and len(derived) == 3 and isinstance(derived[0], np.ndarray):
+                seg_first, segs, dflags = derived                      # (already as arrays: pipeline builds them in one go)
+                nd = len(seg_first) - 1
+            else:
+                seg_first = np.zeros(nd + 1, dtype=np.int32)
+                np.cumsum([len(sg) for sg, _u in derived], out=seg_first[1:])
+                segs = np.zeros(max(int(seg_first[-1]), 1), dtype=L.SEG_DTYPE)
+                w = 0
+                for sg, _u in derived:
+                    for par, off, ln, rc in sg:
+                        segs[w] = (par, off, ln, L.SEG_REVCOMP if rc else 0)
+                        w += 1
+                dflags = np.asarray([L.SEQ_UPPER if u else 0 for _sg, u in derived], dtype=np.uint8)
+            info = np.zeros(2 * (self.n + nd), dtype=np.int32)
+            L.check(lib.vapor_seqset_create_derived(engine._ctx, self.n, ptrs, L.ptr(lens, ctypes.c_int32), L.ptr(flags, ctypes.c_uint8),
+                                                    nd, L.ptr(np.ascontiguousarray(seg_first, dtype=np.int32), ctypes.c_int32),
+                                                    np.ascontiguousarray(segs, dtype=L.SEG_DTYPE).ctypes.data_as(ctypes.c_void_p),
+                                                    L.ptr(np.ascontiguousarray(dflags, dtype=np.uint8), ctypes.c_uint8),
+                                                    L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+            dl = np.zeros(nd, dtype=np.int32)
+            np.add.at(dl, np.repeat(np.arange(nd), np.diff(seg_first)), segs["len"][:int(seg_first[-1])])
+            self.lens = np.concatenate([self.lens[:self.n], dl])
+            self.n += nd
+        else:
+            info = np.zeros(2 * n1, dtype=np.int32)
+            L.check(lib.vapor_seqset_create_ptrs(engine._ctx, self.n, ptrs, L.ptr(lens, ctypes.c_int32),
+                                                 L.ptr(flags, ctypes.c_uint8), L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
         del keep
         self._h = h
         engine._live.add(self)
         self.n_exc = info[0::2][:self.n].copy()
         self.n_invalid = info[1::2][:self.n].copy()
+
+    def planes(self, idx: int):
+        """(p2, e1, x4) uint32 arrays of sequence `idx` as they lie in HBM: 2, 1 and 4 words per 32-symbol chunk."""
+        ch = (int(self.lens[idx]) + 31) // 32
+        p2, e1, x4 = np.zeros(2 * ch, np.uint32), np.zeros(ch, np.uint32), np.zeros(4 * ch, np.uint32)
+        L.check(L.load().vapor_seqset_planes(self._h, int(idx), p2.ctypes.data_as(ctypes.c_void_p), e1.ctypes.data_as(ctypes.c_void_p),
+                                             x4.ctypes.data_as(ctypes.c_void_p)))
+        return p2, e1, x4
 
     def close(self) -> None:
         if self._h:
@@ -122,10 +160,10 @@ class Plan:
         return self.stats[:self.n]
 
     def timings(self) -> dict:
-        ms = np.zeros(6, dtype=np.float64)
-        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 6))
+        ms = np.zeros(8, dtype=np.float64)
+        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 8))
         return {"join_ms": ms[0], "clean_ms": ms[1], "total_ms": ms[2], "join_launches": int(ms[3]),
-                "retried_pairs": int(ms[4]), "finish_ms": ms[5]}
+                "retried_pairs": int(ms[4]), "finish_ms": ms[5], "pairs_served_by_shared_joins": int(ms[6]), "shared_joins": int(ms[7])}
 
     def record_counts(self) -> np.ndarray:
         """Run records per pair of the last run (the device stores runs of consecutive dots as one record)."""
@@ -219,8 +257,8 @@ class Engine:
         """Enqueue on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream); 0: the library's own."""
         L.check(L.load().vapor_set_stream(self._ctx, ctypes.c_void_p(hip_stream) if hip_stream else None))
 
-    def seqset(self, seqs: Sequence, upper: Optional[Sequence[bool]] = None) -> SeqSet:
-        return SeqSet(self, seqs, upper)
+    def seqset(self, seqs: Sequence, upper: Optional[Sequence[bool]] = None, derived=None) -> SeqSet:
+        return SeqSet(self, seqs, upper, derived)
 
     def plan(self, seqset: SeqSet, pairs: np.ndarray) -> Plan:
         return Plan(self, seqset, pairs)

@@ -31,12 +31,26 @@ class Workload:
     len_alt: np.ndarray
     n_loci: int
     svtypes: List[str]
+    # The alt windows as the reference's drivers build them - by string surgery on the ref window (SF:1712, 1755, 1907, 1872) -
+    # described instead of uploaded (include/vapor_hip.h, vapor_seqset_create_derived): seqs[:n_lit] travel as bytes,
+    # seqs[n_lit + d] is `derived[d]` = (segments of (parent, off, len, revcomp), upper) and is assembled on the device.
+    # derived = None: every sequence as bytes (the same strings, the same indices).
+    n_lit: int = 0
+    derived: list = None
+
+    def upload(self, eng):
+        """The batch's sequence set on `eng`."""
+        if self.derived:
+            return eng.seqset(self.seqs[:self.n_lit], derived=self.derived)
+        return eng.seqset(self.seqs)
 
 
 def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], read_len: int, allele_len: int,
-                  reads_per_locus: int, k: int = 10) -> Workload:
+                  reads_per_locus: int, k: int = 10, derived: bool = True) -> Workload:
     rng = np.random.default_rng(seed)
-    seqs: List[str] = []
+    seqs: List[str] = []             # in creation order; ("alt", n) entries are moved behind the literals below
+    is_alt: List[bool] = []
+    segs_of = {}
     rows = []
     read_locus, read_kind, len_ref, len_alt, types = [], [], [], [], []
     for li in range(n_loci):
@@ -45,16 +59,26 @@ def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], rea
         ref = synth.random_dna(rng, allele_len)
         span = int(rng.integers(300, 3000))
         s = int(rng.integers(allele_len // 4, allele_len // 2))
+        ri = len(seqs)
+        seqs.append(ref); is_alt.append(False)
         if t == "DEL":
             alt = ref[:s] + ref[s + span:]
+            sg = [(ri, 0, s, False), (ri, s + span, allele_len - s - span, False)]
         elif t == "TANDUP":
             alt = ref[:s + span] + ref[s:s + span] + ref[s + span:]
+            sg = [(ri, 0, s + span, False), (ri, s, span, False), (ri, s + span, allele_len - s - span, False)]
         elif t == "INV":
             alt = ref[:s] + synth.revcomp(ref[s:s + span]) + ref[s + span:]
+            sg = [(ri, 0, s, False), (ri, s, span, True), (ri, s + span, allele_len - s - span, False)]
         else:
-            alt = ref[:s] + synth.random_dna(rng, span) + ref[s:]
-        ri, ai = len(seqs), len(seqs) + 1
-        seqs += [ref, alt]
+            ins = synth.random_dna(rng, span)
+            alt = ref[:s] + ins + ref[s:]
+            xi = len(seqs)
+            seqs.append(ins); is_alt.append(False)          # (the inserted bytes are a sequence of their own, as ins_seq is, SF:1856)
+            sg = [(ri, 0, s, False), (xi, 0, span, False), (ri, s, allele_len - s, False)]
+        ai = len(seqs)
+        seqs.append(alt); is_alt.append(True)
+        segs_of[ai] = sg
         kind = {"DEL": 0, "TANDUP": 3}.get(t, 1)
         for _ in range(reads_per_locus):
             hap = alt if rng.random() < 0.5 else ref
@@ -62,7 +86,7 @@ def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], rea
             hi = max(lo, min(s - 200, len(hap) - read_len))
             st = int(rng.integers(lo, hi + 1))
             rd, _c = synth.mutate(rng, hap[st:st + read_len + read_len // 8], cigar=False)
-            seqs.append(rd[:read_len])
+            seqs.append(rd[:read_len]); is_alt.append(False)
             q = len(seqs) - 1
             rows.append((q, ri, 0, k, SCORER_FLAGS[t]))
             rows.append((q, ai, 0, k, SCORER_FLAGS[t]))
@@ -75,8 +99,21 @@ def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], rea
     for c, name in enumerate(("seq1", "seq2", "off2", "k", "flags")):
         pa[name] = pairs[:, c]
     pairs = pa
+    n_lit, der = len(seqs), None
+    if derived:
+        # literals first (their order kept), the alt windows behind them as derived sequences
+        lit = [t for t in range(len(seqs)) if not is_alt[t]]
+        alts = [t for t in range(len(seqs)) if is_alt[t]]
+        new = np.empty(len(seqs), dtype=np.int64)
+        new[lit] = np.arange(len(lit))
+        new[alts] = len(lit) + np.arange(len(alts))
+        der = [([(int(new[p]), o, n, rc) for p, o, n, rc in segs_of[t]], False) for t in alts]
+        seqs = [seqs[t] for t in lit] + [seqs[t] for t in alts]
+        pairs["seq1"] = new[pairs["seq1"]]
+        pairs["seq2"] = new[pairs["seq2"]]
+        n_lit = len(lit)
     return Workload(name, seqs, pairs, np.asarray(read_locus), np.asarray(read_kind), np.asarray(len_ref),
-                    np.asarray(len_alt), n_loci, types)
+                    np.asarray(len_alt), n_loci, types, n_lit, der)
 
 
 WORKLOADS = {
