@@ -10,10 +10,22 @@ from vapor_amd import _lib as L
 _VALID = set("ACGTNRYSWKMBDHVacgtnryswkmbdhv")       # what pack_kernel's sym_code accepts (IUPAC folds to N, SF:908-949)
 
 
+def _materialise(seqs, derived):
+    """Derived sequences (vapor_amd.engine.SeqSet's `derived`: [(segments of (parent, off, len, revcomp), upper)]) as text, built
+    the way the reference builds them: slices, reverse(complementary()) of slices (SF:471-478), str.upper()."""
+    from vapor_amd import seqio
+    out = []
+    for segs, up in derived or ():
+        t = "".join(seqio.reverse(seqio.complementary(seqs[p][o:o + n])) if rc else seqs[p][o:o + n] for p, o, n, rc in segs)
+        out.append(t.upper() if up else t)
+    return out
+
+
 class _SeqSet:
-    def __init__(self, seqs, upper):
-        self.seqs = [s.upper() if u else s for s, u in zip(seqs, upper)]
-        self.n = len(seqs)
+    def __init__(self, seqs, upper, derived=None):
+        self.seqs = [s.upper() if u else s for s, u in zip(seqs, upper)] + _materialise(seqs, derived)
+        self.n = len(self.seqs)
+        self.n_derived = len(derived or ())
         self.lens = np.array([len(s) for s in self.seqs], dtype=np.int32)
         self.n_invalid = np.array([sum(1 for ch in set(s) if ch not in _VALID) for s in self.seqs], dtype=np.int32)
 
@@ -101,8 +113,9 @@ class FakeEngine:
         self.orc = orc
         self.batches = []        # (n_seqs, n_pairs) per plan, for batching assertions
 
-    def seqset(self, seqs, upper=None):
-        return _SeqSet(list(seqs), list(upper) if upper is not None else [False] * len(seqs))
+    def seqset(self, seqs, upper=None, derived=None):
+        self.derived_seen = getattr(self, "derived_seen", 0) + len(derived or ())
+        return _SeqSet(list(seqs), list(upper) if upper is not None else [False] * len(seqs), derived)
 
     def plan(self, ss, pairs):
         self.batches.append((ss.n, len(pairs)))

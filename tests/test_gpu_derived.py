@@ -18,6 +18,14 @@ from vapor_amd import seqio, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def eng():
+    from vapor_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
 def _rc(s):
     return seqio.reverse(seqio.complementary(s))
 

@@ -19,9 +19,10 @@ from vapor_amd.finish import result_organize_ins
 
 
 class _SS:
-    def __init__(self, seqs):
-        self.n = len(seqs)
-        self.lens = np.fromiter(map(len, seqs), dtype=np.int32, count=self.n)
+    def __init__(self, seqs, derived=None):
+        self.n = len(seqs) + len(derived or ())
+        self.lens = np.concatenate([np.fromiter(map(len, seqs), dtype=np.int32, count=len(seqs)),
+                                    np.asarray([sum(g[2] for g in sg) for sg, _u in (derived or ())], dtype=np.int32)])
         self.n_invalid = np.zeros(self.n, dtype=np.int32)
         self.n_exc = np.zeros(self.n, dtype=np.int32)
 
@@ -49,8 +50,8 @@ class _Plan:
 
 
 class NullEngine:
-    def seqset(self, seqs, upper=None):
-        return _SS(seqs)
+    def seqset(self, seqs, upper=None, derived=None):
+        return _SS(seqs, derived)
 
     def plan(self, ss, pairs):
         return _Plan(ss, pairs)

@@ -83,6 +83,59 @@ def _rc(seq: str) -> str:
     return seqio.reverse(seqio.complementary(seq))
 
 
+class Allele(str):
+    """An allele string that remembers how the driver built it: `segs` = [(parent string, off, len, revcomp), ...] - slices of
+    windows the driver has read (and of an insertion's sequence), in order.  It IS the string (every consumer that wants
+    text - figures, the window check, the reference-named functions - sees a str); the executors hand the segments to the
+    library instead of the bytes (include/vapor_hip.h, vapor_seqset_create_derived): the device assembles the allele from
+    the window it already has, and a read is joined once against the window and the alleles derived from it.
+    `segs` is None when the text is not a concatenation of slices (complementary() drops characters outside ATGCN / atgcn,
+    SF:471-478: a reversed slice that lost one is uploaded as bytes)."""
+    segs = None
+
+
+def _cat(*parts) -> Allele:
+    """''.join of the parts, each (s, a, b) = s[a:b] or (s, a, b, True) = reverse(complementary(s[a:b])) with Python's slice
+    rules (negative and None bounds), as an Allele that knows its segments."""
+    text, segs = [], []
+    for part in parts:
+        src, a, b = part[0], part[1], part[2]
+        i0, i1, _ = slice(a, b).indices(len(src))
+        n = max(0, i1 - i0)
+        piece = src[i0:i1]
+        rc = len(part) > 3 and part[3]
+        if rc:
+            piece = _rc(piece)
+            if len(piece) != n:
+                segs = None                 # complementary() dropped something: not a slice of anything any more
+        text.append(piece)
+        if segs is not None and n:
+            base = getattr(src, "segs", None)
+            if base is not None and not rc and len(base) == 1 and not base[0][3]:
+                segs.append((base[0][0], base[0][1] + i0, n, False))      # (a slice of a one-slice allele: of its parent)
+            elif type(src) is str:
+                segs.append((src, i0, n, rc))
+            else:
+                segs = None
+    out = Allele("".join(text))
+    out.segs = segs
+    return out
+
+
+def _within(window: str, w0: int, piece: str, a: int):
+    """The _cat part for `piece` = the reference from coordinate `a` on, given a window that starts at coordinate `w0`: a
+    slice of the window where the window really holds those bases (the usual case: the drivers fetch a block's bases again
+    although they lie inside the window they already hold, e.g. SF:1809-1813), else the piece as text of its own."""
+    off = a - w0
+    if off >= 0 and len(piece) and window[off:off + len(piece)] == piece:
+        return (window, off, off + len(piece))
+    return (piece, None, None)
+
+
+def _rcpart(part):
+    return (part[0], part[1], part[2], True)
+
+
 # ------------------------------------------------------------------------------------------
 def vapor_simple_del(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
     """vapor_simple_del_Vapor, SF:1701-1745."""
@@ -94,7 +147,7 @@ def vapor_simple_del(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_nam
             ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[2] + flank)
             k = yield from _window(ref_seq)
             if not k == "Error":
-                alt_seq = ref_seq[:flank] + ref_seq[-flank:]
+                alt_seq = _cat((ref_seq, None, flank), (ref_seq, -flank, None))      # ref_seq[:flank] + ref_seq[-flank:], SF:1712
                 res = yield Score("del", ref_seq, alt_seq, reads, k)     # min of the two scorers' scores, SF:1718-1726
                 best = _collect(res, reads, scores)
                 yield Figure(scores, best, k, ref_seq, alt_seq, out_figure_name)
@@ -104,8 +157,9 @@ def vapor_simple_del(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_nam
             ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1] + flank)
             k = yield from _window(ref_seq)
             if not k == "Error":
-                alt_seq = (seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1])
-                           + seqio.ref_seq_readin(ref, sv_info[0], sv_info[2], sv_info[2] + flank))
+                left = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1])
+                alt_seq = _cat(_within(ref_seq, sv_info[1] - flank, left, sv_info[1] - flank),
+                               (seqio.ref_seq_readin(ref, sv_info[0], sv_info[2], sv_info[2] + flank), None, None))
                 k = yield from _window(alt_seq)
                 if not k == "Error":
                     res = yield Score("s2", ref_seq, alt_seq, reads, k)
@@ -122,7 +176,8 @@ def vapor_simple_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_nam
         ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[2] + flank)
         k = yield from _window(ref_seq)
         if not k == "Error":
-            alt_seq = ref_seq[:flank] + _rc(ref_seq[flank:(-flank)]) + ref_seq[-flank:]
+            # ref_seq[:flank] + reverse(complementary(ref_seq[flank:-flank])) + ref_seq[-flank:], SF:1907
+            alt_seq = _cat((ref_seq, None, flank), (ref_seq, flank, -flank, True), (ref_seq, -flank, None))
             k = yield from _window(alt_seq)
             if not k == "Error":
                 reads = seqio.simple_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
@@ -134,7 +189,7 @@ def vapor_simple_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_nam
     ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[1] + flank)
     k = yield from _window(ref_seq)
     if not k == "Error":
-        alt_seq = ref_seq[:flank] + seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2], "TRUE")
+        alt_seq = _cat((ref_seq, None, flank), (seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2], "TRUE"), None, None))
         k = yield from _window(alt_seq)
         if not k == "Error":
             reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info, flank)
@@ -153,8 +208,8 @@ def vapor_simple_tandup(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_
         ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[1] - flank, sv_info[2] + flank)
         k = yield from _window(ref_seq)
         if not k == "Error":
-            mid = ref_seq[flank:(-flank)]
-            alt_seq = ref_seq[:flank] + mid + mid + ref_seq[-flank:]
+            # ref_seq[:flank] + mid + mid + ref_seq[-flank:] with mid = ref_seq[flank:-flank], SF:1755
+            alt_seq = _cat((ref_seq, None, flank), (ref_seq, flank, -flank), (ref_seq, flank, -flank), (ref_seq, -flank, None))
             k = yield from _window(alt_seq)
             if not k == "Error":
                 reads = seqio.simple_chop_pacbio_read_simple_short(
@@ -167,8 +222,9 @@ def vapor_simple_tandup(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_
     ref_seq = seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2] + flank)
     k = yield from _window(ref_seq)
     if not k == "Error":
-        alt_seq = (seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2])
-                   + seqio.ref_seq_readin(ref, sv_info[0], sv_info[1], sv_info[1] + flank))
+        left = seqio.ref_seq_readin(ref, sv_info[0], sv_info[2] - flank, sv_info[2])
+        alt_seq = _cat(_within(ref_seq, sv_info[2] - flank, left, sv_info[2] - flank),
+                       (seqio.ref_seq_readin(ref, sv_info[0], sv_info[1], sv_info[1] + flank), None, None))
         k = yield from _window(alt_seq)
         if not k == "Error":
             reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, [sv_info[0], sv_info[2]], flank)
@@ -201,8 +257,10 @@ def vapor_simple_ins(num_reads_cff, plt_li, bam_in, ref, ins_pos, ins_seq, out_f
             ref_seq = seqio.ref_seq_readin(ref, chrom, pos - flank, pos + flank)
             k = yield from _window(ref_seq)
         if not k == "Error":
-            alt_seq = (seqio.ref_seq_readin(ref, chrom, pos - flank, pos) + ins_seq_2
-                       + seqio.ref_seq_readin(ref, chrom, pos, pos + flank))
+            # flank + ins_seq + flank, SF:1872 (both flanks lie inside the window just read)
+            alt_seq = _cat(_within(ref_seq, pos - flank, seqio.ref_seq_readin(ref, chrom, pos - flank, pos), pos - flank),
+                           (ins_seq_2, None, None),
+                           _within(ref_seq, pos - flank, seqio.ref_seq_readin(ref, chrom, pos, pos + flank), pos))
 
             def few_n(x):                                   # SF:1878
                 return float(x[0].count("N") + x[0].count("n")) / float(len(x[0])) < 0.1
@@ -241,12 +299,14 @@ def vapor_simple_disdup(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_
                     structure = ["b", "a", "b"]
                 else:
                     raise UnboundLocalError("alt_structure")  # SF:1803-1804: insert point inside the block
-                alt_seq = seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, min(bp))
-                a_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[0], bp[1])
-                b_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[1], bp[2])
+                w0 = min(bp) - flank                   # (every block lies inside the window just read: slices of it)
+                parts = [_within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, min(bp)), w0)]
+                a_seq = _within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], bp[0], bp[1]), bp[0])
+                b_seq = _within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], bp[1], bp[2]), bp[1])
                 for x in structure:
-                    alt_seq += a_seq if x == "a" else b_seq
-                alt_seq += seqio.ref_seq_readin(ref, sv_info[0], max(bp), max(bp) + flank)
+                    parts.append(a_seq if x == "a" else b_seq)
+                parts.append(_within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], max(bp), max(bp) + flank), max(bp)))
+                alt_seq = _cat(*parts)
                 k = yield from _window(alt_seq)
                 if not k == "Error":
                     res = yield Score("s3", ref_seq, alt_seq, reads, k)
@@ -260,10 +320,10 @@ def vapor_simple_disdup(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_
             k = yield from _window(ref_seq)
             if not k == "Error":
                 if short:
-                    alt_seq = (ref_seq[:flank] + seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[2])
-                               + ref_seq[-flank:])
+                    alt_seq = _cat((ref_seq, None, flank), (seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[2]), None, None),
+                                   (ref_seq, -flank, None))
                 else:
-                    alt_seq = ref_seq[:flank] + seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[1] + flank)
+                    alt_seq = _cat((ref_seq, None, flank), (seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[1] + flank), None, None))
                 k = yield from _window(alt_seq)
                 if not k == "Error":
                     res = yield Score("s1" if short else "s2", ref_seq, alt_seq, reads, k)
@@ -296,12 +356,14 @@ def vapor_dup_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
                 reads = seqio.simple_chop_pacbio_read_simple_short(
                     bam_in, [sv_info[0]] + bp + [bp[-1] + sv_info[2] - sv_info[1]], flank)
                 if len(reads) > num_reads_cff:
-                    alt_seq = seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, min(bp))
-                    a_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[0], bp[1])
-                    b_seq = seqio.ref_seq_readin(ref, sv_info[0], bp[1], bp[2])
+                    w0 = min(bp) - flank
+                    parts = [_within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], min(bp) - flank, min(bp)), w0)]
+                    a_seq = _within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], bp[0], bp[1]), bp[0])
+                    b_seq = _within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], bp[1], bp[2]), bp[1])
                     for x in structure:
-                        alt_seq += {"a": a_seq, "a^": _rc(a_seq), "b": b_seq, "b^": _rc(b_seq)}[x]
-                    alt_seq += seqio.ref_seq_readin(ref, sv_info[0], max(bp), max(bp) + flank)
+                        parts.append({"a": a_seq, "a^": _rcpart(a_seq), "b": b_seq, "b^": _rcpart(b_seq)}[x])
+                    parts.append(_within(ref_seq, w0, seqio.ref_seq_readin(ref, sv_info[0], max(bp), max(bp) + flank), max(bp)))
+                    alt_seq = _cat(*parts)
                     k = yield from _window(alt_seq)
                     if not k == "Error":
                         res = yield Score("s3", ref_seq, alt_seq, reads, k)
@@ -315,10 +377,11 @@ def vapor_dup_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
                 reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, ins_point, flank)
                 if len(reads) > num_reads_cff:
                     if short:
-                        alt_seq = (ref_seq[:flank] + _rc(seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[2]))
-                                   + ref_seq[-flank:])
+                        alt_seq = _cat((ref_seq, None, flank), (seqio.ref_seq_readin(ref, dup_block[0], dup_block[1], dup_block[2]), None, None, True),
+                                       (ref_seq, -flank, None))
                     else:
-                        alt_seq = ref_seq[:flank] + _rc(seqio.ref_seq_readin(ref, dup_block[0], dup_block[2] - flank, dup_block[2]))
+                        alt_seq = _cat((ref_seq, None, flank),
+                                       (seqio.ref_seq_readin(ref, dup_block[0], dup_block[2] - flank, dup_block[2]), None, None, True))
                     k = yield from _window(alt_seq)
                     if not k == "Error":
                         res = yield Score("s1" if short else "s2", ref_seq, alt_seq, reads, k)
@@ -334,7 +397,7 @@ def vapor_long_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_n
     ref_seq = seqio.ref_seq_readin(ref, sv_info[0][0], sv_info[0][1] - flank, sv_info[1][1] + flank)
     k = yield from _window(ref_seq)
     if not k == "Error":
-        alt_seq = ref_seq[:flank] + _rc(seqio.ref_seq_readin(ref, sv_info[1][0], sv_info[1][2] - flank, sv_info[1][2]))
+        alt_seq = _cat((ref_seq, None, flank), (seqio.ref_seq_readin(ref, sv_info[1][0], sv_info[1][2] - flank, sv_info[1][2]), None, None, True))
         k = yield from _window(alt_seq)
         if not k == "Error":
             reads = seqio.simple_del_chop_pacbio_read_simple_short(bam_in, sv_info[0], flank)
@@ -355,13 +418,14 @@ def vapor_del_inv(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figure_name):
             ref_seq = seqio.ref_seq_readin(ref, sv_block[0], sv_block[1] - flank, sv_block[2] + flank)
             k = yield from _window(ref_seq)
             if not k == "Error":
-                alt_seq = ref_seq[:flank]
+                parts = [(ref_seq, None, flank)]
                 for x in sv_info:
                     if x[-1] == "del":
                         continue
                     elif x[-1] == "inv":
-                        alt_seq += _rc(seqio.ref_seq_readin(ref, x[0], x[1], x[2]))
-                alt_seq += ref_seq[-flank:]
+                        parts.append(_rcpart(_within(ref_seq, sv_block[1] - flank, seqio.ref_seq_readin(ref, x[0], x[1], x[2]), x[1])))
+                parts.append((ref_seq, -flank, None))
+                alt_seq = _cat(*parts)
                 k = yield from _window(alt_seq)
                 if not k == "Error":
                     reads = seqio.simple_chop_pacbio_read_simple_short(
@@ -477,10 +541,12 @@ def vapor_cannot_classify(num_reads_cff, plt_li, bam_in, ref, sv_info, out_figur
                     for i in list(let_hash.keys()):
                         let_seq[i] = seqio.ref_seq_readin(ref, let_hash[i][0], int(let_hash[i][1]), int(let_hash[i][-1]))
                     for alt_allele in alt_sv:
-                        alt_seq = ref_seq[:flank]
+                        parts = [(ref_seq, None, flank)]
                         for i in letter_split(alt_allele):
-                            alt_seq += let_seq[i] if '^' not in i else _rc(let_seq[i[0]])
-                        alt_seq += ref_seq[-flank:]
+                            blk = _within(ref_seq, b0[1] - flank, let_seq[i[0]], int(let_hash[i[0]][1]))
+                            parts.append(blk if '^' not in i else _rcpart(blk))
+                        parts.append((ref_seq, -flank, None))
+                        alt_seq = _cat(*parts)
                         k = yield from _window(alt_seq)
                         if not k == "Error":
                             repeated = max([alt_allele.count(i) for i in alt_allele] + [0]) > 1

@@ -234,11 +234,43 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
 
     One sequence set and one plan for all requests: request t is "locus" t of the plan, its reads are the plan's
     reads in order.  The arrays are put together with numpy per request, not per read."""
-    seqs: List[str] = []
-    upper: List[bool] = []
+    seqs: List[str] = []              # sequences that travel as bytes: windows, insertion payloads, reads
+    derived: List[tuple] = []         # sequences described instead (drivers.Allele.segs; the str.upper() twins of abs_dis_m1b): (segments, upper)
+    lit_of: Dict[int, int] = {}       # id(string) -> its index among the literals (a window is uploaded once per batch)
+    nocomp_of: Dict[int, bool] = {}
+
+    def lit(sq: str) -> int:
+        q = lit_of.get(id(sq))
+        if q is None:
+            q = lit_of[id(sq)] = len(seqs)
+            seqs.append(sq)
+        return q
+
+    def describe(sq, up: bool) -> int:
+        """Index of `sq` (upper-cased when `up`) in the set: a literal, or - (d + 1) for derived sequence d (their place behind
+        the literals is known when all literals are)."""
+        segs = getattr(sq, "segs", None)
+        if segs is not None and segs:
+            # (a reversed slice needs a parent complementary() keeps whole, SF:471-478: the library checks the same)
+            for par, _o, _n, rc in segs:
+                if rc:
+                    bad = nocomp_of.get(id(par))
+                    if bad is None:
+                        bad = nocomp_of[id(par)] = _NOCOMP.search(par) is not None
+                    if bad:
+                        segs = None
+                        break
+        if segs:
+            derived.append(([(lit(par), o, n, rc) for par, o, n, rc in segs], up))
+            return -len(derived)
+        if up:
+            derived.append(([(lit(sq), 0, len(sq), False)], True))
+            return -len(derived)
+        return lit(sq)
+
     # per request: scalars only; the per-read and per-pair columns are expanded from them in one go below
     rq_n, rq_k, rq_kind, rq_lref, rq_lalt, rq_blk_a, rq_blk_b = [], [], [], [], [], [], []
-    bl_rq, bl_allele, bl_flags = [], [], []                  # blocks of pairs: (request, first allele sequence, pair flags)
+    bl_rq, bl_ref, bl_alt, bl_flags = [], [], [], []         # blocks of pairs: (request, its two allele sequences, pair flags)
     miss: List[int] = []
     first_read, read_seq_first = [], []
     n_reads_tot = 0
@@ -249,29 +281,25 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
             read_seq_first.append(len(seqs))
             continue
         # allele sequences of this request: as given, and (abs_dis_m1b, SF:183-184) upper-cased where that differs
-        ri = len(seqs)
-        seqs += [r.ref_seq, r.alt_seq]
-        upper += [False, False]
+        ri, ai = describe(r.ref_seq, False), describe(r.alt_seq, False)
         if r.kind in ("del", "s1") and not (_is_upper(r.ref_seq) and _is_upper(r.alt_seq)):
-            ui = len(seqs)
-            seqs += [r.ref_seq, r.alt_seq]
-            upper += [True, True]
+            uri, uai = describe(r.ref_seq, True), describe(r.alt_seq, True)
         else:
-            ui = ri
+            uri, uai = ri, ai
         read_seq_first.append(len(seqs))
-        seqs += [x[0] for x in r.reads]
-        upper += [False] * n
+        seqs += [x[0] for x in r.reads]                      # (reads are never shared between requests: no look-up)
         miss += [int(x[1]) for x in r.reads]
         k = len(rq_n)
-        if r.kind == "del" and ui != ri:
+        if r.kind == "del" and uri != ri:
             blk_a = len(bl_rq)
-            bl_rq += [k, k]; bl_allele += [ui, ri]; bl_flags += [L.PF_C1, L.PF_C2]
+            bl_rq += [k, k]; bl_ref += [uri, ri]; bl_alt += [uai, ai]; bl_flags += [L.PF_C1, L.PF_C2]
             blk_b = blk_a + 1
         else:
             # (a deletion whose alleles are upper case already: one fill serves both scorers)
             blk_a = blk_b = len(bl_rq)
             bl_rq.append(k)
-            bl_allele.append(ri if r.kind in ("del", "s2", "s3") else ui)
+            plain = r.kind in ("del", "s2", "s3")
+            bl_ref.append(ri if plain else uri); bl_alt.append(ai if plain else uai)
             bl_flags.append(L.PF_C1 | L.PF_C2 if r.kind == "del" else _FLAGS[r.kind])
         rq_n.append(n); rq_k.append(int(r.k)); rq_kind.append(_KIND[r.kind]); rq_lref.append(len(r.ref_seq)); rq_lalt.append(len(r.alt_seq))
         rq_blk_a.append(blk_a); rq_blk_b.append(blk_b)
@@ -293,8 +321,14 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
     br_rq = bl_rq_a[br_blk]
     pairs = np.zeros(2 * len(br_blk), dtype=L.PAIR_DTYPE)
     pairs["seq1"] = np.repeat((rq_q0[br_rq] + br_i).astype(i32), 2)
-    al = np.repeat(np.asarray(bl_allele, dtype=i32)[br_blk], 2)
-    al[1::2] += 1
+    n_lit = len(seqs)
+
+    def placed(v):                                            # derived sequence d: behind the literals
+        v = np.asarray(v, dtype=np.int64)
+        return np.where(v < 0, n_lit - 1 - v, v).astype(i32)
+    al = np.empty(2 * len(br_blk), dtype=i32)
+    al[0::2] = placed(bl_ref)[br_blk]
+    al[1::2] = placed(bl_alt)[br_blk]
     pairs["seq2"] = al
     pairs["off2"] = np.repeat(miss_a[rq_first[br_rq] + br_i], 2)
     pairs["k"] = np.repeat(np.asarray(rq_k, dtype=i32)[br_rq], 2)
@@ -310,7 +344,7 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
     table["locus"] = np.asarray(nz, dtype=i32)[rd_rq]
     table["len_ref"] = np.asarray(rq_lref, dtype=i32)[rd_rq]
     table["len_alt"] = np.asarray(rq_lalt, dtype=i32)[rd_rq]
-    ss = engine.seqset(seqs, upper)
+    ss = engine.seqset(seqs, None, derived) if derived else engine.seqset(seqs)
     try:
         plan = engine.plan(ss, pairs)
         try:
@@ -367,6 +401,11 @@ def scorer_outputs(engine, kind: str, ref_seq: str, alt_seq: str, x, k):
     fn = {"s1": finish.score_abs_dis_m1b, "s2": finish.score_within_10Perc_m1b,
           "s3": finish.score_directed_dis_m1b_redefine_diagnal}[kind]
     return fn(st[0], st[1], len(ref_seq), len(alt_seq))
+
+
+import re as _re
+
+_NOCOMP = _re.compile("[^ACGTNacgtn]")       # what complementary() drops (SF:471-478)
 
 
 def _is_upper(s: str) -> bool:
