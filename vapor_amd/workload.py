@@ -61,6 +61,7 @@ def make_workload(name: str, seed: int, n_loci: int, svtypes: Sequence[str], rea
         s = int(rng.integers(allele_len // 4, allele_len // 2))
         ri = len(seqs)
         seqs.append(ref); is_alt.append(False)
+        span = min(span, allele_len - s)                  # (what the slices below take on a short window)
         if t == "DEL":
             alt = ref[:s] + ref[s + span:]
             sg = [(ri, 0, s, False), (ri, s + span, allele_len - s - span, False)]
