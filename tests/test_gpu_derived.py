@@ -208,7 +208,10 @@ def test_shared_joins_through_the_loci_path(eng):
         assert np.array_equal(np.isnan(again), np.isnan(recs[-1][0])) and np.array_equal(again[~np.isnan(again)], recs[-1][0][~np.isnan(recs[-1][0])])
         plan.close(); ss.close()
     (a, sa, sta, ta), (b, sb, stb, tb) = recs
-    assert ta["shared_joins"] == len(w.pairs) // 2 and ta["pairs_served_by_shared_joins"] == len(w.pairs) and tb["shared_joins"] == 0
+    # (a read shorter than the window size has no dot plot to share: the tiny shape has a few)
+    n_joined = sum(1 for p in w.pairs[0::2] if len(w.seqs[p["seq1"]]) >= 10)
+    assert n_joined > 64
+    assert ta["shared_joins"] == n_joined and ta["pairs_served_by_shared_joins"] == 2 * n_joined and tb["shared_joins"] == 0
     assert np.array_equal(sta, stb)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     assert np.array_equal(np.isnan(sa), np.isnan(sb)) and np.array_equal(sa[~np.isnan(sa)], sb[~np.isnan(sb)])
