@@ -894,7 +894,6 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
                 if (cand[c].slot >= 0 && cand[c].slot < 4 && tgt[cand[c].slot] < 0) { tgt[cand[c].slot] = cand[c].pair; ++n_t; }
             const Cand c0 = cand[a];
             a = b;
-            if (getenv("VAPOR_DEBUG_SHARE") && n_t < 2) fprintf(stderr, "share: seq1 %d group %d k %d: %d target(s) in %d candidates\n", c0.seq1, c0.group, c0.k, n_t, (int)(b - (a - (b - a))));
             if (n_t < 2) continue;
             const ShareGroup& g = set->groups[(size_t)c0.group];
             const SeqDesc& s1 = set->h[(size_t)c0.seq1];
@@ -904,9 +903,9 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             int sep = 0;
             for (int t = 0; t < 4; ++t)
                 if (tgt[t] >= 0) sep += tiles(p->hp[(size_t)tgt[t]].len2, c0.k, mode[(size_t)tgt[t]]);
-            if (tiles(st.len, c0.k, md) >= sep) { if (getenv("VAPOR_DEBUG_SHARE")) fprintf(stderr, "share: tiles %d >= %d\n", tiles(st.len, c0.k, md), sep); continue; }
+            if (tiles(st.len, c0.k, md) >= sep) continue;           // (a shared sequence of more tiles than its targets together: no gain)
             const auto mp = build_maps(c0.group, c0.k);
-            if (mp.second <= 0) { if (getenv("VAPOR_DEBUG_SHARE")) fprintf(stderr, "share: no maps for group %d k %d\n", c0.group, c0.k); continue; }
+            if (mp.second <= 0 || mp.second > REMAP_MAX_MAPS) continue;
             DPair d;
             memset(&d, 0, sizeof d);
             d.seq1 = c0.seq1; d.seq2 = g.t_seq; d.off2 = 0; d.k = c0.k; d.flags = 0;
@@ -921,15 +920,6 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             p->hp.push_back(d);
             mode.push_back((uint8_t)md);
             p->shares.push_back(sh);
-        }
-        if (getenv("VAPOR_DEBUG_SHARE")) {
-            int ng = 0;
-            for (auto& g : set->groups) ng += g.t_seq >= 0;
-            fprintf(stderr, "share: %zu groups (%d with a shared sequence), %zu candidates of %zu pairs, %zu shares\n", set->groups.size(), ng, cand.size(), order.size(), p->shares.size());
-            for (size_t q = 0; q < set->groups.size(); ++q) {
-                const ShareGroup& g = set->groups[q];
-                fprintf(stderr, "  group %zu: parent %d identity %d members %zu t_seq %d pieces %zu\n", q, g.parent, g.identity, g.members.size(), g.t_seq, g.pieces.size());
-            }
         }
         p->n_dpairs = (int64_t)p->shares.size();
         if (p->n_dpairs) {

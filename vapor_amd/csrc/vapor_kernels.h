@@ -2160,11 +2160,37 @@ struct DShare {        // 32 B
     int32_t pad;
 };
 
+constexpr int REMAP_MAX_MAPS = 32;     // interval maps per share (the host shares no group with more)
+constexpr int REMAP_PER = 8;           // records per thread and round
+
+// (what one record gives under one map: the cut run's first i, first j in the target's sliced coordinates, dots, direction)
+struct CutRun { int i, j, n, dj; };
+__device__ __forceinline__ CutRun remap_cut(unsigned long long r, bool have, const DMap& mp, int off2)
+{
+    const int e0 = VREC_J(r), i0 = VREC_I(r), len = have ? VREC_LEN(r) : 0;
+    const int sd = VREC_RC(r) ? -1 : 1;                           // e(t) = e0 + sd * t, i(t) = i0 + t
+    int a = sd > 0 ? mp.lo - e0 : e0 - mp.hi, b = sd > 0 ? mp.hi - e0 : e0 - mp.lo;       // t with lo <= e(t) <= hi
+    a = max(a, 0); b = min(b, len - 1);
+    // j(t) = ja + dj * (t - a) in the target's full coordinates; only j >= off2 counts (the allele[miss_bp:] slice)
+    const int sg = mp.flip ? -1 : 1, dj = sg * sd;
+    int ja = mp.base + sg * (e0 + sd * a - mp.lo);
+    if (dj > 0) { const int skip = max(0, off2 - ja); a += skip; ja += skip; }
+    else b = min(b, a + (ja - off2));
+    return CutRun{i0 + a, ja - off2, b - a + 1, dj};
+}
+
 __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pairs, const DShare* __restrict__ shares,
                                                    const DMap* __restrict__ maps, unsigned long long* hits,
                                                    unsigned long long* n_hits, unsigned int* __restrict__ overflow)
 {
+    // Everything a round needs is fetched once: the share's maps and its targets' slots into LDS, REMAP_PER records per thread
+    // into registers (independent loads).  Per map the workgroup then counts (one wave scan and one LDS atomic per wave),
+    // and writes: the dependent chain of a round is `maps` short, not maps x records.
     __shared__ uint32_t c_rec[4], c_dots[4];
+    __shared__ DMap s_map[REMAP_MAX_MAPS];
+    __shared__ int s_tp[4], s_off2[4];
+    __shared__ uint32_t s_cap[4];
+    __shared__ long long s_hoff[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const DShare sh = shares[blockIdx.x];
     const DPair dp = pairs[sh.dpair];
@@ -2176,48 +2202,58 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
         if (tid == 0) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
         nrec = dp.cap;
     }
-    if (tid < 4) { c_rec[tid] = 0u; c_dots[tid] = 0u; }
+    const int n_maps = min(sh.n_maps, REMAP_MAX_MAPS);
+    if (tid < n_maps) s_map[tid] = maps[sh.map_first + tid];
+    if (tid >= 64 && tid < 68) {
+        const int t = tid - 64, tp = shares[blockIdx.x].target[t];
+        s_tp[t] = tp;
+        c_rec[t] = 0u; c_dots[t] = 0u;
+        if (tp >= 0) { const DPair tg = pairs[tp]; s_off2[t] = tg.off2; s_cap[t] = tg.cap; s_hoff[t] = tg.hit_off; }
+    }
     __syncthreads();
     const unsigned long long* src = hits + dp.hit_off;
-    for (uint32_t h0 = 0; h0 < nrec; h0 += 256) {
-        const uint32_t h = h0 + (uint32_t)tid;
-        const bool have = h < nrec;
-        const unsigned long long r = have ? src[h] : 0ull;
-        const int e0 = VREC_J(r), i0 = VREC_I(r), len = have ? VREC_LEN(r) : 0;
-        const int sd = VREC_RC(r) ? -1 : 1;                       // e(t) = e0 + sd * t, i(t) = i0 + t
-        for (int m = 0; m < sh.n_maps; ++m) {
-            const DMap mp = maps[sh.map_first + m];
-            const int tp = shares[blockIdx.x].target[mp.slot];   // (a scalar load: indexing the register copy would cost a private array)
-            if (tp < 0) continue;                                  // (uniform: the whole workgroup reads the same map)
-            const DPair tg = pairs[tp];
-            // t with lo <= e(t) <= hi
-            int a = sd > 0 ? mp.lo - e0 : e0 - mp.hi, b = sd > 0 ? mp.hi - e0 : e0 - mp.lo;
-            a = max(a, 0); b = min(b, len - 1);
-            // j(t) = jl + dj * (t - a) in the target's full coordinates; only j >= off2 counts (the allele[miss_bp:] slice)
-            const int dj = (mp.flip ? -1 : 1) * sd;
-            int ja = mp.base + (mp.flip ? -1 : 1) * (e0 + sd * a - mp.lo);
-            if (dj > 0) { const int skip = max(0, tg.off2 - ja); a += skip; ja += skip; }
-            else b = min(b, a + (ja - tg.off2));
-            const int n = b - a + 1;
-            const bool emit = have && n > 0;
-            const unsigned long long mask = __ballot(emit);
-            if (!mask) continue;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            const int dots = wave_sum_i32(emit ? n : 0);
+    for (uint32_t h0 = 0; h0 < nrec; h0 += 256u * REMAP_PER) {
+        unsigned long long r[REMAP_PER];
+        uint32_t have = 0;
+#pragma unroll
+        for (int q = 0; q < REMAP_PER; ++q) {
+            const uint32_t h = h0 + (uint32_t)(q * 256 + tid);
+            r[q] = h < nrec ? src[h] : 0ull;
+            have |= (h < nrec ? 1u : 0u) << q;
+        }
+        for (int m = 0; m < n_maps; ++m) {
+            const DMap mp = s_map[m];
+            if (s_tp[mp.slot] < 0) continue;                       // (uniform)
+            const int off2 = s_off2[mp.slot];
+            uint32_t em = 0;
+            int dots = 0;
+#pragma unroll
+            for (int q = 0; q < REMAP_PER; ++q) {
+                const CutRun c = remap_cut(r[q], (have >> q) & 1u, mp, off2);
+                if (c.n > 0) { em |= 1u << q; dots += c.n; }
+            }
+            const uint32_t mine = (uint32_t)__popc(em);
+            const uint32_t incl = wave_incl_scan_u32(mine);
+            const int wdots = wave_sum_i32(dots);
             uint32_t base = 0;
-            if (lane == 0) { base = atomicAdd(&c_rec[mp.slot], (uint32_t)__popcll(mask)); atomicAdd(&c_dots[mp.slot], (uint32_t)dots); }
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t slot = base + rank;
-            if (emit && slot < tg.cap)
-                hits[tg.hit_off + slot] = (unsigned long long)(uint32_t)(i0 + a) | ((unsigned long long)(uint32_t)(ja - tg.off2) << 16) |
-                                          ((unsigned long long)n << 32) | ((unsigned long long)(dj < 0 ? 1u : 0u) << 48);
+            if (lane == 63 && incl) { base = atomicAdd(&c_rec[mp.slot], incl); atomicAdd(&c_dots[mp.slot], (uint32_t)wdots); }
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+            uint32_t slot = base + incl - mine;
+            const uint32_t cap = s_cap[mp.slot];
+            unsigned long long* dst = hits + s_hoff[mp.slot];
+#pragma unroll
+            for (int q = 0; q < REMAP_PER; ++q) {
+                if (!((em >> q) & 1u)) continue;
+                const CutRun c = remap_cut(r[q], true, mp, off2);
+                if (slot < cap)
+                    dst[slot] = (unsigned long long)(uint32_t)c.i | ((unsigned long long)(uint32_t)c.j << 16) |
+                                ((unsigned long long)c.n << 32) | ((unsigned long long)(c.dj < 0 ? 1u : 0u) << 48);
+                ++slot;
+            }
         }
     }
     __syncthreads();
-    if (tid < 4) {
-        const int tp = shares[blockIdx.x].target[tid];
-        if (tp >= 0) n_hits[tp] = (unsigned long long)c_rec[tid] | ((unsigned long long)c_dots[tid] << 32);
-    }
+    if (tid < 4 && s_tp[tid] >= 0) n_hits[s_tp[tid]] = (unsigned long long)c_rec[tid] | ((unsigned long long)c_dots[tid] << 32);
 }
 
 // expands the records of selected pairs to dots (int32 j, i) and per-dot flag bytes in a dense buffer; the dots
