@@ -238,9 +238,10 @@ struct vapor_plan {
     // join runs instead of the pairs they serve
     int64_t n_dpairs = 0, n_served = 0;
     std::vector<DShare> shares;
-    std::vector<DMap> maps;
+    std::vector<DMap> maps;                    // (host only: the interval maps the tables are cut from)
+    std::vector<int32_t> tables;               // per (group, k): boundaries and op words (remap_kernel)
     DShare* d_shares = nullptr;
-    DMap* d_maps = nullptr;
+    int32_t* d_maps = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -875,8 +876,35 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
                 }
                 if (ok && u <= n_a - k) novel(u, n_a - k);
             }
-            std::pair<int32_t, int32_t> res{first, ok ? (int32_t)p->maps.size() - first : -1};
-            if (!ok) p->maps.resize((size_t)first);
+            std::pair<int32_t, int32_t> res{-1, -1};
+            if (ok && (int32_t)p->maps.size() > first) {
+                // the maps cut at each other's ends: boundaries over the k-mer starts of the shared sequence and, per elementary
+                // interval, the op words of the maps that cover it (remap_kernel)
+                std::vector<int32_t> bd{0};
+                for (size_t m = (size_t)first; m < p->maps.size(); ++m) { bd.push_back(p->maps[m].lo); bd.push_back(p->maps[m].hi + 1); }
+                std::sort(bd.begin(), bd.end());
+                bd.erase(std::unique(bd.begin(), bd.end()), bd.end());
+                const int n_iv = (int)bd.size() - 1;
+                if (n_iv >= 1 && n_iv <= REMAP_MAX_IV) {
+                    std::vector<int32_t> ops((size_t)n_iv * REMAP_OPS, 0);
+                    for (int t = 0; t < n_iv && ok; ++t)
+                        for (size_t m = (size_t)first; m < p->maps.size(); ++m) {
+                            const DMap& mp = p->maps[m];
+                            if (!(mp.lo <= bd[(size_t)t] && bd[(size_t)t + 1] - 1 <= mp.hi)) continue;
+                            const int32_t delta = mp.flip ? mp.base + mp.lo : mp.base - mp.lo;
+                            int32_t* o = &ops[(size_t)t * REMAP_OPS + (size_t)mp.slot * 2];
+                            const int c = (o[0] & 1) ? 1 : 0;
+                            if (c == 1 && (o[1] & 1)) { ok = false; break; }            // a third copy of one stretch in one allele
+                            o[c] = (int32_t)(((uint32_t)delta << 2) | (mp.flip ? 2u : 0u) | 1u);
+                        }
+                    if (ok) {
+                        res = {(int32_t)p->tables.size(), n_iv};
+                        p->tables.insert(p->tables.end(), bd.begin(), bd.end());
+                        p->tables.insert(p->tables.end(), ops.begin(), ops.end());
+                    }
+                }
+            }
+            p->maps.resize((size_t)first);
             maps_of[{gi, k}] = res;
             return res;
         };
@@ -905,7 +933,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
                 if (tgt[t] >= 0) sep += tiles(p->hp[(size_t)tgt[t]].len2, c0.k, mode[(size_t)tgt[t]]);
             if (tiles(st.len, c0.k, md) >= sep) continue;           // (a shared sequence of more tiles than its targets together: no gain)
             const auto mp = build_maps(c0.group, c0.k);
-            if (mp.second <= 0 || mp.second > REMAP_MAX_MAPS) continue;
+            if (mp.second <= 0) continue;
             DPair d;
             memset(&d, 0, sizeof d);
             d.seq1 = c0.seq1; d.seq2 = g.t_seq; d.off2 = 0; d.k = c0.k; d.flags = 0;
@@ -915,7 +943,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             DShare sh;
             memset(&sh, 0, sizeof sh);
             sh.dpair = (int32_t)p->hp.size();
-            sh.map_first = mp.first; sh.n_maps = mp.second;
+            sh.iv_first = mp.first; sh.n_iv = mp.second;
             for (int t = 0; t < 4; ++t) { sh.target[t] = tgt[t]; if (tgt[t] >= 0) { served[(size_t)tgt[t]] = 1; ++p->n_served; } }
             p->hp.push_back(d);
             mode.push_back((uint8_t)md);
@@ -1029,10 +1057,10 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     chk(hmalloc(ctx, (void**)&p->h_overflow, 2 * sizeof(unsigned int)), "hipHostMalloc overflow");
     if (p->n_dpairs) {
         chk(dmalloc(ctx, (void**)&p->d_shares, sizeof(DShare) * p->shares.size()), "hipMalloc shares");
-        chk(dmalloc(ctx, (void**)&p->d_maps, sizeof(DMap) * std::max<size_t>(p->maps.size(), 1)), "hipMalloc maps");
+        chk(dmalloc(ctx, (void**)&p->d_maps, sizeof(int32_t) * std::max<size_t>(p->tables.size(), 1)), "hipMalloc maps");
         if (rc == VAPOR_OK) chk(hipMemcpyAsync(p->d_shares, p->shares.data(), sizeof(DShare) * p->shares.size(), hipMemcpyHostToDevice, ctx->stream), "copy shares");
-        if (rc == VAPOR_OK && !p->maps.empty())
-            chk(hipMemcpyAsync(p->d_maps, p->maps.data(), sizeof(DMap) * p->maps.size(), hipMemcpyHostToDevice, ctx->stream), "copy maps");
+        if (rc == VAPOR_OK && !p->tables.empty())
+            chk(hipMemcpyAsync(p->d_maps, p->tables.data(), sizeof(int32_t) * p->tables.size(), hipMemcpyHostToDevice, ctx->stream), "copy maps");
     }
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
@@ -1167,7 +1195,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
     }
     if (p->n_dpairs) {
         hipLaunchKernelGGL(remap_kernel, dim3((unsigned)p->n_dpairs), dim3(256), 0, st, (const DPair*)p->d_pairs, (const DShare*)p->d_shares,
-                           (const DMap*)p->d_maps, p->d_hits, p->d_nhits, p->d_overflow);
+                           (const int32_t*)p->d_maps, p->d_hits, p->d_nhits, p->d_overflow);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ev[1], st));

@@ -2147,47 +2147,36 @@ __global__ __launch_bounds__(CLEAN_THREADS, 4) void clean_big_kernel(
 // K-mer starts of T that belong to no interval (the k-1 positions that straddle two stretches) are dots of nothing and are
 // dropped here.  Every dot of every target is produced exactly once: a k-mer start of an allele lies inside exactly one of its
 // slices or inside exactly one of its own stretches in T.  One workgroup per read.
-struct DMap {          // 16 B
+struct DMap {          // 16 B (host side: the interval maps of a (window, k) group before they are cut into the table below)
     int32_t lo, hi;    // k-mer starts of the shared sequence, inclusive
     int32_t base;      // position in the target at e == lo
     uint16_t flip;     // 1: reverse-complemented slice (j decreases with e, strands swap)
     uint16_t slot;     // which target of the share
 };
+// What the kernel reads is the same maps cut at each other's ends: boundaries B[0] = 0 < B[1] < ... < B[n_iv] over the k-mer
+// starts of the shared sequence, and per elementary interval [B[t], B[t+1]) what a dot inside it becomes - for every target
+// slot up to two ops (a tandem duplication's repeated stretch lies twice in its allele), each one word:
+//     bit 0 valid, bit 1 flip, bits 2.. delta (signed):   j = e + delta,  or  j = delta - e with the strands swapped.
+// A record looks its interval up once (binary search) and is then copied, shifted, under the ops of that interval; only a run
+// that crosses a boundary is cut, interval by interval.
+constexpr int REMAP_MAX_IV = 48;       // elementary intervals per share (the host shares no group with more)
+constexpr int REMAP_PER = 4;           // records per thread and round
+constexpr int REMAP_OPS = 8;           // op words per interval: 4 target slots x 2 copies
 struct DShare {        // 32 B
     int32_t dpair;     // the (read, T) pair the join ran
-    int32_t map_first, n_maps;
+    int32_t iv_first;  // first word of this group's table in the maps buffer: B[0 .. n_iv], then n_iv x REMAP_OPS op words
+    int32_t n_iv;
     int32_t target[4]; // pair index per slot, -1: this read has no pair against that allele
     int32_t pad;
 };
 
-constexpr int REMAP_MAX_MAPS = 32;     // interval maps per share (the host shares no group with more)
-constexpr int REMAP_PER = 8;           // records per thread and round
-
-// (what one record gives under one map: the cut run's first i, first j in the target's sliced coordinates, dots, direction)
-struct CutRun { int i, j, n, dj; };
-__device__ __forceinline__ CutRun remap_cut(unsigned long long r, bool have, const DMap& mp, int off2)
-{
-    const int e0 = VREC_J(r), i0 = VREC_I(r), len = have ? VREC_LEN(r) : 0;
-    const int sd = VREC_RC(r) ? -1 : 1;                           // e(t) = e0 + sd * t, i(t) = i0 + t
-    int a = sd > 0 ? mp.lo - e0 : e0 - mp.hi, b = sd > 0 ? mp.hi - e0 : e0 - mp.lo;       // t with lo <= e(t) <= hi
-    a = max(a, 0); b = min(b, len - 1);
-    // j(t) = ja + dj * (t - a) in the target's full coordinates; only j >= off2 counts (the allele[miss_bp:] slice)
-    const int sg = mp.flip ? -1 : 1, dj = sg * sd;
-    int ja = mp.base + sg * (e0 + sd * a - mp.lo);
-    if (dj > 0) { const int skip = max(0, off2 - ja); a += skip; ja += skip; }
-    else b = min(b, a + (ja - off2));
-    return CutRun{i0 + a, ja - off2, b - a + 1, dj};
-}
-
 __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pairs, const DShare* __restrict__ shares,
-                                                   const DMap* __restrict__ maps, unsigned long long* hits,
+                                                   const int32_t* __restrict__ tables, unsigned long long* hits,
                                                    unsigned long long* n_hits, unsigned int* __restrict__ overflow)
 {
-    // Everything a round needs is fetched once: the share's maps and its targets' slots into LDS, REMAP_PER records per thread
-    // into registers (independent loads).  Per map the workgroup then counts (one wave scan and one LDS atomic per wave),
-    // and writes: the dependent chain of a round is `maps` short, not maps x records.
     __shared__ uint32_t c_rec[4], c_dots[4];
-    __shared__ DMap s_map[REMAP_MAX_MAPS];
+    __shared__ int s_B[REMAP_MAX_IV + 2];
+    __shared__ uint32_t s_ops[REMAP_MAX_IV * REMAP_OPS];
     __shared__ int s_tp[4], s_off2[4];
     __shared__ uint32_t s_cap[4];
     __shared__ long long s_hoff[4];
@@ -2202,10 +2191,13 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
         if (tid == 0) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
         nrec = dp.cap;
     }
-    const int n_maps = min(sh.n_maps, REMAP_MAX_MAPS);
-    if (tid < n_maps) s_map[tid] = maps[sh.map_first + tid];
-    if (tid >= 64 && tid < 68) {
-        const int t = tid - 64, tp = shares[blockIdx.x].target[t];
+    const int n_iv = min(sh.n_iv, REMAP_MAX_IV);
+    const int32_t* tb = tables + sh.iv_first;
+    if (tid <= n_iv) s_B[tid] = tb[tid];
+    if (tid == n_iv + 1) s_B[tid] = 0x7FFFFFFF;
+    for (int x = tid; x < n_iv * REMAP_OPS; x += 256) s_ops[x] = (uint32_t)tb[n_iv + 1 + x];
+    if (tid >= 192 && tid < 196) {
+        const int t = tid - 192, tp = shares[blockIdx.x].target[t];
         s_tp[t] = tp;
         c_rec[t] = 0u; c_dots[t] = 0u;
         if (tp >= 0) { const DPair tg = pairs[tp]; s_off2[t] = tg.off2; s_cap[t] = tg.cap; s_hoff[t] = tg.hit_off; }
@@ -2213,42 +2205,82 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
     __syncthreads();
     const unsigned long long* src = hits + dp.hit_off;
     for (uint32_t h0 = 0; h0 < nrec; h0 += 256u * REMAP_PER) {
-        unsigned long long r[REMAP_PER];
-        uint32_t have = 0;
+        // the round's records: first and last k-mer start, first read position, and the interval the first start lies in
+        int e_lo[REMAP_PER], e_hi[REMAP_PER], i_at_lo[REMAP_PER], iv[REMAP_PER];
+        uint32_t rcbits = 0;                                      // record q is a reverse-complement record (e falls as i rises)
 #pragma unroll
         for (int q = 0; q < REMAP_PER; ++q) {
             const uint32_t h = h0 + (uint32_t)(q * 256 + tid);
-            r[q] = h < nrec ? src[h] : 0ull;
-            have |= (h < nrec ? 1u : 0u) << q;
+            const bool have = h < nrec;
+            const unsigned long long r = have ? src[h] : 0ull;
+            const int e0 = VREC_J(r), i0 = VREC_I(r), len = VREC_LEN(r);
+            const bool rc = VREC_RC(r);
+            rcbits |= (rc ? 1u : 0u) << q;
+            // e(t) = e0 +- t, i(t) = i0 + t: the k-mer starts run over [e_lo, e_hi]; i_at_lo = the read position that goes with e_lo
+            e_lo[q] = rc ? e0 - (len - 1) : e0;
+            e_hi[q] = have ? e_lo[q] + len - 1 : e_lo[q] - 1;     // (an empty slot: no interval ever reaches it)
+            i_at_lo[q] = rc ? i0 + (len - 1) : i0;
+            int pos = 0;                                          // largest t with B[t] <= e_lo (B[0] = 0)
+#pragma unroll
+            for (int stp = 32; stp > 0; stp >>= 1)
+                if (pos + stp <= n_iv && s_B[pos + stp] <= e_lo[q]) pos += stp;
+            iv[q] = pos;
         }
-        for (int m = 0; m < n_maps; ++m) {
-            const DMap mp = s_map[m];
-            if (s_tp[mp.slot] < 0) continue;                       // (uniform)
-            const int off2 = s_off2[mp.slot];
-            uint32_t em = 0;
-            int dots = 0;
+        for (int step = 0;; ++step) {
+            // the part of every record inside interval iv + step (the whole record, nearly always, at step 0)
+            uint32_t act = 0;
 #pragma unroll
-            for (int q = 0; q < REMAP_PER; ++q) {
-                const CutRun c = remap_cut(r[q], (have >> q) & 1u, mp, off2);
-                if (c.n > 0) { em |= 1u << q; dots += c.n; }
-            }
-            const uint32_t mine = (uint32_t)__popc(em);
-            const uint32_t incl = wave_incl_scan_u32(mine);
-            const int wdots = wave_sum_i32(dots);
-            uint32_t base = 0;
-            if (lane == 63 && incl) { base = atomicAdd(&c_rec[mp.slot], incl); atomicAdd(&c_dots[mp.slot], (uint32_t)wdots); }
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
-            uint32_t slot = base + incl - mine;
-            const uint32_t cap = s_cap[mp.slot];
-            unsigned long long* dst = hits + s_hoff[mp.slot];
+            for (int q = 0; q < REMAP_PER; ++q) act |= ((iv[q] + step < n_iv && s_B[iv[q] + step] <= e_hi[q]) ? 1u : 0u) << q;
+            if (!__ballot(act != 0u)) break;
 #pragma unroll
-            for (int q = 0; q < REMAP_PER; ++q) {
-                if (!((em >> q) & 1u)) continue;
-                const CutRun c = remap_cut(r[q], true, mp, off2);
-                if (slot < cap)
-                    dst[slot] = (unsigned long long)(uint32_t)c.i | ((unsigned long long)(uint32_t)c.j << 16) |
-                                ((unsigned long long)c.n << 32) | ((unsigned long long)(c.dj < 0 ? 1u : 0u) << 48);
-                ++slot;
+            for (int sc = 0; sc < REMAP_OPS; ++sc) {
+                const int slot = sc >> 1;
+                if (s_tp[slot] < 0) continue;                      // (uniform)
+                uint32_t op[REMAP_PER], em = 0;
+#pragma unroll
+                for (int q = 0; q < REMAP_PER; ++q) {
+                    op[q] = ((act >> q) & 1u) ? s_ops[(iv[q] + step) * REMAP_OPS + sc] : 0u;
+                    em |= (op[q] & 1u) << q;
+                }
+                if (!__ballot(em != 0u)) continue;
+                const int off2 = s_off2[slot];
+                uint32_t w_lo[REMAP_PER], w_hi[REMAP_PER];
+                int dots = 0;
+#pragma unroll
+                for (int q = 0; q < REMAP_PER; ++q) {
+                    const int t = iv[q] + step;
+                    const int pe_lo = max(e_lo[q], s_B[t]), pe_hi = min(e_hi[q], s_B[t + 1] - 1);
+                    const bool rc = (rcbits >> q) & 1u, flip = (op[q] >> 1) & 1u;
+                    const int delta = (int)op[q] >> 2;
+                    // in read order the part starts at e_first (its first i) and moves by sd per dot
+                    const int e_first = rc ? pe_hi : pe_lo;
+                    int i_first = rc ? i_at_lo[q] - (pe_hi - e_lo[q]) : i_at_lo[q] + (pe_lo - e_lo[q]);
+                    int n = pe_hi - pe_lo + 1;
+                    int ja = flip ? delta - e_first : e_first + delta;
+                    const int dj = (flip ? -1 : 1) * (rc ? -1 : 1);
+                    // only j >= off2 counts (the allele[miss_bp:] slice)
+                    if (dj > 0) { const int skip = max(0, off2 - ja); i_first += skip; ja += skip; n -= skip; }
+                    else n = min(n, ja - off2 + 1);
+                    if (!((em >> q) & 1u) || n <= 0) { n = 0; em &= ~(1u << q); }
+                    dots += n;
+                    w_lo[q] = (uint32_t)i_first | ((uint32_t)(ja - off2) << 16);
+                    w_hi[q] = (uint32_t)n | ((dj < 0 ? 1u : 0u) << 16);
+                }
+                const uint32_t mine = (uint32_t)__popc(em);
+                const uint32_t incl = wave_incl_scan_u32(mine);
+                const int wdots = wave_sum_i32(dots);
+                uint32_t base = 0;
+                if (lane == 63 && incl) { base = atomicAdd(&c_rec[slot], incl); atomicAdd(&c_dots[slot], (uint32_t)wdots); }
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+                uint32_t at = base + incl - mine;
+                const uint32_t cap = s_cap[slot];
+                unsigned long long* dst = hits + s_hoff[slot];
+#pragma unroll
+                for (int q = 0; q < REMAP_PER; ++q) {
+                    if (!((em >> q) & 1u)) continue;
+                    if (at < cap) dst[at] = (unsigned long long)w_lo[q] | ((unsigned long long)w_hi[q] << 32);
+                    ++at;
+                }
             }
         }
     }
