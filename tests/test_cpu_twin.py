@@ -61,6 +61,7 @@ def test_derived_sequences_on_the_twin(eng, oracle):
     D.check_planes(eng)
     D.test_revcomp_of_a_window_with_iupac_codes_is_refused(eng)
     assert D.check_shared_joins(eng, oracle, ks=(10, 30), want_shared=False) == 0      # (the twin joins pair by pair)
+    assert D.check_random_structures(eng, oracle, n_windows=3) == 0
 
 
 def test_pipeline_and_cli_on_the_twin(eng, tmp_path):

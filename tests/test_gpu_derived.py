@@ -234,3 +234,65 @@ def test_shared_join_overflow_is_resized(eng, oracle):
         exp = oracle.dotdata_array(10, read, a)
         assert st[t, 15] == 0 and st[t, 0] == len(exp) and np.array_equal(dots[t], exp.reshape(-1, 2))
     assert st[0, 0] > 20000
+
+
+def check_random_structures(eng, oracle, n_windows=6, seed=1234):
+    """Random segment lists - two to six slices of a window (some reversed, some a few bases short, some overlapping, some
+    from a second text) - as derived alleles: the dots of every (read, allele) pair equal the oracle's on the text the segments
+    spell, with the joins shared.  Lower-case stretches and N in windows and reads take the pairs through every symbol mode."""
+    rng = np.random.default_rng(seed)
+    served = 0
+    for wi in range(n_windows):
+        n = int(rng.integers(600, 5000))
+        win = synth.random_dna(rng, n)
+        other = synth.random_dna(rng, int(rng.integers(50, 700)))
+        if wi % 3 == 1:
+            a = int(rng.integers(0, n - 200))
+            win = win[:a] + win[a:a + 150].lower() + win[a + 150:]
+        if wi % 3 == 2:
+            a = int(rng.integers(0, n - 50))
+            win = win[:a] + "N" * 5 + win[a + 5:]
+        lits = [win, other]
+        der, texts = [], []
+        for _ in range(3):
+            segs, txt = [], ""
+            for _s in range(int(rng.integers(2, 7))):
+                par = 0 if rng.random() < 0.85 else 1
+                plen = len(lits[par])
+                ln = int(rng.choice([int(rng.integers(1, 25)), int(rng.integers(25, 400)), int(rng.integers(400, max(401, plen)))]))
+                ln = min(ln, plen)
+                off = int(rng.integers(0, plen - ln + 1))
+                rc = bool(rng.random() < 0.3)
+                piece = lits[par][off:off + ln]
+                segs.append((par, off, ln, rc))
+                txt += _rc(piece) if rc else piece
+            der.append((segs, False))
+            texts.append(txt)
+        reads = []
+        for src in [win] + texts:
+            r, _ = synth.mutate(rng, src[:3000], 0.01, 0.05, 0.03)
+            reads.append(r)
+        reads.append(reads[0][:120] + "n" * 3 + reads[0][123:])
+        seqs = lits + reads
+        fr, fd = len(lits), len(lits) + len(reads)
+        allt = seqs + texts
+        for k in (10, 20, 40):
+            rows = []
+            for r in range(len(reads)):
+                miss = int(rng.integers(0, 60)) if r % 2 else 0
+                for a in [0] + [fd + d for d in range(len(der))]:
+                    rows.append((fr + r, a, miss, k, L.PF_C1 | L.PF_C2))
+            ss = eng.seqset(seqs, derived=der)
+            try:
+                st, dots, tm = _plots(eng, ss, eng.make_pairs(rows))
+            finally:
+                ss.close()
+            served += tm["pairs_served_by_shared_joins"]
+            for t, (s1, s2, off2, kk, _fl) in enumerate(rows):
+                exp = oracle.dotdata_array(kk, allt[s1], allt[s2][off2:]).reshape(-1, 2)
+                assert st[t, 15] == 0 and st[t, 0] == len(exp) and np.array_equal(dots[t], exp), (wi, k, t, der, len(dots[t]), len(exp))
+    return served
+
+
+def test_shared_joins_on_random_segment_structures(eng, oracle):
+    assert check_random_structures(eng, oracle) > 300

@@ -33,7 +33,7 @@ if "--child" in sys.argv:
     name = sys.argv[sys.argv.index("--child") + 1]
     w = wl.make_workload(name, seed=1000, **wl.WORKLOADS[name])
     eng = Engine(0)
-    plan = eng.plan(eng.seqset(w.seqs), w.pairs)
+    plan = eng.plan(w.upload(eng), w.pairs)          # (derived alt windows: the plan shares its joins)
     for _ in range(5):
         plan.run()
     tj, tc = [], []

@@ -1193,7 +1193,11 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
         first = false;
         HIPCHK(hipGetLastError());
     }
+#if defined(VAPOR_AB) && VAPOR_AB == 3               /* (developer variant 3: the shared joins without their remap) */
+    if (false) {
+#else
     if (p->n_dpairs) {
+#endif
         hipLaunchKernelGGL(remap_kernel, dim3((unsigned)p->n_dpairs), dim3(256), 0, st, (const DPair*)p->d_pairs, (const DShare*)p->d_shares,
                            (const int32_t*)p->d_maps, p->d_hits, p->d_nhits, p->d_overflow);
         HIPCHK(hipGetLastError());

@@ -2278,7 +2278,9 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
 #pragma unroll
                 for (int q = 0; q < REMAP_PER; ++q) {
                     if (!((em >> q) & 1u)) continue;
+#if !(defined(VAPOR_AB) && VAPOR_AB == 1)       /* (developer variant 1: everything but the stores) */
                     if (at < cap) dst[at] = (unsigned long long)w_lo[q] | ((unsigned long long)w_hi[q] << 32);
+#endif
                     ++at;
                 }
             }
