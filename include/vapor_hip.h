@@ -284,6 +284,19 @@ int vapor_bam_chop(vapor_bam* bam, int32_t tid, int64_t start, int64_t end, int6
 int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, const char* const* cigar,
                        const int64_t* seq_len, int64_t start, int64_t end, int64_t flank, int64_t* q0_miss, uint8_t* keep);
 /*
+ * chop_pacbio_read_by_pos (SF:339-354) followed by minimize_pacbio_read_list (SF:1091-1102: at most max_keep reads, the smallest
+ * miss_bp first, input order inside one miss_bp value) for MANY regions in one call (host, no device) - the read selection of a
+ * whole batch of loci, which the reference runs as a samtools process and two Python loops per locus.  Region g looks at
+ * n_rec[g] records given as vapor_chop_records' arrays (pos[g], ref_span[g], cigar[g], seq_len[g]: one pointer per region);
+ * its kept reads are entries kept_first[g] .. kept_first[g + 1] of rec_idx (index into the region's records), q0 (offset into
+ * the read) and miss (miss_bp); the three have room for max_keep entries per region.  status[g] = VAPOR_E_ARG for a region
+ * with a record without CIGAR operation (IndexError in the reference, SF:331), else 0.
+ */
+int vapor_chop_records_many(int32_t n_regions, const int32_t* n_rec, const int64_t* const* pos, const int64_t* const* ref_span,
+                            const char* const* const* cigar, const int64_t* const* seq_len, const int64_t* start,
+                            const int64_t* end, const int64_t* flank, int32_t max_keep, int32_t* kept_first, int32_t* rec_idx,
+                            int64_t* q0, int64_t* miss, int32_t* status);
+/*
  * The row tails of a whole output table in one call (host, no device): per locus t with read scores
  * scores[off[t] .. off[t+1]) what result_organize_ins (SF:1219-1231) and gt_estimate_log_likelihood (SF:2054-2069, reading
  * the rounded Rec string back, SF:2056) derive from them - n_pos[t] = scores > 0, qs[t] = their np.mean (numpy's pairwise

@@ -45,7 +45,7 @@ EXPORTS = [
     "vapor_plan_set_reads", "vapor_plan_run_loci", "vapor_set_stream", "vapor_plan_run_loci_async", "vapor_plan_sync", "vapor_plan_then", "vapor_plan_after",
     "vapor_cigar2alignstart", "vapor_cigar2alignstart_ops",
     "vapor_bam_open", "vapor_bam_close", "vapor_bam_set_threads", "vapor_bam_last_error", "vapor_bam_chop",
-    "vapor_inflate_raw", "vapor_chop_records", "vapor_row_tails", "vapor_crc32",
+    "vapor_inflate_raw", "vapor_chop_records", "vapor_chop_records_many", "vapor_row_tails", "vapor_crc32",
 ]
 
 _lib = None
@@ -163,6 +163,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_crc32.argtypes = [vp, ctypes.c_int64, ctypes.c_int32]
     L.vapor_crc32.restype = ctypes.c_uint32
     L.vapor_chop_records.argtypes = [ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp]
+    L.vapor_chop_records_many.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp]
     L.vapor_row_tails.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.c_int64, vp]
     L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
     L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]

@@ -466,6 +466,49 @@ extern "C" int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* 
     return VAPOR_OK;
 }
 
+// chop_pacbio_read_by_pos (SF:339-354) and minimize_pacbio_read_list (SF:1091-1102: at most `max_keep` reads, smallest miss_bp
+// first, input order inside one miss_bp value) for MANY regions in one call: region g looks at n_rec[g] records given as the
+// arrays of vapor_chop_records (one pointer per region), keeps what that call keeps and, when there are more than max_keep,
+// the first max_keep of them in a stable order by miss_bp.  kept_first[g] .. kept_first[g + 1] index rec_idx / q0 / miss
+// (capacity max_keep per region).  status[g] = 0, or VAPOR_E_ARG where a record without CIGAR reaches the walk (the reference
+// raises IndexError there, SF:331: the caller lets that region take the reference-named route).
+extern "C" int vapor_chop_records_many(int32_t n_regions, const int32_t* n_rec, const int64_t* const* pos,
+                                       const int64_t* const* ref_span, const char* const* const* cigar,
+                                       const int64_t* const* seq_len, const int64_t* start, const int64_t* end,
+                                       const int64_t* flank, int32_t max_keep, int32_t* kept_first, int32_t* rec_idx,
+                                       int64_t* q0, int64_t* miss, int32_t* status)
+{
+    if (n_regions < 0 || max_keep < 1 || (n_regions && (!n_rec || !pos || !ref_span || !cigar || !seq_len || !start || !end || !flank ||
+                                                           !kept_first || !rec_idx || !q0 || !miss || !status)))
+        return bfail(VAPOR_E_ARG, "vapor_chop_records_many: null argument");
+    std::vector<int64_t> qm;
+    std::vector<uint8_t> keep;
+    std::vector<int32_t> order;
+    int32_t w = 0;
+    for (int32_t g = 0; g < n_regions; ++g) {
+        kept_first[g] = w;
+        status[g] = 0;
+        const int32_t n = n_rec[g];
+        if (n <= 0) continue;
+        qm.resize((size_t)2 * n);
+        keep.resize((size_t)n);
+        if (vapor_chop_records(n, pos[g], ref_span[g], cigar[g], seq_len[g], start[g], end[g], flank[g], qm.data(), keep.data()) != VAPOR_OK) {
+            status[g] = VAPOR_E_ARG;
+            continue;
+        }
+        order.clear();
+        for (int32_t r = 0; r < n; ++r)
+            if (keep[(size_t)r]) order.push_back(r);
+        if ((int32_t)order.size() > max_keep) {
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qm[(size_t)2 * a + 1] < qm[(size_t)2 * b + 1]; });
+            order.resize((size_t)max_keep);
+        }
+        for (int32_t r : order) { rec_idx[w] = r; q0[w] = qm[(size_t)2 * r]; miss[w] = qm[(size_t)2 * r + 1]; ++w; }
+    }
+    kept_first[n_regions] = w;
+    return VAPOR_OK;
+}
+
 // The row tails of a whole table in one call (no device): what result_organize_ins (SF:1219-1231) and
 // gt_estimate_log_likelihood (SF:2054-2069) compute per locus from its read scores, minus the parts that are table lookups on
 // the caller's side.  Per locus t with scores[off[t] .. off[t+1]):
