@@ -289,13 +289,14 @@ int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* ref_span, c
  * whole batch of loci, which the reference runs as a samtools process and two Python loops per locus.  Region g looks at
  * n_rec[g] records given as vapor_chop_records' arrays (pos[g], ref_span[g], cigar[g], seq_len[g]: one pointer per region);
  * its kept reads are entries kept_first[g] .. kept_first[g + 1] of rec_idx (index into the region's records), q0 (offset into
- * the read) and miss (miss_bp); the three have room for max_keep entries per region.  status[g] = VAPOR_E_ARG for a region
+ * the read) and miss (miss_bp); the three have room for max_keep entries per region.  addr_out (may be NULL, same room)
+ * receives seq_addr[g][record] per kept read: the address of that record's sequence where the caller keeps it.  status[g] = VAPOR_E_ARG for a region
  * with a record without CIGAR operation (IndexError in the reference, SF:331), else 0.
  */
 int vapor_chop_records_many(int32_t n_regions, const int32_t* n_rec, const int64_t* const* pos, const int64_t* const* ref_span,
                             const char* const* const* cigar, const int64_t* const* seq_len, const int64_t* start,
                             const int64_t* end, const int64_t* flank, int32_t max_keep, int32_t* kept_first, int32_t* rec_idx,
-                            int64_t* q0, int64_t* miss, int32_t* status);
+                            int64_t* q0, int64_t* miss, int32_t* status, const uint64_t* const* seq_addr, uint64_t* addr_out);
 /*
  * The row tails of a whole output table in one call (host, no device): per locus t with read scores
  * scores[off[t] .. off[t+1]) what result_organize_ins (SF:1219-1231) and gt_estimate_log_likelihood (SF:2054-2069, reading

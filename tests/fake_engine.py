@@ -28,6 +28,7 @@ class _SeqSet:
         self.n_derived = len(derived or ())
         self.lens = np.array([len(s) for s in self.seqs], dtype=np.int32)
         self.n_invalid = np.array([sum(1 for ch in set(s) if ch not in _VALID) for s in self.seqs], dtype=np.int32)
+        self.n_exc = np.array([sum(1 for ch in s if ch not in "ACGT") for s in self.seqs], dtype=np.int32)
 
     def close(self):
         pass
@@ -116,6 +117,18 @@ class FakeEngine:
     def seqset(self, seqs, upper=None, derived=None):
         self.derived_seen = getattr(self, "derived_seen", 0) + len(derived or ())
         return _SeqSet(list(seqs), list(upper) if upper is not None else [False] * len(seqs), derived)
+
+    def seqset_raw(self, addr, lens, derived=None, keepalive=None):
+        """Sequences given by address (vapor_amd.engine.SeqSet.from_addresses): read back as text."""
+        import ctypes
+        seqs = [ctypes.string_at(int(a), int(n)).decode("ascii") for a, n in zip(addr, lens)]
+        der = None
+        if derived is not None:
+            seg_first, segs, dflags = derived
+            der = [([(int(g["parent"]), int(g["off"]), int(g["len"]), bool(g["flags"] & 1)) for g in segs[seg_first[d]:seg_first[d + 1]]],
+                    bool(dflags[d] & 1)) for d in range(len(seg_first) - 1)]
+        self.raw_sets = getattr(self, "raw_sets", 0) + 1
+        return self.seqset(seqs, None, der)
 
     def plan(self, ss, pairs):
         self.batches.append((ss.n, len(pairs)))

@@ -45,6 +45,10 @@ class _Plan:
     def run_loci(self, device_out=0, want_host=True, want_scores=False):
         return None
 
+    def fetch_hits(self, idx, want_flags=True):
+        idx = list(idx)
+        return np.zeros((0, 2), np.int32), None, np.zeros(len(idx) + 1, dtype=np.int64)
+
     def close(self):
         pass
 
@@ -52,6 +56,18 @@ class _Plan:
 class NullEngine:
     def seqset(self, seqs, upper=None, derived=None):
         return _SS(seqs, derived)
+
+    def seqset_raw(self, addr, lens, derived=None, keepalive=None):
+        ss = _SS.__new__(_SS)
+        nd = (len(derived[0]) - 1) if derived is not None else 0
+        ss.n = len(addr) + nd
+        dl = np.zeros(nd, dtype=np.int32)
+        if nd:
+            np.add.at(dl, np.repeat(np.arange(nd), np.diff(derived[0])), derived[1]["len"][:int(derived[0][-1])])
+        ss.lens = np.concatenate([np.asarray(lens, dtype=np.int32), dl])
+        ss.n_invalid = np.zeros(ss.n, dtype=np.int32)
+        ss.n_exc = np.zeros(ss.n, dtype=np.int32)
+        return ss
 
     def plan(self, ss, pairs):
         return _Plan(ss, pairs)

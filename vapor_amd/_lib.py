@@ -163,7 +163,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_crc32.argtypes = [vp, ctypes.c_int64, ctypes.c_int32]
     L.vapor_crc32.restype = ctypes.c_uint32
     L.vapor_chop_records.argtypes = [ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp]
-    L.vapor_chop_records_many.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp]
+    L.vapor_chop_records_many.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.vapor_row_tails.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.c_int64, vp]
     L.vapor_plan_algorithmic_bytes.argtypes = [vp, i64p, i64p]
     L.vapor_plan_fetch_hits.argtypes = [vp, ctypes.c_int64, i64p, i32p, u8p, ctypes.c_int64, i64p]

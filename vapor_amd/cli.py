@@ -181,10 +181,13 @@ def vcf_list_readin(file_in):
 class Job:
     """One output row: how to score it (a driver generator factory, or fixed scores) and how to
     write it.  `cost`: what the locus is expected to take (microseconds, `job_cost`), for the shares of the ranks."""
-    __slots__ = ("key", "make", "fixed", "row_prefix", "label", "cost")
+    __slots__ = ("key", "make", "fixed", "row_prefix", "label", "cost", "spec", "ctx")
 
-    def __init__(self, key, make=None, fixed=None, row_prefix=None, label=None, cost=None):
+    def __init__(self, key, make=None, fixed=None, row_prefix=None, label=None, cost=None, spec=None, ctx=None):
         self.key, self.make, self.fixed, self.row_prefix, self.label = key, make, fixed, row_prefix, label
+        # the four simple types also say WHAT they are - (type, chrom, start, end, ins_seq) and (num_reads_cff, bam, ref) - so
+        # that a chunk of them can take the array route (vapor_amd.fastpath); `make` stays the driver's own route
+        self.spec, self.ctx = spec, ctx
         self.cost = cost if cost is not None else (COST_FIXED_US if make is None else COST_HOST_US)
 
 
@@ -230,6 +233,7 @@ def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
     """The loop of vapor_vali/vapor:334-367."""
     jobs = []
     plt_li = 0
+    ctx = (num_reads_cff, bam_in, ref)
     for x in bed_info:
         tag = x[-1]
         if tag in ['a/', '/a', '/', 'DEL']:
@@ -246,7 +250,8 @@ def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
             fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
             jobs.append(Job(key, (lambda p=plt_li, a=ins_pos, s=ins_seq, f=fig:
                                   drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, f, '+')),
-                            row_prefix=x[3], label=x, cost=job_cost('INS', len(ins_seq))))
+                            row_prefix=x[3], label=x, cost=job_cost('INS', len(ins_seq)),
+                            spec=('INS', x[0], x[1], None, ins_seq), ctx=ctx))
             continue
         elif tag in ['a/aa', 'aa/a', 'aa/aa', 'DUP', 'TANDUP']:
             key = ':'.join([str(i) for i in x[:-3]] + ['TANDUP'])
@@ -257,7 +262,7 @@ def bed_jobs(bed_info, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
         plt_li += 1
         fig = out_path + sample_name + '.' + name + '.' + key.replace(':', '__') + '.png'
         jobs.append(Job(key, (lambda p=plt_li, f=fn, info=x[:-3], g=fig: f(num_reads_cff, p, bam_in, ref, info, g)),
-                        row_prefix=x[3], label=x, cost=job_cost(name, x[2] - x[1])))
+                        row_prefix=x[3], label=x, cost=job_cost(name, x[2] - x[1]), spec=(name, x[0], x[1], x[2], None), ctx=ctx))
     return jobs
 
 
@@ -265,6 +270,7 @@ def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
     """The loop of vapor_vali/vapor:387-465 (TANDUP is bucketed but never scored there either)."""
     jobs = []
     plt_li = 0
+    ctx = (num_reads_cff, bam_in, ref)
     for x in list(vcf_list.keys()):
         if x not in ('DEL', 'INV', 'INS', 'DISDUP', 'DEL_INV', 'DUP_INV', 'Other'):
             print(x)
@@ -282,7 +288,7 @@ def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
                 fn = drivers.vapor_simple_del if x == 'DEL' else drivers.vapor_simple_inv
                 fig = out_path + sample_name + '.' + x + '.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, f=fn, info=y, g=fig: f(num_reads_cff, p, bam_in, ref, info, g)),
-                                cost=job_cost(x, y[2] - y[1])))
+                                cost=job_cost(x, y[2] - y[1]), spec=(x, y[0], y[1], y[2], None), ctx=ctx))
             elif x == 'INS':
                 key = ':'.join([str(i) for i in y[:3] + ['INS']])
                 ins_pos = '_'.join([str(i) for i in y[:2]])
@@ -290,7 +296,7 @@ def vcf_jobs(vcf_list, num_reads_cff, bam_in, ref, out_path, sample_name) -> Lis
                 fig = out_path + sample_name + '.INS.' + key.replace(':', '__') + '.png'
                 jobs.append(Job(key, (lambda p=plt_li, a=ins_pos, s=ins_seq, g=fig:
                                       drivers.vapor_simple_ins(num_reads_cff, p, bam_in, ref, a, s, g, '+')),
-                                cost=job_cost('INS', len(ins_seq))))
+                                cost=job_cost('INS', len(ins_seq)), spec=('INS', y[0], y[1], None, ins_seq), ctx=ctx))
             elif x == 'DISDUP':
                 key = ':'.join([str(i) for i in y + ['DISDUP']])
                 fig = out_path + sample_name + '.DISDUP.' + key.replace(':', '__') + '.png'
@@ -449,8 +455,29 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
     def one_chunk(a, engine=None):
         part = mine[a:a + chunk]
         todo = [t for t in part if jobs[t].make is not None]
-        res = pipeline.run_batch([jobs[t].make() for t in todo], engine=engine, figure_fn=figure_fn)
-        return part, todo, res
+        done = {}
+        if figure_fn is None and os.environ.get("VAPOR_FAST_PATH", "1") != "0":
+            # the simple types of the chunk in array form (vapor_amd.fastpath); what leaves the drivers' straight route comes
+            # back unanswered and goes the generators' way below - as everything does when figures are drawn (they need the
+            # best read as text)
+            from . import fastpath, seqio
+            by_ctx = {}
+            for t in todo:
+                j = jobs[t]
+                if j.spec is not None and j.ctx is not None:
+                    by_ctx.setdefault(j.ctx, []).append(t)
+            for ctx, ts in by_ctx.items():
+                eng = engine or pipeline.get_engine()
+                if len(ts) >= 8 and fastpath.capable(seqio.get_backend(), ctx[1], eng):
+                    got = fastpath.run(eng, [jobs[t].spec for t in ts], ctx[1], ctx[2], ctx[0])
+                    for t, r in zip(ts, got):
+                        if r is not fastpath.FALLBACK:
+                            done[t] = r
+        rest = [t for t in todo if t not in done]
+        res = pipeline.run_batch([jobs[t].make() for t in rest], engine=engine, figure_fn=figure_fn) if rest else []
+        for t, r in zip(rest, res):
+            done[t] = r
+        return part, todo, [done[t] for t in todo]
 
     starts = list(range(0, len(mine), max(chunk, 1)))
     in_flight = max(1, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "2")))

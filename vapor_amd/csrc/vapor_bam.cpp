@@ -470,13 +470,15 @@ extern "C" int vapor_chop_records(int32_t n, const int64_t* pos, const int64_t* 
 // first, input order inside one miss_bp value) for MANY regions in one call: region g looks at n_rec[g] records given as the
 // arrays of vapor_chop_records (one pointer per region), keeps what that call keeps and, when there are more than max_keep,
 // the first max_keep of them in a stable order by miss_bp.  kept_first[g] .. kept_first[g + 1] index rec_idx / q0 / miss
-// (capacity max_keep per region).  status[g] = 0, or VAPOR_E_ARG where a record without CIGAR reaches the walk (the reference
+// (capacity max_keep per region); addr_out (may be NULL) receives seq_addr[g][record] for every kept read - where the caller
+// keeps the records' sequences.  status[g] = 0, or VAPOR_E_ARG where a record without CIGAR reaches the walk (the reference
 // raises IndexError there, SF:331: the caller lets that region take the reference-named route).
 extern "C" int vapor_chop_records_many(int32_t n_regions, const int32_t* n_rec, const int64_t* const* pos,
                                        const int64_t* const* ref_span, const char* const* const* cigar,
                                        const int64_t* const* seq_len, const int64_t* start, const int64_t* end,
                                        const int64_t* flank, int32_t max_keep, int32_t* kept_first, int32_t* rec_idx,
-                                       int64_t* q0, int64_t* miss, int32_t* status)
+                                       int64_t* q0, int64_t* miss, int32_t* status, const uint64_t* const* seq_addr,
+                                       uint64_t* addr_out)
 {
     if (n_regions < 0 || max_keep < 1 || (n_regions && (!n_rec || !pos || !ref_span || !cigar || !seq_len || !start || !end || !flank ||
                                                            !kept_first || !rec_idx || !q0 || !miss || !status)))
@@ -503,7 +505,11 @@ extern "C" int vapor_chop_records_many(int32_t n_regions, const int32_t* n_rec, 
             std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qm[(size_t)2 * a + 1] < qm[(size_t)2 * b + 1]; });
             order.resize((size_t)max_keep);
         }
-        for (int32_t r : order) { rec_idx[w] = r; q0[w] = qm[(size_t)2 * r]; miss[w] = qm[(size_t)2 * r + 1]; ++w; }
+        for (int32_t r : order) {
+            rec_idx[w] = r; q0[w] = qm[(size_t)2 * r]; miss[w] = qm[(size_t)2 * r + 1];
+            if (addr_out) addr_out[w] = (seq_addr && seq_addr[g]) ? seq_addr[g][r] : 0;
+            ++w;
+        }
     }
     kept_first[n_regions] = w;
     return VAPOR_OK;

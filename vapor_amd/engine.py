@@ -121,6 +121,44 @@ class SeqSet:
         self.n_exc = info[0::2][:self.n].copy()
         self.n_invalid = info[1::2][:self.n].copy()
 
+    @classmethod
+    def from_addresses(cls, engine: "Engine", addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None) -> "SeqSet":
+        """A set whose byte sequences are given as (address, length) pairs - slices of strings and buffers the caller keeps
+        alive (`keepalive`) until this returns: a read is a slice of its record's sequence, a window a slice of its contig;
+        nothing is copied on the Python side.  `derived` as (seg_first, segs, flags) arrays."""
+        self = cls.__new__(cls)
+        self.engine = engine
+        self.n_lit = self.n = int(len(addr))
+        addr = np.ascontiguousarray(addr, dtype=np.uint64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.int32)
+        ptrs = ctypes.cast(addr.ctypes.data, ctypes.POINTER(ctypes.c_void_p))
+        h = ctypes.c_void_p()
+        lib = L.load()
+        nd = 0
+        if derived is not None:
+            seg_first, segs, dflags = derived
+            nd = len(seg_first) - 1
+        info = np.zeros(2 * max(self.n + nd, 1), dtype=np.int32)
+        lens_p = L.ptr(self.lens if self.n else np.zeros(1, np.int32), ctypes.c_int32)
+        if nd:
+            seg_first = np.ascontiguousarray(seg_first, dtype=np.int32)
+            segs = np.ascontiguousarray(segs, dtype=L.SEG_DTYPE)
+            L.check(lib.vapor_seqset_create_derived(engine._ctx, self.n, ptrs, lens_p, None, nd, L.ptr(seg_first, ctypes.c_int32),
+                                                    segs.ctypes.data_as(ctypes.c_void_p), L.ptr(np.ascontiguousarray(dflags, dtype=np.uint8), ctypes.c_uint8),
+                                                    L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+            dl = np.zeros(nd, dtype=np.int32)
+            np.add.at(dl, np.repeat(np.arange(nd), np.diff(seg_first)), segs["len"][:int(seg_first[-1])])
+            self.lens = np.concatenate([self.lens, dl])
+            self.n += nd
+        else:
+            L.check(lib.vapor_seqset_create_ptrs(engine._ctx, self.n, ptrs, lens_p, None, L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+        del keepalive
+        self._h = h
+        engine._live.add(self)
+        self.n_exc = info[0::2][:self.n].copy()
+        self.n_invalid = info[1::2][:self.n].copy()
+        return self
+
     def planes(self, idx: int):
         """(p2, e1, x4) uint32 arrays of sequence `idx` as they lie in HBM: 2, 1 and 4 words per 32-symbol chunk."""
         ch = (int(self.lens[idx]) + 31) // 32
@@ -259,6 +297,10 @@ class Engine:
 
     def seqset(self, seqs: Sequence, upper: Optional[Sequence[bool]] = None, derived=None) -> SeqSet:
         return SeqSet(self, seqs, upper, derived)
+
+    def seqset_raw(self, addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None) -> SeqSet:
+        """A set from (address, length) pairs - slices of strings the caller keeps alive - and derived sequences as arrays."""
+        return SeqSet.from_addresses(self, addr, lens, derived, keepalive)
 
     def plan(self, seqset: SeqSet, pairs: np.ndarray) -> Plan:
         return Plan(self, seqset, pairs)

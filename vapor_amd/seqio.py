@@ -284,6 +284,56 @@ class MemorySamtools:
             out.append([r.seq[q0:q0 + (end - start - miss)] if q0 >= 0 else r.seq[q0:][:end - start - miss], miss, r.qname])
         return out
 
+    def chop_many(self, bam: str, chroms, starts, ends, flanks, max_keep: int = 20):
+        """chop_pacbio_read_by_pos (SF:339-354) + minimize_pacbio_read_list (SF:1091-1102) for many regions in ONE native call
+        (vapor_chop_records_many): per region its kept reads as numbers, not as lists of strings -
+        (kept_first [n + 1], addr, q0, miss, status [n], keepalive): read t of region g (kept_first[g] <= t < kept_first[g + 1])
+        is the `end - start - miss[t]` bytes at address addr[t] + q0[t] (inside the record's own sequence string, which
+        `keepalive` holds); status[g] != 0: the region needs the per-record route (a record without CIGAR, a record whose
+        sequence is not ASCII text)."""
+        import ctypes
+        import numpy as np
+        from . import _lib
+        from .engine import _ASCII_OFF
+        n = len(chroms)
+        # per contig, once: (records, pos*, span*, cigar**, seq_len*, addresses of the records' sequences or None)
+        per = self.__dict__.setdefault("_many_cache", {})
+
+        def entry(c):
+            recs, arrs, p, keep, _cnt = self._arrays(c)
+            ok = 0 < _ASCII_OFF < 256 and all(type(r.seq) is str and r.seq.isascii() for r in recs)
+            sa_c = (np.fromiter(map(id, (r.seq for r in recs)), dtype=np.uint64, count=len(recs)) + np.uint64(_ASCII_OFF)) if ok else None
+            e = per[c] = (len(recs), p[0], p[1], p[2], p[3], sa_c, recs)
+            return e
+        ent = [per.get(c) or entry(c) for c in chroms]
+        for g, e in enumerate(ent):                            # (a contig whose record list was replaced since)
+            if e[6] is not self.world.reads.get(chroms[g], ()) or e[0] != len(e[6]):
+                ent[g] = entry(chroms[g])
+        n_rec = np.fromiter((e[0] for e in ent), dtype=np.int32, count=n)
+        ptr = np.asarray([(e[1], e[2], e[3], e[4]) for e in ent], dtype=np.uint64).reshape(n, 4).T.copy()
+        sa_ptr = np.fromiter((e[5].ctypes.data if e[5] is not None else 0 for e in ent), dtype=np.uint64, count=n)
+        bad = np.fromiter((e[5] is None and e[0] > 0 for e in ent), dtype=bool, count=n)
+        cap = max_keep * max(n, 1)
+        kept_first = np.zeros(n + 1, dtype=np.int32)
+        rec_idx = np.zeros(cap, dtype=np.int32)
+        q0 = np.zeros(cap, dtype=np.int64)
+        miss = np.zeros(cap, dtype=np.int64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        addr = np.zeros(cap, dtype=np.uint64)
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        en = np.ascontiguousarray(ends, dtype=np.int64)
+        fl = np.ascontiguousarray(flanks, dtype=np.int64)
+        rc = _lib.load().vapor_chop_records_many(n, n_rec.ctypes.data, ptr[0].ctypes.data, ptr[1].ctypes.data, ptr[2].ctypes.data,
+                                                 ptr[3].ctypes.data, st.ctypes.data, en.ctypes.data, fl.ctypes.data, max_keep,
+                                                 kept_first.ctypes.data, rec_idx.ctypes.data, q0.ctypes.data, miss.ctypes.data,
+                                                 status.ctypes.data, sa_ptr.ctypes.data, addr.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(_lib.load().vapor_bam_last_error().decode())
+        tot = int(kept_first[n])
+        addr = addr[:tot]
+        status[:n][bad] = -1
+        return kept_first, addr, q0[:tot], miss[:tot], status[:n], self.world
+
     def isfile(self, path: str) -> bool:
         return True
 
