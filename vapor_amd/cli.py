@@ -479,10 +479,13 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
             done[t] = r
         return part, todo, [done[t] for t in todo]
 
-    starts = list(range(0, len(mine), max(chunk, 1)))
     in_flight = max(1, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "2")))
     if in_flight >= 2 and not _chunk_threads_ok():
         in_flight = 1
+    if in_flight >= 2 and 256 <= len(mine) <= chunk:
+        chunk = -(-len(mine) // 2)          # a share of one chunk: two halves, so that both threads have one (the native half of a
+                                            # chunk's work - read selection, upload, planning, kernels - runs beside the other's Python)
+    starts = list(range(0, len(mine), max(chunk, 1)))
     if len(starts) >= 2 and in_flight >= 2:
         # Two chunks in flight (the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage): each on a thread
         # with a library context of its own (one host thread per context), so that the host preparation of one chunk - allele

@@ -483,31 +483,54 @@ extern "C" int vapor_chop_records_many(int32_t n_regions, const int32_t* n_rec, 
     if (n_regions < 0 || max_keep < 1 || (n_regions && (!n_rec || !pos || !ref_span || !cigar || !seq_len || !start || !end || !flank ||
                                                            !kept_first || !rec_idx || !q0 || !miss || !status)))
         return bfail(VAPOR_E_ARG, "vapor_chop_records_many: null argument");
-    std::vector<int64_t> qm;
-    std::vector<uint8_t> keep;
-    std::vector<int32_t> order;
+    // every region into slots of its own (max_keep of them), on a few threads when there are many regions; then packed
+    std::vector<int32_t> cnt((size_t)n_regions, 0), t_rec((size_t)n_regions * max_keep);
+    std::vector<int64_t> t_q0((size_t)n_regions * max_keep), t_miss((size_t)n_regions * max_keep);
+    auto work = [&](int32_t g0, int32_t g1) {
+        std::vector<int64_t> qm;
+        std::vector<uint8_t> keep;
+        std::vector<int32_t> order;
+        for (int32_t g = g0; g < g1; ++g) {
+            status[g] = 0;
+            const int32_t n = n_rec[g];
+            if (n <= 0) continue;
+            qm.resize((size_t)2 * n);
+            keep.resize((size_t)n);
+            if (vapor_chop_records(n, pos[g], ref_span[g], cigar[g], seq_len[g], start[g], end[g], flank[g], qm.data(), keep.data()) != VAPOR_OK) {
+                status[g] = VAPOR_E_ARG;
+                continue;
+            }
+            order.clear();
+            for (int32_t r = 0; r < n; ++r)
+                if (keep[(size_t)r]) order.push_back(r);
+            if ((int32_t)order.size() > max_keep) {
+                std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qm[(size_t)2 * a + 1] < qm[(size_t)2 * b + 1]; });
+                order.resize((size_t)max_keep);
+            }
+            int32_t c = 0;
+            for (int32_t r : order) {
+                const size_t o = (size_t)g * max_keep + (size_t)c++;
+                t_rec[o] = r; t_q0[o] = qm[(size_t)2 * r]; t_miss[o] = qm[(size_t)2 * r + 1];
+            }
+            cnt[(size_t)g] = c;
+        }
+    };
+    const int n_thr = n_regions >= 512 ? 4 : 1;
+    if (n_thr == 1) {
+        work(0, n_regions);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; ++t)
+            th.emplace_back(work, (int32_t)((int64_t)n_regions * t / n_thr), (int32_t)((int64_t)n_regions * (t + 1) / n_thr));
+        for (auto& x : th) x.join();
+    }
     int32_t w = 0;
     for (int32_t g = 0; g < n_regions; ++g) {
         kept_first[g] = w;
-        status[g] = 0;
-        const int32_t n = n_rec[g];
-        if (n <= 0) continue;
-        qm.resize((size_t)2 * n);
-        keep.resize((size_t)n);
-        if (vapor_chop_records(n, pos[g], ref_span[g], cigar[g], seq_len[g], start[g], end[g], flank[g], qm.data(), keep.data()) != VAPOR_OK) {
-            status[g] = VAPOR_E_ARG;
-            continue;
-        }
-        order.clear();
-        for (int32_t r = 0; r < n; ++r)
-            if (keep[(size_t)r]) order.push_back(r);
-        if ((int32_t)order.size() > max_keep) {
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qm[(size_t)2 * a + 1] < qm[(size_t)2 * b + 1]; });
-            order.resize((size_t)max_keep);
-        }
-        for (int32_t r : order) {
-            rec_idx[w] = r; q0[w] = qm[(size_t)2 * r]; miss[w] = qm[(size_t)2 * r + 1];
-            if (addr_out) addr_out[w] = (seq_addr && seq_addr[g]) ? seq_addr[g][r] : 0;
+        for (int32_t c = 0; c < cnt[(size_t)g]; ++c) {
+            const size_t o = (size_t)g * max_keep + (size_t)c;
+            rec_idx[w] = t_rec[o]; q0[w] = t_q0[o]; miss[w] = t_miss[o];
+            if (addr_out) addr_out[w] = (seq_addr && seq_addr[g]) ? seq_addr[g][t_rec[o]] : 0;
             ++w;
         }
     }
