@@ -530,32 +530,35 @@ def inclusive_rate(eng, w, wl, reps: int = 6):
     for _ in range(reps):
         times.append(batch(eng, parts)[0])
     t_one = float(np.median(times))
-    # two batches in flight
-    eng2 = Engine(eng.device)
-    batch(eng2)
-    n_each = max(reps, 6)
-    recs = [None, None]
+    # several batches in flight: as many as cli.score_jobs keeps chunks of a run in flight (VAPOR_CHUNKS_IN_FLIGHT, default 3)
+    n_fl = max(2, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "3")))
+    more = [Engine(eng.device) for _ in range(n_fl - 1)]
+    for e in more:
+        batch(e)
+    n_each = max(reps, 8)
+    recs = [None] * n_fl
 
     def worker(k, e):
         for _ in range(n_each):
             recs[k] = batch(e)[1].copy()
-    th = [threading.Thread(target=worker, args=(k, e)) for k, e in enumerate((eng, eng2))]
+    th = [threading.Thread(target=worker, args=(k, e)) for k, e in enumerate([eng] + more)]
     t0 = time.perf_counter()
     for x in th:
         x.start()
     for x in th:
         x.join()
-    t_two = (time.perf_counter() - t0) / (2 * n_each)
-    same = np.array_equal(np.isnan(recs[0]), np.isnan(recs[1])) and np.array_equal(recs[0][~np.isnan(recs[0])], recs[1][~np.isnan(recs[1])])
-    eng2.close()
-    return {"value": round(w.n_loci / t_two, 2), "unit": "loci/s", "batches_in_flight": 2, "ms_per_batch_in_flight": round(t_two * 1e3, 3),
+    t_two = (time.perf_counter() - t0) / (n_fl * n_each)
+    same = all(np.array_equal(np.isnan(recs[0]), np.isnan(r)) and np.array_equal(recs[0][~np.isnan(recs[0])], r[~np.isnan(r)]) for r in recs[1:])
+    for e in more:
+        e.close()
+    return {"value": round(w.n_loci / t_two, 2), "unit": "loci/s", "batches_in_flight": n_fl, "ms_per_batch_in_flight": round(t_two * 1e3, 3),
             "one_at_a_time": {"value": round(w.n_loci / t_one, 2), "ms_per_batch": round(t_one * 1e3, 3),
                               "ms": dict(zip(("upload_pack", "window_selfplots", "plan", "join_clean_finish"), [round(x / reps * 1e3, 3) for x in parts]))},
             "records_equal": bool(same),
             "includes": "host bytes -> pinned staging -> H2D -> pack_kernel (the alt windows travel as segment descriptors and are assembled by "
                         "derive_kernel); %d self dot plots (k = 10) for window_size_refine's integer part; vapor_plan_create + set_reads; one "
-                        "blocking join -> remap -> clean -> finish; records to host.  `value`: %d batches on each of two threads, a library context "
-                        "each (the way cli.score_jobs keeps two chunks of a run in flight); `one_at_a_time`: median of %d batches" % (len(allele_idx), n_each, reps)}
+                        "blocking join -> remap -> clean -> finish; records to host.  `value`: %d batches on each of %d threads, a library context "
+                        "each (the way cli.score_jobs keeps chunks of a run in flight); `one_at_a_time`: median of %d batches" % (len(allele_idx), n_each, n_fl, reps)}
 
 
 def pipeline_rate(n_loci: int = 400):

@@ -479,12 +479,13 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
             done[t] = r
         return part, todo, [done[t] for t in todo]
 
-    in_flight = max(1, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "2")))
+    in_flight = max(1, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "3")))
     if in_flight >= 2 and not _chunk_threads_ok():
         in_flight = 1
     if in_flight >= 2 and 256 <= len(mine) <= chunk:
-        chunk = -(-len(mine) // 2)          # a share of one chunk: two halves, so that both threads have one (the native half of a
-                                            # chunk's work - read selection, upload, planning, kernels - runs beside the other's Python)
+        # a share of one chunk: in halves (thirds from 1 536 loci on), so that every thread has one - the native half of a
+        # chunk's work (read selection, upload, planning, kernels) runs beside the others' Python
+        chunk = -(-len(mine) // (min(in_flight, 3) if len(mine) >= 1536 else 2))
     starts = list(range(0, len(mine), max(chunk, 1)))
     if len(starts) >= 2 and in_flight >= 2:
         # Two chunks in flight (the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage): each on a thread

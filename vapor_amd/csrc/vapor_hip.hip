@@ -21,6 +21,7 @@
 #include <thread>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <vector>
 
 using namespace vapor;
@@ -92,6 +93,8 @@ struct vapor_ctx {
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
     bool shared_join = true;                   // reads scored against a window and alleles derived from it: one join for all
+    int stage_threads = 3;                     // host threads that copy a large upload into the pinned staging buffer (measured:
+                                               // two to four are as fast as it gets, more are slower - tools/upload_sweep.py)
     bool attrs_set = false;
     BlockPool pool;
 };
@@ -346,6 +349,11 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
         c->shared_join = v != 0;
         return VAPOR_OK;
     }
+    if (!strcmp(name, "stage_threads")) {
+        if (v < 1 || v > 64) return fail(VAPOR_E_ARG, "stage_threads out of range");
+        c->stage_threads = (int)v;
+        return VAPOR_OK;
+    }
     return fail(VAPOR_E_ARG, std::string("unknown parameter ") + name);
 }
 
@@ -448,6 +456,9 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
                               const vapor_segment* segs = nullptr, const uint8_t* derived_flags = nullptr)
 {
     HIPCHK(hipSetDevice(ctx->device));
+    const bool dbg_t = getenv("VAPOR_DEBUG_UPLOAD") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq[8] = {now(), 0, 0, 0, 0, 0, 0, 0};
     vapor_seqset* s = new (std::nothrow) vapor_seqset();
     if (!s) return fail(VAPOR_E_NOMEM, "out of memory");
     s->ctx = ctx;
@@ -521,6 +532,7 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
     s->plane_chunks = pl;
     const size_t n_asc = asc;
     int rc = VAPOR_OK;
+    tq[1] = now();
 #define SS_CHK(expr)                                                                               \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
@@ -570,7 +582,8 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         SS_CHK(hipMemsetAsync(s->d_e1, 0, pl * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemcpyAsync(s->d_seqs, s->h.data(), sizeof(SeqDesc) * s->h.size(), hipMemcpyHostToDevice, ctx->stream));
-        const int n_thr = (n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? 4 : 1;
+        tq[2] = now();
+        const int n_thr = (n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? ctx->stage_threads : 1;
         if (n_thr == 1) {
             stage_range(0, n_seqs);
             if (n_asc) SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 36, hipMemcpyHostToDevice, ctx->stream));
@@ -608,6 +621,7 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
             SS_CHK(err);
             SS_CHK(hipMemcpyAsync(d_map, h_map, n_asc * 4, hipMemcpyHostToDevice, ctx->stream));
         }
+        tq[3] = now();
         if (n_asc) {
             unsigned grid = (unsigned)((n_asc + 255) / 256);
             hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_asc, s->d_seqs, n_seqs, d_map,
@@ -637,8 +651,11 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
                                (uint32_t)der_chunks, dsf, dsg, n_seqs, s->d_p2, s->d_e1, s->d_x4);
             SS_CHK(hipGetLastError());
         }
+        tq[4] = now();
         SS_CHK(hipMemcpyAsync(s->h.data(), s->d_seqs, sizeof(SeqDesc) * s->h.size(), hipMemcpyDeviceToHost, ctx->stream));
         SS_CHK(hipStreamSynchronize(ctx->stream));
+        tq[5] = now();
+        if (dbg_t) fprintf(stderr, "seqset: layout+groups %.3f  alloc+memset %.3f  stage+h2d %.3f  launches %.3f  sync %.3f ms\n", tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
         // complementary() drops what is not ATGCN / atgcn (SF:471-478): a reversed slice of a window that holds such a
         // character is not what the reference would have built
         for (size_t d = 0; d < s->derived.size() && rc == VAPOR_OK; ++d)
