@@ -33,8 +33,50 @@ def twin_rows(rec):
     return json.load(open(out))
 
 
+def twin_rows_distinct(rec, procs=4):
+    """A distinct world (tools/run_at_size.py --distinct): the sampled records alone - the same seeded tiles made again - through
+    the CLI on the CPU twin, in a few child processes; returns the rows in the sample's order."""
+    from oracle import oracle as orc
+    orc.build()
+    twin = orc.build_twin()
+    env = dict(os.environ, VAPOR_HIP_LIB=twin, VAPOR_ALLOW_TWIN="1", VAPOR_QC_SEED=str(rec["qc_seed"]),
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), VAPOR_HOST_PROCS="0", VAPOR_CHUNKS_IN_FLIGHT="1")
+    idx = [t for t, _row in rec["sample"]]
+    shares = [idx[k::procs] for k in range(procs)]
+    jobs = []
+    for k, sh in enumerate(shares):
+        if not sh:
+            continue
+        only = tempfile.mktemp(suffix=".only.json")
+        json.dump(sh, open(only, "w"))
+        out = tempfile.mktemp(suffix=".json")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), rec["config"], "--loci", str(rec["records"]), "--base", str(rec["base_loci"]),
+               "--distinct", "--only", only, "--out", out, "--all-rows", "--chunk", "256"]
+        jobs.append((sh, out, subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL)))
+    rows = {}
+    for sh, out, p in jobs:
+        assert p.wait() == 0
+        got = json.load(open(out))["sample"]
+        assert len(got) == len(sh), (len(got), len(sh))
+        for t, (_q, row) in zip(sh, got):
+            rows[t] = row
+    return rows
+
+
 def main():
     rec = json.load(open(sys.argv[1]))
+    if rec.get("distinct"):
+        tw = twin_rows_distinct(rec)
+        bad = 0
+        for t, row in rec["sample"]:
+            if tw.get(t) != row:
+                bad += 1
+                if bad <= 5:
+                    print("row %d differs:\n  gpu : %s\n  twin: %s" % (t, row[:300], (tw.get(t) or "<missing>")[:300]))
+        scored = sum(1 for _t, r in rec["sample"] if "\tNA" not in r)
+        print("%s: %d sampled rows of %d distinct loci (%d with scores) against the CPU twin's rows of the same records: %d differ"
+              % (rec["config"], len(rec["sample"]), rec["rows"], scored, bad))
+        return 1 if bad else 0
     tw = twin_rows(rec)
     strip = re.compile(r"\.t\d+")
     by_key = {}

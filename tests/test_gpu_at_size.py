@@ -25,3 +25,18 @@ def test_at_size_runner_and_twin_check(cfg, loci, base, tmp_path):
     assert rec["records"] == loci and rec["rows"] >= loci and rec["rc"] == 0 and len(rec["sample"]) >= min(loci, 400) - 1
     c = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "at_size_check.py"), out], env=env, capture_output=True, text=True, timeout=600)
     assert c.returncode == 0 and " 0 differ" in c.stdout, (c.stdout[-1500:], c.stderr[-1500:])
+
+
+def test_distinct_world_runner_and_twin_check(tmp_path):
+    """The same with a world of DISTINCT loci (every tile of the base world mutated on its own and made when it is reached,
+    synth.DistinctTilesWorld): the sampled rows equal the CPU twin's rows for the same records made again."""
+    out = str(tmp_path / "at_size_distinct.json")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), "cfg5", "--loci", "90", "--base", "15", "--distinct",
+                        "--sample", "40", "--chunk", "32", "--lru", "64", "--out", out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    assert rec["distinct"] and rec["distinct_loci"] == rec["records"] == 90 and len(rec["sample"]) == 40
+    assert len({row.split("\t", 5)[-1] for _t, row in rec["sample"] if "\tNA" not in row}) > 30          # different loci, different scores
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "at_size_check.py"), out], env=env, capture_output=True, text=True, timeout=900)
+    assert c.returncode == 0 and " 0 differ" in c.stdout, (c.stdout[-1500:], c.stderr[-1500:])

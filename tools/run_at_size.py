@@ -39,7 +39,14 @@ def main():
     os.environ["VAPOR_TIMING"] = "1"
     t0 = time.perf_counter()
     from vapor_amd.workload import at_size_input
-    big, text, n_records = at_size_input(cfg, n_total, base)
+    distinct = "--distinct" in sys.argv
+    big, text, n_records = at_size_input(cfg, n_total, base, distinct=distinct, cap=arg("--lru", 4096))
+    if "--only" in sys.argv:
+        # (tests/at_size_check.py: the sampled records of a distinct world alone, in their order)
+        only = json.load(open(sys.argv[sys.argv.index("--only") + 1]))
+        lines = text.splitlines(True)
+        text = "".join(lines[t] for t in only)
+        n_records = len(only)
     t_world = time.perf_counter() - t0
     tmp = tempfile.mkdtemp(prefix="vapor_at_size_")
     src = os.path.join(tmp, "in.bed" if cfg == "cfg5" else "in.vcf")
@@ -47,7 +54,7 @@ def main():
     seqio.set_backend(seqio.MemorySamtools(big))
     result = os.path.join(tmp, "out.vapor") if cfg == "cfg5" else src + ".vapor"
     argv = [sp["mode"], "--sv-input", src, "--reference", "ref.fa", "--pacbio-input", "x.bam", "--output-path", os.path.join(tmp, "figs"),
-            "--output-file", result, "--no-figures"]
+            "--output-file", result, "--no-figures", "--chunk", str(arg("--chunk", 2048))]
     print("%s: %d records (%d distinct loci tiled; world in %.1f s), running `vapor %s`" % (cfg, n_records, base, t_world, sp["mode"]), flush=True)
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
@@ -68,10 +75,11 @@ def main():
         sys.stdout = real_stdout
     dt = time.perf_counter() - t0
     rows = open(result).read().splitlines()
-    body = rows[1:] if rows and rows[0].startswith("#CHR") else rows
+    body = [r for r in rows if not r.startswith("#")]          # (the table's header line; the ##INFO lines of the rewritten VCF)
     rss_mb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
     rng = np.random.default_rng(1)
-    pick = list(range(len(body))) if "--all-rows" in sys.argv else sorted(rng.choice(len(body), size=min(400, len(body)), replace=False).tolist())
+    n_sample = arg("--sample", 2000 if distinct else 400)
+    pick = list(range(len(body))) if "--all-rows" in sys.argv else sorted(rng.choice(len(body), size=min(n_sample, len(body)), replace=False).tolist())
     scored = sum(1 for r in body if "\tNA\t" not in r and not r.endswith("\tNA"))
     rec = {"config": cfg, "mode": sp["mode"], "records": n_records, "rows": len(body), "rows_with_scores": scored, "base_loci": base,
            "n_reads_per_locus": sp["n_reads"], "read_len": sp["read_len"], "seed": sp["seed"], "seconds": round(dt, 3),
@@ -81,7 +89,15 @@ def main():
            # windows that met the reference's unseeded X-means: `one_cluster` outcomes are the reference's
            # answer under any seed; `sizes_decide` counts the windows where the cluster sizes could change the window size at all
            "xmeans_windows": dict(pipeline.qc_counts),
-           "note": "one process, one GPU, in-memory world, figures off; tiles repeat the base loci under alias contig names"}
+           "distinct": distinct, "distinct_loci": (n_records if distinct else base),
+           "note": ("one process, one GPU, figures off; every tile of the base world carries its own substitutions in contigs, reads and "
+                    "insertion payloads and is made when a chunk reaches it (synth.DistinctTilesWorld): as many distinct loci as "
+                    "records; the time includes making them" if distinct else
+                    "one process, one GPU, in-memory world, figures off; tiles repeat the base loci under alias contig names")}
+    if distinct:
+        parts = getattr(big, "parts", [big])
+        rec["tile_generation"] = {"contigs_made": sum(p_.contigs.made for p_ in parts), "read_lists_made": sum(p_.reads.made for p_ in parts),
+                                  "seconds_inside_the_run": round(sum(p_.contigs.seconds + p_.reads.seconds for p_ in parts), 2)}
     json.dump(rec, open(out, "w"))
     print(json.dumps({k: v for k, v in rec.items() if k != "sample"}), flush=True)
 

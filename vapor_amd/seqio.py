@@ -239,7 +239,8 @@ class MemorySamtools:
         cache = self.__dict__.setdefault("_chop_cache", {})
         recs = self.world.reads.get(chrom, ())
         key = id(recs)                       # (contigs that share one record list - tiled worlds - share its arrays)
-        got = cache.get(key)
+        keep_it = getattr(self.world, "cache_ok", True)      # (a world that makes its record lists on demand: nothing is kept)
+        got = cache.get(key) if keep_it else None
         if got is None or got[0] is not recs or got[4] != len(recs):
             import ctypes
             import numpy as np
@@ -253,7 +254,8 @@ class MemorySamtools:
             got = (recs, arrs, (arrs[0].ctypes.data, arrs[1].ctypes.data, ctypes.addressof(ptrs), arrs[2].ctypes.data), (cig, ptrs), len(recs))
             if len(cache) > 200000:
                 cache.clear()
-            cache[key] = got
+            if keep_it:
+                cache[key] = got
         return got
 
     def chop(self, bam: str, chrom: str, start: int, end: int, flank_length):
@@ -297,18 +299,21 @@ class MemorySamtools:
         from .engine import _ASCII_OFF
         n = len(chroms)
         # per contig, once: (records, pos*, span*, cigar**, seq_len*, addresses of the records' sequences or None)
-        per = self.__dict__.setdefault("_many_cache", {})
+        keep_it = getattr(self.world, "cache_ok", True)
+        per = self.__dict__.setdefault("_many_cache", {}) if keep_it else {}
 
         def entry(c):
             recs, arrs, p, keep, _cnt = self._arrays(c)
             ok = 0 < _ASCII_OFF < 256 and all(type(r.seq) is str and r.seq.isascii() for r in recs)
             sa_c = (np.fromiter(map(id, (r.seq for r in recs)), dtype=np.uint64, count=len(recs)) + np.uint64(_ASCII_OFF)) if ok else None
-            e = per[c] = (len(recs), p[0], p[1], p[2], p[3], sa_c, recs)
+            # (the arrays behind the pointers travel with the entry: they live as long as it does)
+            e = per[c] = (len(recs), p[0], p[1], p[2], p[3], sa_c, recs, arrs, keep)
             return e
         ent = [per.get(c) or entry(c) for c in chroms]
-        for g, e in enumerate(ent):                            # (a contig whose record list was replaced since)
-            if e[6] is not self.world.reads.get(chroms[g], ()) or e[0] != len(e[6]):
-                ent[g] = entry(chroms[g])
+        if keep_it:
+            for g, e in enumerate(ent):                        # (a contig whose record list was replaced since)
+                if e[6] is not self.world.reads.get(chroms[g], ()) or e[0] != len(e[6]):
+                    ent[g] = entry(chroms[g])
         n_rec = np.fromiter((e[0] for e in ent), dtype=np.int32, count=n)
         ptr = np.asarray([(e[1], e[2], e[3], e[4]) for e in ent], dtype=np.uint64).reshape(n, 4).T.copy()
         sa_ptr = np.fromiter((e[5].ctypes.data if e[5] is not None else 0 for e in ent), dtype=np.uint64, count=n)
@@ -332,13 +337,14 @@ class MemorySamtools:
         tot = int(kept_first[n])
         addr = addr[:tot]
         status[:n][bad] = -1
-        return kept_first, addr, q0[:tot], miss[:tot], status[:n], self.world
+        return kept_first, addr, q0[:tot], miss[:tot], status[:n], ent      # (the entries hold the records the addresses point into)
 
     def isfile(self, path: str) -> bool:
         return True
 
     def fai_lines(self, ref: str) -> Iterable[str]:
-        return ["%s\t%d\t0\t60\t61" % (k, len(v)) for k, v in self.world.contigs.items()]
+        rows = self.world.fai_rows() if hasattr(self.world, "fai_rows") else [(k, len(v)) for k, v in self.world.contigs.items()]
+        return ["%s\t%d\t0\t60\t61" % (k, n) for k, n in rows]
 
 
 def _env_is(name: bytes, value: bytes) -> bool:

@@ -541,3 +541,106 @@ def write_world_files(world: SynthWorld, directory: str, block_size: int = 8192)
     bam = os.path.join(directory, "reads.bam")
     bamio.write_bam(bam, [(n, len(world.contigs[n])) for n in names], recs, block_size=block_size)
     return fa, bam
+
+
+# ---------------------------------------------------------------------------
+# at-size worlds of DISTINCT loci without holding them: tiles of a base world, every tile mutated on its own
+# ---------------------------------------------------------------------------
+_NEXT_BASE = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgt", b"CGTAcgta"):
+    _NEXT_BASE[_a] = _b
+
+
+def _mutated(text: str, rng, rate: float = 0.002) -> str:
+    """`text` with one base in five hundred replaced by the next one of A -> C -> G -> T -> A (case kept, other symbols
+    kept): another sequence of the same length and structure."""
+    a = np.frombuffer(text.encode("ascii"), dtype=np.uint8).copy()
+    if len(a):
+        pos = rng.integers(0, len(a), size=max(1, int(len(a) * rate)))
+        a[pos] = _NEXT_BASE[a[pos]]
+    return a.tobytes().decode("ascii")
+
+
+class _LazyTiles:
+    """Mapping `<base name>.t<k>` -> the base world's entry, mutated for tile k when it is asked for; the last `cap` answers are
+    kept (a chunk's loci are neighbours).  Stands in for SynthWorld.contigs / .reads."""
+
+    def __init__(self, base: dict, n_tiles: int, make, cap: int):
+        from collections import OrderedDict
+        self.base, self.n_tiles, self.make, self.cap = base, n_tiles, make, cap
+        self.lru = OrderedDict()
+        import threading
+        self.lock = threading.Lock()
+        self.made = 0
+        self.seconds = 0.0
+
+    def _split(self, name):
+        b, _, k = name.rpartition(".t")
+        return (b, int(k)) if b in self.base and k.isdigit() and int(k) < self.n_tiles else (None, -1)
+
+    def __contains__(self, name):
+        return self._split(name)[0] is not None
+
+    def __getitem__(self, name):
+        with self.lock:
+            got = self.lru.get(name)
+            if got is not None:
+                self.lru.move_to_end(name)
+                return got
+        b, k = self._split(name)
+        if b is None:
+            raise KeyError(name)
+        import time
+        t0 = time.perf_counter()
+        got = self.make(b, k)
+        with self.lock:
+            self.seconds += time.perf_counter() - t0
+            self.made += 1
+            self.lru[name] = got
+            while len(self.lru) > self.cap:
+                self.lru.popitem(last=False)
+        return got
+
+    def get(self, name, default=None):
+        try:
+            return self[name]
+        except KeyError:
+            return default
+
+    def __len__(self):
+        return len(self.base) * self.n_tiles
+
+
+class DistinctTilesWorld(SynthWorld):
+    """`n_tiles` copies of a base world under the contig names `<c>.t<k>`, every copy with its own substitutions in contigs,
+    reads and insertion payloads (seeded by tile and contig): as many DISTINCT loci as records, generated when a locus is
+    reached and dropped again, so that a 50 000-locus world of 30 kb reads never lies in memory (BASELINE configs[3], [4])."""
+    cache_ok = False                   # (backends must not keep per-contig caches of this world: they would keep the world)
+
+    def __init__(self, base: SynthWorld, n_tiles: int, seed: int, cap: int = 1024):
+        super().__init__()
+        import zlib
+        self.base_world, self.n_tiles, self.seed = base, n_tiles, seed
+
+        def rng_of(name, k, what):
+            return np.random.default_rng([seed, k, zlib.crc32(name.encode()), what])
+
+        def contig(b, k):
+            return _mutated(base.contigs[b], rng_of(b, k, 0))
+
+        def reads(b, k):
+            rng = rng_of(b, k, 1)
+            return [SamRecord(r.qname, "%s.t%d" % (r.rname, k), r.pos, r.cigar, _mutated(r.seq, rng), r.ref_span) for r in base.reads.get(b, [])]
+        self.contigs = _LazyTiles(base.contigs, n_tiles, contig, cap)
+        self.reads = _LazyTiles(base.reads, n_tiles, reads, cap)
+        self._rng_of = rng_of
+
+    def tile_locus(self, l: Locus, k: int) -> Locus:
+        extra = dict(l.extra) if l.extra else None
+        if extra and "insert_chrom" in extra:
+            extra["insert_chrom"] = "%s.t%d" % (extra["insert_chrom"], k)
+        ins = _mutated(l.ins_seq, self._rng_of(l.chrom, k, 2)) if l.ins_seq and "X" not in l.ins_seq else l.ins_seq
+        return Locus("%s.t%d" % (l.chrom, k), l.svtype, l.start, l.end, "%s.t%d" % (l.svid, k), ins, extra)
+
+    def fai_rows(self):
+        return [("%s.t%d" % (c, k), len(v)) for k in range(self.n_tiles) for c, v in self.base_world.contigs.items()]

@@ -244,9 +244,13 @@ def at_size_tile(w, n_total, text_of):
     return big, "".join(lines), per
 
 
-def at_size_input(cfg: str, n_total: int, base: int):
-    """(world, input text, records) of an at-size run: the tiled world and its BED (cfg5) or header-less VCF (cfg4)."""
+def at_size_input(cfg: str, n_total: int, base: int, distinct: bool = False, cap: int = 2048):
+    """(world, input text, records) of an at-size run: the tiled world and its BED (cfg5) or header-less VCF (cfg4).
+    distinct: every tile mutated on its own and made when it is reached (synth.DistinctTilesWorld): as many distinct loci as
+    records, without the world ever lying in memory."""
     w, cx = at_size_base_world(cfg, base)
+    if distinct:
+        return _at_size_distinct(cfg, n_total, w, cx, cap)
     if cfg == "cfg5":
         big, text, _ = at_size_tile(w, n_total, synth.bed_text)
     else:
@@ -257,3 +261,68 @@ def at_size_input(cfg: str, n_total: int, base: int):
         big.contigs.update(b2.contigs); big.reads.update(b2.reads); big.loci += b2.loci
         text = t1 + t2
     return big, text, text.count("\n")
+
+
+def _at_size_distinct(cfg, n_total, w, cx, cap):
+    seed = AT_SIZE[cfg]["seed"]
+    worlds = [(w, n_total if cfg == "cfg5" else n_total - n_total // 3, synth.bed_text if cfg == "cfg5" else (lambda s: synth.vcf_text(s, header=False)))]
+    if cfg != "cfg5":
+        worlds.append((cx, n_total // 3, lambda s: synth.complex_vcf_text(s, header=False)))
+    big = synth.SynthWorld()
+    parts = []
+    texts = []
+    for base_w, want, text_of in worlds:
+        per = len(base_w.loci)
+        n_tiles = -(-want // per)
+        dw = synth.DistinctTilesWorld(base_w, n_tiles, seed, cap)
+        parts.append(dw)
+        left = want
+        for k in range(n_tiles):
+            sub = synth.SynthWorld()
+            sub.loci = [dw.tile_locus(l, k) for l in base_w.loci[:left]]
+            left -= len(sub.loci)
+            big.loci += sub.loci
+            texts.append(text_of(sub))
+    if len(parts) == 1:
+        parts[0].loci = big.loci
+        return parts[0], "".join(texts), "".join(texts).count("\n")
+    merged = _MergedWorld(parts)
+    merged.loci = big.loci
+    text = "".join(texts)
+    return merged, text, text.count("\n")
+
+
+class _MergedWorld(synth.SynthWorld):
+    """Two lazily tiled worlds behind one set of contig names (cfg4: simple and complex records)."""
+    cache_ok = False
+
+    class _Both:
+        def __init__(self, maps):
+            self.maps = maps
+
+        def __contains__(self, k):
+            return any(k in m for m in self.maps)
+
+        def __getitem__(self, k):
+            for m in self.maps:
+                if k in m:
+                    return m[k]
+            raise KeyError(k)
+
+        def get(self, k, d=None):
+            for m in self.maps:
+                if k in m:
+                    return m[k]
+            return d
+
+        def __len__(self):
+            return sum(len(m) for m in self.maps)
+
+    def __init__(self, parts):
+        super().__init__()
+        self.parts = parts
+        self.contigs = self._Both([p.contigs for p in parts])
+        self.reads = self._Both([p.reads for p in parts])
+
+    def fai_rows(self):
+        return [r for p in self.parts for r in p.fai_rows()]
