@@ -98,3 +98,43 @@ def test_array_route_leaves_what_is_not_straight_to_the_drivers(fake):
     got = fastpath.run(fake, specs, "x.bam", "ref.fa", 3)
     assert all(got[t] is fastpath.FALLBACK for t in range(4))
     assert all(isinstance(got[t], list) for t in range(4, 10))
+
+
+def test_bam_files_through_the_array_route(fake, tmp_path):
+    """The same from FASTA/BAM files: the in-process reader's chop_many (every region through the library's native BAM reader,
+    the kept reads as slices of one text per region) gives the reads chop() gives, and the two routes write the same table."""
+    w = synth.make_world(seed=51, n_loci=18, svtypes=("DEL", "INV", "INS", "TANDUP", "DEL"), span_range=(80, 1500), read_len=5200, n_reads=24)
+    for c in w.reads:
+        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+    fa, bam = synth.write_world_files(w, str(tmp_path), block_size=0xFF00)
+    be = seqio.InProcessBam()
+    seqio.set_backend(be)
+    # the read selection itself: numbers against the lists of the per-locus call (more than 20 candidates: the 20 smallest miss_bp)
+    import ctypes
+    loci = w.loci
+    starts = [l.start - 300 for l in loci]
+    ends = [l.start + 300 for l in loci]
+    kf, addr, q0, miss, status, keep = be.chop_many(bam, [l.chrom for l in loci], starts, ends, [300] * len(loci))
+    assert status.tolist() == [0] * len(loci)
+    for g, l in enumerate(loci):
+        want = seqio.minimize_pacbio_read_list(be.chop(bam, l.chrom, starts[g], ends[g], 300))
+        got = [[ctypes.string_at(int(addr[t] + q0[t]), ends[g] - starts[g] - int(miss[t])).decode(), int(miss[t])] for t in range(kf[g], kf[g + 1])]
+        assert got == [[x[0], x[1]] for x in want], g
+    assert int(kf[-1]) > 100
+    bed = tmp_path / "in.bed"
+    bed.write_text(synth.bed_text(w))
+    tables = {}
+    for fast in ("1", "0"):
+        out = tmp_path / ("out%s.vapor" % fast)
+        os.environ["VAPOR_FAST_PATH"] = fast
+        os.environ["VAPOR_QC_SEED"] = "7"
+        n0 = getattr(fake, "raw_sets", 0)
+        try:
+            assert cli.main(["bed", "--sv-input", str(bed), "--reference", fa, "--pacbio-input", bam,
+                             "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+        finally:
+            os.environ.pop("VAPOR_FAST_PATH", None)
+            os.environ.pop("VAPOR_QC_SEED", None)
+        tables[fast] = out.read_text()
+        assert (getattr(fake, "raw_sets", 0) > n0) == (fast == "1")
+    assert tables["1"] == tables["0"] and tables["1"].count("\n") == 19 and "\tNA" not in tables["1"].split("\n", 1)[1][:2000]

@@ -283,6 +283,24 @@ class BamFile:
             with self._lock:
                 self._free.append(tl)
 
+    def chop_native_raw(self, chrom: str, start: int, end: int, flank_length: int):
+        """chop_native's answer as numbers: (text, offsets, lengths, miss_bp) - read r is text[offsets[r] : offsets[r] + lengths[r]]
+        - for callers that hand the reads on by address (vapor_amd.fastpath) instead of making a string per read."""
+        from . import _lib
+        lib = _lib.load()
+        tid = self.tid.get(chrom)
+        if tid is None:
+            return None
+        ch = self.index.chunks(tid, max(int(start) - 1, 0), int(end))
+        if not ch:
+            return None
+        tl = self._take_handle(lib)
+        try:
+            return self._chop_with(lib, tl, tid, ch, start, end, flank_length, raw=True)
+        finally:
+            with self._lock:
+                self._free.append(tl)
+
     def _take_handle(self, lib):
         """A native handle with its output buffers, for the duration of one call: from the free list, else a new one.
         (Handles are not tied to threads: a pool of threads that lives for one batch would leave its handles - a file
@@ -303,7 +321,7 @@ class BamFile:
             self._handles.append(h)
         return tl
 
-    def _chop_with(self, lib, tl, tid, ch, start, end, flank_length):
+    def _chop_with(self, lib, tl, tid, ch, start, end, flank_length, raw=False):
         import ctypes
         from . import _lib
         chunks = np.asarray(ch, dtype=np.uint64).reshape(-1)
@@ -325,7 +343,11 @@ class BamFile:
                          "names": ctypes.create_string_buffer(int(need[1]) * 2 + 256),
                          "meta": np.empty(4 * (int(need[2]) * 2 + 16), dtype=np.int64), "need": need}
         if n.value == 0:
-            return []
+            return None if raw else []
+        if raw:
+            meta = bf["meta"][:4 * n.value].reshape(-1, 4).copy()
+            whole = bf["seq"][:int((meta[:, 0] + meta[:, 1]).max())].tobytes().decode("ascii")
+            return whole, meta[:, 0], meta[:, 1], meta[:, 2]
         # (one conversion of the numbers, one of the bases: this runs under the interpreter lock on every pool thread)
         m = bf["meta"][:4 * n.value].tolist()
         whole = bf["seq"][:max(m[4 * r] + m[4 * r + 1] for r in range(n.value))].tobytes().decode("ascii")

@@ -78,7 +78,10 @@ def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: in
     if len(idx) == 0:
         return out
     chroms = [specs[t][1] for t in idx.tolist()]
-    kf, addr, q0, miss, status, keepalive = be.chop_many(bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
+    try:
+        kf, addr, q0, miss, status, keepalive = be.chop_many(bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
+    except NotImplementedError:
+        return out
     n_reads = np.diff(kf).astype(np.int64)
     # (a read that starts before its record: Python's negative slice - the drivers' way)
     neg = np.zeros(len(idx), dtype=bool)

@@ -145,6 +145,56 @@ class InProcessBam(SamtoolsHybrid):
             return self._open(bam).chop_native(chrom, int(start), int(end), int(flank_length))
         return self.chop_python(bam, chrom, start, end, flank_length)
 
+    def chop_many(self, bam: str, chroms, starts, ends, flanks, max_keep: int = 20):
+        """MemorySamtools.chop_many's contract from a BAM file: every region through the library's native reader (vapor_bam_chop:
+        threaded inflate, binary CIGAR walk, only the kept bases decoded) on a few threads, the kept reads of a region as slices
+        of ONE text per region - (kept_first, addr, q0 = 0, miss, status, keepalive).  minimize_pacbio_read_list (SF:1091-1102)
+        on the numbers: the first max_keep in a stable order by miss_bp."""
+        import numpy as np
+        from .engine import _ASCII_OFF
+        if _env_is(b"VAPOR_BAM_NATIVE", b"0") or not (0 < _ASCII_OFF < 256):
+            raise NotImplementedError("chop_many needs the native reader")
+        n = len(chroms)
+        b = self._open(bam)
+        st, en, fl = [int(x) for x in starts], [int(x) for x in ends], [int(x) for x in flanks]
+
+        def one(g):
+            try:
+                return b.chop_native_raw(chroms[g], st[g], en[g], fl[g])
+            except IndexError:
+                return IndexError                       # (a record without CIGAR: the drivers' route raises it where the reference does)
+        from . import pipeline
+        n_thr = pipeline._prefetch_threads(n)
+        if n_thr > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=n_thr) as pool:
+                got = list(pool.map(one, range(n), chunksize=max(1, n // (n_thr * 8))))
+        else:
+            got = [one(g) for g in range(n)]
+        kept_first = np.zeros(n + 1, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        pa, pm, keep = [], [], []
+        w = 0
+        for g, r in enumerate(got):
+            kept_first[g] = w
+            if r is IndexError:
+                status[g] = -4
+                continue
+            if r is None:
+                continue
+            whole, off, ln, miss = r
+            order = np.arange(len(off))
+            if len(order) > max_keep:
+                order = np.argsort(miss, kind="stable")[:max_keep]
+            keep.append(whole)
+            pa.append((off[order] + (id(whole) + _ASCII_OFF)).astype(np.uint64))
+            pm.append(miss[order])
+            w += len(order)
+        kept_first[n] = w
+        addr = np.concatenate(pa) if pa else np.zeros(0, dtype=np.uint64)
+        miss_a = np.concatenate(pm).astype(np.int64) if pm else np.zeros(0, dtype=np.int64)
+        return kept_first, addr, np.zeros(w, dtype=np.int64), miss_a, status, keep
+
     def isfile(self, path: str) -> bool:
         # (bam_in_decide, SF:69-89, asks once per locus: a file this reader holds open is a file - no stat, and no release of
         # the interpreter lock around one, for the loci after the first)
