@@ -212,9 +212,43 @@ def x_means(xs: Sequence[int], ys: Sequence[int]) -> List[List[List[int]]]:
     return out
 
 
+_warm_lock = None
+_warm_done = False
+
+
+def _warm() -> None:
+    """The clustering libraries are imported on first use, inside the functions that need them - and chunks of a run are scored
+    on several threads: two threads that meet their first window at the same moment would import scikit-learn / SciPy (C
+    extensions, module locks taken in different orders) against each other and never come back.  The first caller imports
+    everything, under a lock; afterwards the imports inside the functions are dictionary look-ups."""
+    global _warm_lock, _warm_done
+    if _warm_done:
+        return
+    import threading
+    if _warm_lock is None:
+        _warm_lock = _WARM_GUARD
+    with _warm_lock:
+        if not _warm_done:
+            import scipy.cluster.vq          # noqa: F401
+            import scipy.spatial.distance    # noqa: F401
+            import sklearn.cluster           # noqa: F401
+            try:
+                import threadpoolctl         # noqa: F401
+            except ImportError:
+                pass
+            _direct_ok()
+            _warm_done = True
+
+
+import threading as _threading
+
+_WARM_GUARD = _threading.Lock()
+
+
 def cluster_sizes(lower_j: Sequence[int], lower_i: Sequence[int]) -> List[float]:
     """sqrt(bounding-box area) of every repeat block (cluster_range_decide SF:372-378,
     cluster_size_decide SF:380-385)."""
+    _warm()
     out = []
     for cx, cy in x_means(list(lower_j), list(lower_i)):
         out.append(np.sqrt((max(cx) - min(cx)) * (max(cy) - min(cy))))
