@@ -296,14 +296,3 @@ def check_random_structures(eng, oracle, n_windows=6, seed=1234):
 
 def test_shared_joins_on_random_segment_structures(eng, oracle):
     assert check_random_structures(eng, oracle) > 100        # (pairs that were served by shared joins: random structures do not all qualify)
-
-
-def test_remap_as_a_kernel_of_its_own(eng, oracle):
-    """The default cuts a shared dot plot into its targets' inside the join workgroup that produced it (remap_by_wave); with
-    the parameter fused_remap = 0 a kernel of its own does (remap_kernel).  Both give the oracle's dots."""
-    eng.set_param("fused_remap", 0)
-    try:
-        assert check_random_structures(eng, oracle, n_windows=3, seed=77) > 50
-        assert check_shared_joins(eng, oracle, ks=(10, 40)) > 300
-    finally:
-        eng.set_param("fused_remap", 1)

@@ -93,7 +93,6 @@ struct vapor_ctx {
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
     bool shared_join = true;                   // reads scored against a window and alleles derived from it: one join for all
-    bool fused_remap = true;                   // ... and the join workgroup itself cuts the shared plot into the targets' (0: remap_kernel)
     int stage_threads = 3;                     // host threads that copy a large upload into the pinned staging buffer (measured:
                                                // two to four are as fast as it gets, more are slower - tools/upload_sweep.py)
     bool attrs_set = false;
@@ -348,10 +347,6 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     }
     if (!strcmp(name, "shared_join")) {
         c->shared_join = v != 0;
-        return VAPOR_OK;
-    }
-    if (!strcmp(name, "fused_remap")) {
-        c->fused_remap = v != 0;
         return VAPOR_OK;
     }
     if (!strcmp(name, "stage_threads")) {
@@ -1103,23 +1098,18 @@ template <int BPS, int K>
 static void launch_join(vapor_plan* p, const Launch& L, bool first, hipStream_t st)
 {
     const vapor_seqset* s = p->set;
-    // (shared joins: the join workgroup that produced a shared dot plot also cuts it into its targets' records - remap_by_wave)
-    const bool fused = p->n_dpairs > 0 && p->ctx->fused_remap;
-    const DShare* sh = fused ? p->d_shares : (const DShare*)nullptr;
-    const int32_t* tb = fused ? p->d_maps : (const int32_t*)nullptr;
-    unsigned int* rst = first ? p->d_overflow : (unsigned int*)nullptr;
     if (BPS == 2 && L.exc == 1)
         hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, (BPS == 2 ? 1 : 0)>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
                            st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
-                           p->d_task_pairs, p->d_hits, p->d_nhits, rst, sh, tb, (int)p->n_pairs, p->d_overflow);
+                           p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
     else if (BPS == 2 && L.exc == 2)
         hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, (BPS == 2 ? 2 : 0)>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
                            st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
-                           p->d_task_pairs, p->d_hits, p->d_nhits, rst, sh, tb, (int)p->n_pairs, p->d_overflow);
+                           p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
     else
         hipLaunchKernelGGL((join_kernel<JoinCfg, BPS, K, 0>), dim3((unsigned)L.n_tasks), dim3(JoinCfg::THREADS), JOIN_DYN_LDS(BPS),
                            st, s->d_seqs, s->d_p2, s->d_e1, s->d_x4, p->d_pairs, p->d_tasks + L.task_begin,
-                           p->d_task_pairs, p->d_hits, p->d_nhits, rst, sh, tb, (int)p->n_pairs, p->d_overflow);
+                           p->d_task_pairs, p->d_hits, p->d_nhits, first ? p->d_overflow : (unsigned int*)nullptr);
 }
 
 static int clean_groups_cap(int range_words_cap) { return range_words_cap * 32 / 10 + 8; }
@@ -1223,7 +1213,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
 #if defined(VAPOR_AB) && VAPOR_AB == 3               /* (developer variant 3: the shared joins without their remap) */
     if (false) {
 #else
-    if (p->n_dpairs && !p->ctx->fused_remap) {            // (fused: the join workgroups have done it, remap_by_wave)
+    if (p->n_dpairs) {
 #endif
         hipLaunchKernelGGL(remap_kernel, dim3((unsigned)p->n_dpairs), dim3(256), 0, st, (const DPair*)p->d_pairs, (const DShare*)p->d_shares,
                            (const int32_t*)p->d_maps, p->d_hits, p->d_nhits, p->d_overflow);

@@ -839,7 +839,7 @@ __device__ __forceinline__ void build_walk16(const uint32_t* tile, const uint32_
     }
 }
 
-// ---- shared joins: what remap_kernel and the join's epilogue read (described with remap_kernel below) ----
+// ---- shared joins: what remap_kernel reads (described with the kernel below) ----
 struct DMap {          // 16 B (host side: the interval maps of a (window, k) group before they are cut into the table below)
     int32_t lo, hi;    // k-mer starts of the shared sequence, inclusive
     int32_t base;      // position in the target at e == lo
@@ -863,126 +863,6 @@ struct DShare {        // 32 B
     int32_t pad;
 };
 
-// The same remap by ONE WAVE, as the epilogue of the join workgroup that produced the shared dot plot (join_kernel): a task owns
-// its reads from first to last, so when its probe is over the records of its (read, shared sequence) pairs are complete - and
-// still in the L2 of its XCD - and its sixteen waves turn them into the targets' records, a read per wave at a time, beside
-// the other tasks' probes.  No kernel boundary, no second pass over the records from HBM.  Only this wave writes the targets
-// of its share, so the slot counters are wave-uniform registers: no atomics.  `w` = 512 words of LDS of the wave's own.
-constexpr int REMAP_WAVE_PER = 4;
-__device__ __forceinline__ void remap_by_wave(const DPair* __restrict__ pairs, const DShare* __restrict__ shares, int si,
-                                              const int32_t* __restrict__ tables, unsigned long long* hits,
-                                              unsigned long long* n_hits, unsigned long long cnt, uint32_t* w,
-                                              unsigned int* __restrict__ overflow)
-{
-    const int lane = threadIdx.x & 63;
-    const DShare sh = shares[si];
-    const DPair dp = pairs[sh.dpair];
-    uint32_t nrec = (uint32_t)cnt;
-    if (nrec > dp.cap) {
-        if (lane == 0) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
-        nrec = dp.cap;
-    }
-    const int n_iv = min(sh.n_iv, REMAP_MAX_IV);
-    const int32_t* tb = tables + sh.iv_first;
-    int* s_B = reinterpret_cast<int*>(w + 32);                     // n_iv + 2 boundaries
-    uint32_t* s_ops = w + 96;                                       // n_iv x REMAP_OPS op words
-    int* s_tp = reinterpret_cast<int*>(w);                          // [0..3] targets, [4..7] their off2
-    uint32_t* s_cap = w + 8;
-    long long* s_hoff = reinterpret_cast<long long*>(w + 16);
-    if (lane <= n_iv) s_B[lane] = tb[lane];
-    if (lane == n_iv + 1) s_B[lane] = 0x7FFFFFFF;
-    for (int x = lane; x < n_iv * REMAP_OPS; x += 64) s_ops[x] = (uint32_t)tb[n_iv + 1 + x];
-    if (lane < 4) {
-        const int tp = shares[si].target[lane];
-        s_tp[lane] = tp;
-        if (tp >= 0) { const DPair tg = pairs[tp]; s_tp[4 + lane] = tg.off2; s_cap[lane] = tg.cap; s_hoff[lane] = tg.hit_off; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t c_rec[4] = {0u, 0u, 0u, 0u}, c_dots[4] = {0u, 0u, 0u, 0u};
-    const unsigned long long* src = hits + dp.hit_off;
-    for (uint32_t h0 = 0; h0 < nrec; h0 += 64u * REMAP_WAVE_PER) {
-        int e_lo[REMAP_WAVE_PER], e_hi[REMAP_WAVE_PER], i_at_lo[REMAP_WAVE_PER], iv[REMAP_WAVE_PER];
-        uint32_t rcbits = 0;
-#pragma unroll
-        for (int q = 0; q < REMAP_WAVE_PER; ++q) {
-            const uint32_t h = h0 + (uint32_t)(q * 64 + lane);
-            const bool have = h < nrec;
-            const unsigned long long r = have ? src[h] : 0ull;
-            const int e0 = VREC_J(r), i0 = VREC_I(r), len = VREC_LEN(r);
-            const bool rc = VREC_RC(r);
-            rcbits |= (rc ? 1u : 0u) << q;
-            e_lo[q] = rc ? e0 - (len - 1) : e0;
-            e_hi[q] = have ? e_lo[q] + len - 1 : e_lo[q] - 1;
-            i_at_lo[q] = rc ? i0 + (len - 1) : i0;
-            int pos = 0;
-#pragma unroll
-            for (int stp = 32; stp > 0; stp >>= 1)
-                if (pos + stp <= n_iv && s_B[pos + stp] <= e_lo[q]) pos += stp;
-            iv[q] = pos;
-        }
-        for (int step = 0;; ++step) {
-            uint32_t act = 0;
-#pragma unroll
-            for (int q = 0; q < REMAP_WAVE_PER; ++q) act |= ((iv[q] + step < n_iv && s_B[iv[q] + step] <= e_hi[q]) ? 1u : 0u) << q;
-            if (!__ballot(act != 0u)) break;
-#pragma unroll
-            for (int sc = 0; sc < REMAP_OPS; ++sc) {
-                const int slot = sc >> 1;
-                if (s_tp[slot] < 0) continue;                      // (uniform)
-                uint32_t op[REMAP_WAVE_PER], em = 0;
-#pragma unroll
-                for (int q = 0; q < REMAP_WAVE_PER; ++q) {
-                    op[q] = ((act >> q) & 1u) ? s_ops[(iv[q] + step) * REMAP_OPS + sc] : 0u;
-                    em |= (op[q] & 1u) << q;
-                }
-                if (!__ballot(em != 0u)) continue;
-                const int off2 = s_tp[4 + slot];
-                uint32_t w_lo[REMAP_WAVE_PER], w_hi[REMAP_WAVE_PER];
-                int dots = 0;
-#pragma unroll
-                for (int q = 0; q < REMAP_WAVE_PER; ++q) {
-                    const int t = iv[q] + step;
-                    const int pe_lo = max(e_lo[q], s_B[t]), pe_hi = min(e_hi[q], s_B[t + 1] - 1);
-                    const bool rc = (rcbits >> q) & 1u, flip = (op[q] >> 1) & 1u;
-                    const int delta = (int)op[q] >> 2;
-                    const int e_first = rc ? pe_hi : pe_lo;
-                    int i_first = rc ? i_at_lo[q] - (pe_hi - e_lo[q]) : i_at_lo[q] + (pe_lo - e_lo[q]);
-                    int n = pe_hi - pe_lo + 1;
-                    int ja = flip ? delta - e_first : e_first + delta;
-                    const int dj = (flip ? -1 : 1) * (rc ? -1 : 1);
-                    if (dj > 0) { const int skip = max(0, off2 - ja); i_first += skip; ja += skip; n -= skip; }
-                    else n = min(n, ja - off2 + 1);
-                    if (!((em >> q) & 1u) || n <= 0) { n = 0; em &= ~(1u << q); }
-                    dots += n;
-                    w_lo[q] = (uint32_t)i_first | ((uint32_t)(ja - off2) << 16);
-                    w_hi[q] = (uint32_t)n | ((dj < 0 ? 1u : 0u) << 16);
-                }
-                const uint32_t mine = (uint32_t)__popc(em);
-                const uint32_t incl = wave_incl_scan_u32(mine);
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const int wdots = __builtin_amdgcn_readlane(wave_scan<OpAdd>(dots, 0), 63);
-                uint32_t at = c_rec[slot] + incl - mine;
-                c_rec[slot] += tot;
-                c_dots[slot] += (uint32_t)wdots;
-                const uint32_t cap = s_cap[slot];
-                unsigned long long* dst = hits + s_hoff[slot];
-#pragma unroll
-                for (int q = 0; q < REMAP_WAVE_PER; ++q) {
-                    if (!((em >> q) & 1u)) continue;
-                    if (at < cap) dst[at] = (unsigned long long)w_lo[q] | ((unsigned long long)w_hi[q] << 32);
-                    ++at;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        if (lane == t && s_tp[t] >= 0) n_hits[s_tp[t]] = (unsigned long long)c_rec[t] | ((unsigned long long)c_dots[t] << 32);
-    __builtin_amdgcn_wave_barrier();                                // (the next read's set-up overwrites the wave's LDS words)
-}
-
 // EXC (2-bit planes; the host groups the pairs): 1 - the launch holds the pairs whose ALLELE has symbols outside upper-case
 // ACGT: the table leaves out the k-mers that cover one, runs end before them.  2 - the pairs whose READ has such symbols (and
 // whose allele has none): the positions whose k-mer covers one are masked out of the lookup, runs end before them; the
@@ -994,8 +874,7 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     const SeqDesc* __restrict__ seqs, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ e1,
     const uint32_t* __restrict__ x4, const DPair* __restrict__ pairs, const DTask* __restrict__ tasks,
     const int32_t* __restrict__ task_pairs, unsigned long long* __restrict__ hits, unsigned long long* __restrict__ n_hits,
-    unsigned int* __restrict__ reset2, const DShare* __restrict__ shares, const int32_t* __restrict__ share_tables, int n_user_pairs,
-    unsigned int* __restrict__ overflow)
+    unsigned int* __restrict__ reset2)
 {
     using KT = KeyT<BPS, K>;
     constexpr int TA = tile_pos<C, BPS>();
@@ -1425,17 +1304,6 @@ __global__ __launch_bounds__(C::THREADS, C::WPS) void join_kernel(
     }
 #endif
     if (tid < task.n_reads) n_hits[task_pairs[task.first + tid]] = cnt[tid];
-    if (shares) {
-        // epilogue (remap_by_wave): the shared dot plots of this task become their targets' records.  The final barrier above
-        // has made every wave's record stores visible to the workgroup (same CU, write-through L1, nothing of these slots read
-        // before); every region of the probe's LDS is free: 512 words per wave from its start.
-        __syncthreads();                                // (cnt[] is read below after the stores above have been issued)
-        for (int r = wave; r < task.n_reads; r += JOIN_WAVES) {
-            const int idx = __builtin_amdgcn_readfirstlane((int)rinfo[4 * r + 0]);
-            if (idx < n_user_pairs) continue;
-            remap_by_wave(pairs, shares, idx - n_user_pairs, share_tables, hits, n_hits, cnt[r], lds + wave * 512, overflow);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
