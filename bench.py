@@ -352,7 +352,8 @@ def main() -> None:
             "kernel_ms": {"join": round(avg["join_ms"], 4), "clean": round(avg["clean_ms"], 4), "finish": round(avg["finish_ms"], 4),
                           "device_total": round(avg["total_ms"], 4), "join_launches": launches,
                           "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)},
-                          "note": "join / clean / finish are HIP-event INTERVALS inside the two-plan overlap (the two plans' kernels "
+                          "note": "join = the join kernel(s) and the remap of their shared joins (remap_kernel: a read is joined once against a "
+                                  "window and the alleles derived from it); join / clean / finish are HIP-event INTERVALS inside the two-plan overlap (the two plans' kernels "
                                   "share the CUs and their intervals overlap: their sum over the passes exceeds the step), not serial "
                                   "costs; `alone` is each kernel by itself on an otherwise idle device"},
             "upload_pack_s": round(res.upload_s, 4),

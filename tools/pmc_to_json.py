@@ -20,13 +20,13 @@ for d in dirs:
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            name = "join_kernel" if "join_kernel" in k else "clean_kernel" if (k.endswith("clean_kernel") or "clean_kernel<" in k) else None
+            name = "join_kernel" if "join_kernel" in k else "clean_kernel" if (k.endswith("clean_kernel") or "clean_kernel<" in k) else "remap_kernel" if "remap_kernel" in k else None
             if name:
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for f in glob.glob(d + "/*/*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            name = "join_kernel" if "join_kernel" in k else "clean_kernel" if (k.endswith("clean_kernel") or "clean_kernel<" in k) else None
+            name = "join_kernel" if "join_kernel" in k else "clean_kernel" if (k.endswith("clean_kernel") or "clean_kernel<" in k) else "remap_kernel" if "remap_kernel" in k else None
             if name:
                 dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
 traffic, util = {}, {}

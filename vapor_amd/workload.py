@@ -41,7 +41,19 @@ class Workload:
     def upload(self, eng):
         """The batch's sequence set on `eng`."""
         if self.derived:
-            return eng.seqset(self.seqs[:self.n_lit], derived=self.derived)
+            arr = self.__dict__.get("_derived_arrays")
+            if arr is None:
+                # (the descriptors as the arrays the library takes, made once: a caller that streams batches builds them
+                # with numpy, as pipeline / fastpath do - not segment by segment on every upload)
+                seg_first = np.zeros(len(self.derived) + 1, dtype=np.int32)
+                np.cumsum([len(sg) for sg, _u in self.derived], out=seg_first[1:])
+                segs = np.zeros(max(int(seg_first[-1]), 1), dtype=L.SEG_DTYPE)
+                rows = [(p, o, n, L.SEG_REVCOMP if rc else 0) for sg, _u in self.derived for p, o, n, rc in sg]
+                if rows:
+                    segs[:len(rows)] = rows
+                arr = self.__dict__["_derived_arrays"] = (seg_first, segs, np.asarray([L.SEQ_UPPER if u else 0 for _sg, u in self.derived], dtype=np.uint8))
+                self.__dict__["_lits"] = self.seqs[:self.n_lit]
+            return eng.seqset(self.__dict__["_lits"], derived=arr)
         return eng.seqset(self.seqs)
 
 
