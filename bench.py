@@ -141,6 +141,7 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inclusive rate and the cfg3 sub-record")
     ap.add_argument("--sub", default="cfg3", help="workload of the sub-record ('' = none)")
+    ap.add_argument("--param", action="append", default=[], help="engine parameter name=value (development: A/B of a kernel route)")
     ap.add_argument("--strong-loci", type=int, default=10000, help="N > 1: records of the cfg4 VCF sharded over the ranks (0 = skip)")
     ap.add_argument("--strong-base", type=int, default=300, help="distinct loci of that world (tiled up to --strong-loci)")
     args = ap.parse_args()
@@ -189,6 +190,8 @@ def main() -> None:
     from vapor_amd.engine import Engine
 
     eng = Engine(local)
+    for kv in args.param:
+        eng.set_param(kv.split("=")[0], int(kv.split("=")[1]))
     spec = wl.WORKLOADS[args.workload]
     w = wl.make_workload(args.workload, seed=1000 + rank, **spec)
     # A batch whose join is a single wave of workgroups (one per CU) leaves CUs idle at its tail, which the other plan's

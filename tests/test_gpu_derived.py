@@ -187,6 +187,17 @@ def test_shared_joins_give_the_dots_of_separate_joins(eng, oracle):
     assert check_shared_joins(eng, oracle) > 1000
 
 
+@pytest.mark.parametrize("route", [0, 2])
+def test_shared_joins_cut_up_by_either_route(eng, oracle, route):
+    # remap_in_clean 0: remap_kernel cuts every target's records out of the shared dot plots before the cleaning starts;
+    # 2: the clean workgroup of each target does (1, the default, picks by the plan's size); both give the dots of separate joins
+    eng.set_param("remap_in_clean", route)
+    try:
+        assert check_shared_joins(eng, oracle, ks=(10, 30)) > 300
+    finally:
+        eng.set_param("remap_in_clean", 1)
+
+
 def test_shared_joins_through_the_loci_path(eng):
     """The bench shapes with derived alt windows: per-locus records of run_loci equal those of the same batch with every
     sequence uploaded as bytes (one join per pair), for DEL / TANDUP / INV / INS - and the plan shares its joins."""

@@ -33,6 +33,9 @@ if "--child" in sys.argv:
     name = sys.argv[sys.argv.index("--child") + 1]
     w = wl.make_workload(name, seed=1000, **wl.WORKLOADS[name])
     eng = Engine(0)
+    for kv in os.environ.get("VAPOR_AB_PARAMS", "").split(","):       # e.g. VAPOR_AB_PARAMS=remap_in_clean=0
+        if kv:
+            eng.set_param(kv.split("=")[0], int(kv.split("=")[1]))
     plan = eng.plan(w.upload(eng), w.pairs)          # (derived alt windows: the plan shares its joins)
     for _ in range(5):
         plan.run()
@@ -51,6 +54,6 @@ workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.arg
 names = [n for n in names if n not in (str(rounds), workload)]
 for r in range(rounds):
     for n in names:
-        env = dict(os.environ, VAPOR_HIP_LIB=so(n))
+        env = dict(os.environ, VAPOR_HIP_LIB=so(n.split("@")[0]), VAPOR_AB_PARAMS=n.partition("@")[2])   # name@param=value,...
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", workload], env=env, capture_output=True, text=True)
         print("%-10s %s %s" % (n, out.stdout.strip(), out.stderr.strip()[-200:] if out.returncode else ""), flush=True)

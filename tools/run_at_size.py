@@ -75,7 +75,7 @@ def main():
         sys.stdout = real_stdout
     dt = time.perf_counter() - t0
     rows = open(result).read().splitlines()
-    body = [r for r in rows if not r.startswith("#")]          # (the table's header line; the ##INFO lines of the rewritten VCF)
+    body = [r for r in rows if r and not r.startswith("#")]         # (the table's header line; the ##INFO lines of the rewritten VCF)
     rss_mb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
     rng = np.random.default_rng(1)
     n_sample = arg("--sample", 2000 if distinct else 400)

@@ -90,9 +90,11 @@ struct vapor_ctx {
     std::vector<double> h_gt;
     double* d_gt = nullptr;
     int reads_per_task = MAX_READS_PER_TASK;   // upper bound on pairs per join task
+    int n_cus = 256;
     int join_tasks = 256;                      // join tasks aimed for per launch (cost-balanced ranges): one per CU
     int64_t max_pair_cap = (int64_t)1 << 28;
     bool shared_join = true;                   // reads scored against a window and alleles derived from it: one join for all
+    int remap_in_clean = 1;                    // ... and the clean workgroup of a target cuts its records out of the shared plot (0: remap_kernel)
     int stage_threads = 3;                     // host threads that copy a large upload into the pinned staging buffer (measured:
                                                // two to four are as fast as it gets, more are slower - tools/upload_sweep.py)
     bool attrs_set = false;
@@ -245,6 +247,8 @@ struct vapor_plan {
     std::vector<int32_t> tables;               // per (group, k): boundaries and op words (remap_kernel)
     DShare* d_shares = nullptr;
     int32_t* d_maps = nullptr;
+    std::vector<DServe> serve;                 // per pair: where its records come from when a shared join serves it
+    DServe* d_serve = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -289,9 +293,11 @@ extern "C" int vapor_init(int device_ordinal, vapor_ctx** out)
     c->device = device_ordinal;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+        if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) {
+            c->n_cus = prop.multiProcessorCount;
             // a join workgroup fills a CU's LDS (or, in the two-per-CU experiment geometry, half of it)
             c->join_tasks = prop.multiProcessorCount * (JoinCfg::THREADS <= 768 ? 2 : 1);
+        }
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(VAPOR_E_HIP, hipGetErrorString(e)); }
@@ -347,6 +353,11 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     }
     if (!strcmp(name, "shared_join")) {
         c->shared_join = v != 0;
+        return VAPOR_OK;
+    }
+    if (!strcmp(name, "remap_in_clean")) {
+        if (v < 0 || v > 2) return fail(VAPOR_E_ARG, "vapor_set_param: remap_in_clean is 0, 1 or 2");
+        c->remap_in_clean = (int)v;
         return VAPOR_OK;
     }
     if (!strcmp(name, "stage_threads")) {
@@ -741,6 +752,7 @@ static void plan_free_device(vapor_plan* p)
     dfree(p->ctx, p->d_loci); p->d_loci = nullptr;
     dfree(p->ctx, p->d_shares); p->d_shares = nullptr;
     dfree(p->ctx, p->d_maps); p->d_maps = nullptr;
+    dfree(p->ctx, p->d_serve); p->d_serve = nullptr;
 }
 
 extern "C" int vapor_plan_destroy(vapor_plan* p)
@@ -793,6 +805,11 @@ static int plan_alloc_hits(vapor_plan* p)
     HIPCHK(dmalloc(p->ctx, (void**)&p->d_hflags, (size_t)tot));
     p->total_cap = tot;
     HIPCHK(hipMemcpyAsync(p->d_pairs, p->hp.data(), sizeof(DPair) * p->hp.size(), hipMemcpyHostToDevice, p->ctx->stream));
+    if (p->n_dpairs) {                                  // the served pairs' view of the shared dot plots' slots
+        for (auto& sv : p->serve)
+            if (sv.dpair >= 0) { sv.hit_off = p->hp[(size_t)sv.dpair].hit_off; sv.cap = p->hp[(size_t)sv.dpair].cap; }
+        HIPCHK(hipMemcpyAsync(p->d_serve, p->serve.data(), sizeof(DServe) * p->serve.size(), hipMemcpyHostToDevice, p->ctx->stream));
+    }
     return VAPOR_OK;
 }
 
@@ -930,6 +947,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             return std::max(1, (len_a - k + 1 + ta - 1) / ta);
         };
         std::vector<uint8_t> served((size_t)n_pairs, 0);
+        { DServe none; memset(&none, 0, sizeof(none)); none.dpair = -1; p->serve.assign((size_t)n_pairs, none); }
         for (size_t a = 0; a < cand.size();) {
             size_t b = a;
             while (b < cand.size() && cand[b].seq1 == cand[a].seq1 && cand[b].group == cand[a].group && cand[b].k == cand[a].k) ++b;
@@ -961,7 +979,14 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             memset(&sh, 0, sizeof sh);
             sh.dpair = (int32_t)p->hp.size();
             sh.iv_first = mp.first; sh.n_iv = mp.second;
-            for (int t = 0; t < 4; ++t) { sh.target[t] = tgt[t]; if (tgt[t] >= 0) { served[(size_t)tgt[t]] = 1; ++p->n_served; } }
+            for (int t = 0; t < 4; ++t) {
+                sh.target[t] = tgt[t];
+                if (tgt[t] >= 0) {
+                    served[(size_t)tgt[t]] = 1; ++p->n_served;
+                    DServe& sv = p->serve[(size_t)tgt[t]];
+                    sv.dpair = sh.dpair; sv.iv_first = sh.iv_first; sv.n_iv = sh.n_iv; sv.slot = t;      // (slot and cap of the join: below)
+                }
+            }
             p->hp.push_back(d);
             mode.push_back((uint8_t)md);
             p->shares.push_back(sh);
@@ -1075,6 +1100,7 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
     if (p->n_dpairs) {
         chk(dmalloc(ctx, (void**)&p->d_shares, sizeof(DShare) * p->shares.size()), "hipMalloc shares");
         chk(dmalloc(ctx, (void**)&p->d_maps, sizeof(int32_t) * std::max<size_t>(p->tables.size(), 1)), "hipMalloc maps");
+        chk(dmalloc(ctx, (void**)&p->d_serve, sizeof(DServe) * p->serve.size()), "hipMalloc serve");
         if (rc == VAPOR_OK) chk(hipMemcpyAsync(p->d_shares, p->shares.data(), sizeof(DShare) * p->shares.size(), hipMemcpyHostToDevice, ctx->stream), "copy shares");
         if (rc == VAPOR_OK && !p->tables.empty())
             chk(hipMemcpyAsync(p->d_maps, p->tables.data(), sizeof(int32_t) * p->tables.size(), hipMemcpyHostToDevice, ctx->stream), "copy maps");
@@ -1184,6 +1210,19 @@ static CleanGeom clean_geom(int range_words_cap, int want)
 
 static int async_fold(vapor_plan* p);
 
+// Who cuts the served pairs' records out of the shared dot plots: the clean workgroup of each pair, or remap_kernel before the
+// cleaning.  Measured (profiles/r04_remap_experiments.txt): the clean workgroups win when all of them are resident at once - a
+// batch of the 10 kb shape, where a kernel boundary and a trip of the records through HBM is what the kernel of its own adds -
+// and lose when they run in several rounds (30 kb reads, two workgroups per CU: every target reading the shared plot again
+// costs more than the boundary).  "remap_in_clean": 1 = that rule, 0 = always the kernel, 2 = always the clean workgroups.
+static bool remap_in_clean(const vapor_plan* p)
+{
+    if (p->n_dpairs <= 0 || p->ctx->remap_in_clean == 0) return false;
+    if (p->ctx->remap_in_clean == 2) return true;
+    const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
+    return p->n_pairs <= (int64_t)cg.per_cu * p->ctx->n_cus;
+}
+
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr, bool skip_big = false,
                          hipEvent_t before_clean = nullptr)
 {
@@ -1213,7 +1252,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
 #if defined(VAPOR_AB) && VAPOR_AB == 3               /* (developer variant 3: the shared joins without their remap) */
     if (false) {
 #else
-    if (p->n_dpairs) {
+    if (p->n_dpairs && !remap_in_clean(p)) {
 #endif
         hipLaunchKernelGGL(remap_kernel, dim3((unsigned)p->n_dpairs), dim3(256), 0, st, (const DPair*)p->d_pairs, (const DShare*)p->d_shares,
                            (const int32_t*)p->d_maps, p->d_hits, p->d_nhits, p->d_overflow);
@@ -1229,10 +1268,12 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
 #ifdef VAPOR_DEV_BUILD
         if (const char* e = getenv("VAPOR_DEV_CLEAN_PAD")) lds += (size_t)atoi(e);   // experiment: fewer workgroups per CU
 #endif
+        const bool in_clean = remap_in_clean(p);
         launch_clean(p->range_words_cap, (unsigned)p->n_pairs, lds, st,
-                     (const DPair*)p->d_pairs, (const int32_t*)nullptr, (const unsigned long long*)p->d_nhits,
-                     (const unsigned long long*)p->d_hits, p->d_hflags, p->d_stats, p->range_words_cap,
-                     clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1, cg.dual ? 1 : 0);
+                     (const DPair*)p->d_pairs, (const int32_t*)nullptr, p->d_nhits,
+                     p->d_hits, p->d_hflags, p->d_stats, p->range_words_cap,
+                     clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1, cg.dual ? 1 : 0,
+                     in_clean ? (const DServe*)p->d_serve : (const DServe*)nullptr, (const int32_t*)p->d_maps);
         HIPCHK(hipGetLastError());
         // (clean_big_kernel needs a CU with free LDS like any other clean workgroup: behind another plan's join it sits
         // on the stream until that join is over even with nothing to do, and holds back the finish kernel and the
@@ -1512,8 +1553,9 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         const CleanGeom cg = clean_geom(rw, 4096);
         const int hcap = cg.hcap;
         launch_clean(rw, (unsigned)n_lists, clean_lds_bytes(rw, hcap, cg.dual), st, (const DPair*)d_dp, (const int32_t*)nullptr,
-                     (const unsigned long long*)d_nh, (const unsigned long long*)d_hits, d_fl, d_st, rw,
-                     clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1, cg.dual ? 1 : 0);
+                     d_nh, d_hits, d_fl, d_st, rw,
+                     clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1, cg.dual ? 1 : 0,
+                     (const DServe*)nullptr, (const int32_t*)nullptr);
         chk(hipGetLastError(), "clean launch");
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);

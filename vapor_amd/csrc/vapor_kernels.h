@@ -863,6 +863,15 @@ struct DShare {        // 32 B
     int32_t pad;
 };
 
+struct DServe {        // 32 B per pair: what the clean workgroup of a pair served by a shared join needs to cut its records out
+    int64_t hit_off;   // of the shared dot plot: the (read, T) pair's record slot ...
+    uint32_t cap;
+    int32_t dpair;     // ... its index (-1: this pair ran a join of its own),
+    int32_t iv_first, n_iv;   // the group's table
+    int32_t slot;      // and this pair's slot in it
+    int32_t pad;
+};
+
 // EXC (2-bit planes; the host groups the pairs): 1 - the launch holds the pairs whose ALLELE has symbols outside upper-case
 // ACGT: the table leaves out the k-mers that cover one, runs end before them.  2 - the pairs whose READ has such symbols (and
 // whose allele has none): the positions whose k-mer covers one are masked out of the lookup, runs end before them; the
@@ -2086,6 +2095,125 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
     pc.flush(tid == 0);
 }
 
+// The remap of a shared join for ONE target, by the clean workgroup of that target itself (256 threads): the workgroup that is
+// about to clean pair p first cuts p's records out of the shared dot plot - the arithmetic of remap_kernel for one slot - writes
+// them to p's slot and goes on to read them back: through the L2 of its own XCD instead of through HBM and a kernel boundary.
+// Returns p's packed count (records | dots << 32), which it also stores for the host.  `w`: the start of the workgroup's dynamic
+// LDS (free until the cleaning proper begins).
+#ifndef VAPOR_REMAP_CLEAN_PER
+#define VAPOR_REMAP_CLEAN_PER 4
+#endif
+constexpr int REMAP_CLEAN_PER = VAPOR_REMAP_CLEAN_PER;
+__device__ __forceinline__ unsigned long long remap_for_target(int p, const DPair& tg, const DServe& sv,
+                                                               const int32_t* __restrict__ tables, unsigned long long* hits,
+                                                               unsigned long long* n_hits, uint32_t* w, unsigned int* overflow)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int slot = sv.slot;
+    uint32_t nrec = (uint32_t)n_hits[sv.dpair];
+    const int n_iv = min(sv.n_iv, REMAP_MAX_IV);
+    const int32_t* tb = tables + sv.iv_first;
+    uint32_t* c = w;                                               // [0] records, [1] dots
+    int* s_B = reinterpret_cast<int*>(w + 4);                      // n_iv + 2 boundaries
+    uint32_t* s_ops = w + 64;                                      // two op words per interval: this slot's
+    if (tid <= n_iv) s_B[tid] = tb[tid];
+    if (tid == n_iv + 1) s_B[tid] = 0x7FFFFFFF;
+    if (tid < 2 * n_iv) s_ops[tid] = (uint32_t)tb[n_iv + 1 + (tid >> 1) * REMAP_OPS + slot * 2 + (tid & 1)];
+    if (tid == 255) { c[0] = 0u; c[1] = 0u; c[2] = 0u; }
+    if (nrec > sv.cap) {
+        if (tid == 0 && overflow) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
+        nrec = sv.cap;
+    }
+    __syncthreads();
+    if (tid < n_iv && (s_ops[2 * tid + 1] & 1u)) c[2] = 1u;       // some stretch of T lies twice in this target (a duplication)
+    __syncthreads();
+    const int n_cp = c[2] ? 2 : 1;
+    int stp0 = 1;                                                  // the interval search starts at the table's size
+    while (stp0 * 2 <= n_iv) stp0 *= 2;
+    const int off2 = tg.off2;
+    const uint32_t cap = tg.cap;
+    const unsigned long long* src = hits + sv.hit_off;
+    unsigned long long* dst = hits + tg.hit_off;
+    uint32_t my_dots = 0;
+    for (uint32_t h0 = 0; h0 < nrec; h0 += 256u * REMAP_CLEAN_PER) {
+        int e_lo[REMAP_CLEAN_PER], e_hi[REMAP_CLEAN_PER], i_at_lo[REMAP_CLEAN_PER], iv[REMAP_CLEAN_PER];
+        uint32_t rcbits = 0;
+#pragma unroll
+        for (int q = 0; q < REMAP_CLEAN_PER; ++q) {
+            const uint32_t h = h0 + (uint32_t)(q * 256 + tid);
+            const bool have = h < nrec;
+            const unsigned long long r = have ? src[h] : 0ull;
+            const int e0 = VREC_J(r), i0 = VREC_I(r), len = VREC_LEN(r);
+            const bool rc = VREC_RC(r);
+            rcbits |= (rc ? 1u : 0u) << q;
+            e_lo[q] = rc ? e0 - (len - 1) : e0;
+            e_hi[q] = have ? e_lo[q] + len - 1 : e_lo[q] - 1;
+            i_at_lo[q] = rc ? i0 + (len - 1) : i0;
+            int pos = 0;
+            for (int stp = stp0; stp > 0; stp >>= 1)
+                if (pos + stp <= n_iv && s_B[pos + stp] <= e_lo[q]) pos += stp;
+            iv[q] = pos;
+        }
+        for (int step = 0;; ++step) {
+            uint32_t act = 0;
+#pragma unroll
+            for (int q = 0; q < REMAP_CLEAN_PER; ++q) act |= ((iv[q] + step < n_iv && s_B[iv[q] + step] <= e_hi[q]) ? 1u : 0u) << q;
+            if (!__ballot(act != 0u)) break;
+            for (int cp = 0; cp < n_cp; ++cp) {
+                uint32_t op[REMAP_CLEAN_PER], em = 0;
+#pragma unroll
+                for (int q = 0; q < REMAP_CLEAN_PER; ++q) {
+                    op[q] = ((act >> q) & 1u) ? s_ops[(iv[q] + step) * 2 + cp] : 0u;
+                    em |= (op[q] & 1u) << q;
+                }
+                if (!__ballot(em != 0u)) continue;
+                uint32_t w_lo[REMAP_CLEAN_PER], w_hi[REMAP_CLEAN_PER];
+                uint32_t dots = 0;
+#pragma unroll
+                for (int q = 0; q < REMAP_CLEAN_PER; ++q) {
+                    const int t = iv[q] + step;
+                    const int pe_lo = max(e_lo[q], s_B[t]), pe_hi = min(e_hi[q], s_B[t + 1] - 1);
+                    const bool rc = (rcbits >> q) & 1u, flip = (op[q] >> 1) & 1u;
+                    const int delta = (int)op[q] >> 2;
+                    const int e_first = rc ? pe_hi : pe_lo;
+                    int i_first = rc ? i_at_lo[q] - (pe_hi - e_lo[q]) : i_at_lo[q] + (pe_lo - e_lo[q]);
+                    int n = pe_hi - pe_lo + 1;
+                    int ja = flip ? delta - e_first : e_first + delta;
+                    const int dj = (flip ? -1 : 1) * (rc ? -1 : 1);
+                    if (dj > 0) { const int skip = max(0, off2 - ja); i_first += skip; ja += skip; n -= skip; }
+                    else n = min(n, ja - off2 + 1);
+                    if (!((em >> q) & 1u) || n <= 0) { n = 0; em &= ~(1u << q); }
+                    dots += (uint32_t)n;
+                    w_lo[q] = (uint32_t)i_first | ((uint32_t)(ja - off2) << 16);
+                    w_hi[q] = (uint32_t)n | ((dj < 0 ? 1u : 0u) << 16);
+                }
+                my_dots += dots;                                   // (summed over the workgroup once, after the last round)
+                const uint32_t mine = (uint32_t)__popc(em);
+                const uint32_t incl = wave_incl_scan_u32(mine);
+                uint32_t base = 0;
+                if (lane == 63 && incl) base = atomicAdd(&c[0], incl);
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+                uint32_t at = base + incl - mine;
+#pragma unroll
+                for (int q = 0; q < REMAP_CLEAN_PER; ++q) {
+                    if (!((em >> q) & 1u)) continue;
+                    if (at < cap) dst[at] = (unsigned long long)w_lo[q] | ((unsigned long long)w_hi[q] << 32);
+                    ++at;
+                }
+            }
+        }
+    }
+    {
+        const uint32_t wd = (uint32_t)wave_sum_i32((int)my_dots);
+        if (lane == 0 && wd) atomicAdd(&c[1], wd);
+    }
+    __syncthreads();                               // (every record store issued and visible to the workgroup; the counters final)
+    const unsigned long long cnt = (unsigned long long)c[0] | ((unsigned long long)c[1] << 32);
+    if (tid == 0) n_hits[p] = cnt;
+    __syncthreads();                               // (the LDS words are the cleaning's from here on)
+    return cnt;
+}
+
 // One workgroup per pair: pairs with at most hcap records and fewer than 65536 dots are cleaned entirely out of
 // LDS with 16-bit group counters; the others are appended to big_list for clean_big_kernel.
 // n_hits[p] = records | dots << 32 (join_verify).  len2 and the value range come with the pair record, so the
@@ -2093,16 +2221,21 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
 template <int PER_MAX>
 __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     const DPair* __restrict__ pairs, const int32_t* __restrict__ pair_list,
-    const unsigned long long* __restrict__ n_hits, const unsigned long long* __restrict__ recs_all,
+    unsigned long long* n_hits, unsigned long long* recs_all,
     uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
-    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list, int big_follows, int dual_layout)
+    unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list, int big_follows, int dual_layout,
+    const DServe* __restrict__ serve, const int32_t* __restrict__ share_tables)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
     const int tid = threadIdx.x;
     const int p = pair_list ? pair_list[blockIdx.x] : (int)blockIdx.x;
     const DPair pr = pairs[p];
-    const unsigned long long cnt = n_hits[p];
+    // a pair served by a shared join: its records are cut out of the shared dot plot here, by the workgroup that cleans them
+    DServe sv;
+    sv.dpair = -1;
+    if (serve) sv = serve[p];
+    const unsigned long long cnt = sv.dpair >= 0 ? remap_for_target(p, pr, sv, share_tables, recs_all, n_hits, lds, overflow) : n_hits[p];
     const uint32_t nrec = (uint32_t)cnt, ndots = (uint32_t)(cnt >> 32);
     if (nrec > pr.cap || nrec == 0u) {
         long long* st = stats + (size_t)p * 16;
