@@ -247,6 +247,8 @@ def main() -> None:
     # every plan ran n_passes / n_plans passes (+-1); its timings are averages over them
     wts = [len(range(k, n_passes, n_plans)) for k in range(n_plans)]
     avg = {key: sum(t[0][key] * wt for t, wt in zip(tm, wts)) / max(sum(wts), 1) for key in ("join_ms", "clean_ms", "total_ms", "finish_ms")}
+    for key in ("clean_workgroups_per_cu", "remap_in_clean"):      # (the plan's geometry, not a time)
+        avg[key] = tm[0][0].get(key)
     last_rec = tm[(n_passes - 1) % n_plans][1]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -354,9 +356,11 @@ def main() -> None:
             "loci_with_scores": int(np.isfinite(np.asarray(last_rec).reshape(-1, 8)[:, 0]).sum()),
             "kernel_ms": {"join": round(avg["join_ms"], 4), "clean": round(avg["clean_ms"], 4), "finish": round(avg["finish_ms"], 4),
                           "device_total": round(avg["total_ms"], 4), "join_launches": launches,
+                          "clean_workgroups_per_cu": avg.get("clean_workgroups_per_cu"), "remap_in_clean": avg.get("remap_in_clean"),
                           "alone": {"join": round(res.alone["join_ms"], 4), "clean": round(res.alone["clean_ms"], 4)},
-                          "note": "join = the join kernel(s) and the remap of their shared joins (remap_kernel: a read is joined once against a "
-                                  "window and the alleles derived from it); join / clean / finish are HIP-event INTERVALS inside the two-plan overlap (the two plans' kernels "
+                          "note": "a read is joined once against a window and the alleles derived from it (shared joins); the pairs' records are cut out "
+                                  "of the shared dot plots by the clean workgroups themselves (this workload: inside `clean`) or, for plans of many "
+                                  "rounds of clean workgroups, by remap_kernel (inside `join`); join / clean / finish are HIP-event INTERVALS inside the two-plan overlap (the two plans' kernels "
                                   "share the CUs and their intervals overlap: their sum over the passes exceeds the step), not serial "
                                   "costs; `alone` is each kernel by itself on an otherwise idle device"},
             "upload_pack_s": round(res.upload_s, 4),

@@ -97,7 +97,12 @@ int vapor_init(int device_ordinal, vapor_ctx** ctx);
 int vapor_destroy(vapor_ctx* ctx);
 /* tuning knobs: "reads_per_task" (at most this many pairs per join workgroup, <= 64), "join_tasks" (number of
  * join workgroups a launch is cut into; default = number of CUs), "max_pair_cap" (largest record slot a pair may
- * grow to on an overflow rerun; beyond it the pair keeps VAPOR_E_OVERFLOW) */
+ * grow to on an overflow rerun; beyond it the pair keeps VAPOR_E_OVERFLOW), "shared_join" (1, the default: a read scored
+ * against a window and alleles derived from it - vapor_seqset_create_derived - is joined once for all of them; 0: one join per
+ * pair), "remap_in_clean" (who cuts a served pair's records out of a shared dot plot.  1, the default: the workgroup that cleans
+ * the pair when the plan's clean workgroups run in at most four rounds (a resident batch of a few thousand pairs), else a kernel
+ * of its own before the cleaning, remap_kernel; 0: always that kernel; 2: always the clean workgroups), "stage_threads" (host threads that copy a
+ * sequence set's bytes into the pinned staging buffer, default 3).  Results do not depend on any of them. */
 int vapor_set_param(vapor_ctx* ctx, const char* name, int64_t value);
 
 /* ---- sequences: ASCII in, packed bit planes resident in HBM ------------------------------ */
@@ -159,9 +164,10 @@ int vapor_plan_destroy(vapor_plan* plan);
  */
 int vapor_plan_run(vapor_plan* plan, int64_t* stats);
 /* device time of the kernels of the last vapor_plan_run, measured with HIP events on the
- * library's stream: ms[0] = join kernels (incl. the remap of shared joins), ms[1] = clean kernel, ms[2] = whole run incl. copies,
- * ms[3] = number of join launches, ms[4] = number of retried pairs, ms[5] = finish kernel, ms[6] = pairs served by a shared
- * join, ms[7] = joins that serve them */
+ * library's stream: ms[0] = join kernels (and remap_kernel where the plan runs it), ms[1] = clean kernels, ms[2] = whole run incl.
+ * copies, ms[3] = number of join launches, ms[4] = number of retried pairs, ms[5] = finish kernel, ms[6] = pairs served by a shared
+ * join, ms[7] = joins that serve them, ms[8] = clean workgroups per CU (what the staged records leave room for), ms[9] = 1 when
+ * the clean workgroups cut the served pairs' records out of the shared dot plots themselves ("remap_in_clean") */
 int vapor_plan_timings(vapor_plan* plan, double* ms, int32_t n);
 /* run records the join of the last run wrote per pair (n_pairs int64): the device keeps runs of consecutive
  * dots (j+t, i+t) / (j-t, i+t) as one record; stats[0] stays the number of dots */

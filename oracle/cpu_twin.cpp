@@ -310,7 +310,7 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
 {
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
-    for (int i = 0; i < n && i < 8; ++i) ms[i] = 0.0;
+    for (int i = 0; i < n && i < 10; ++i) ms[i] = 0.0;
     return VAPOR_OK;
 }
 extern "C" int vapor_plan_record_counts(vapor_plan* p, int64_t* rec)

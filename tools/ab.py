@@ -54,6 +54,9 @@ workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.arg
 names = [n for n in names if n not in (str(rounds), workload)]
 for r in range(rounds):
     for n in names:
-        env = dict(os.environ, VAPOR_HIP_LIB=so(n.split("@")[0]), VAPOR_AB_PARAMS=n.partition("@")[2])   # name@param=value,...
+        # name@param=value,...  (engine parameters; an upper-case name is an environment variable of the child: a dev-build switch)
+        kvs = [kv for kv in n.partition("@")[2].split(",") if kv]
+        env = dict(os.environ, VAPOR_HIP_LIB=so(n.split("@")[0]), VAPOR_AB_PARAMS=",".join(kv for kv in kvs if not kv[0].isupper()))
+        env.update(kv.split("=") for kv in kvs if kv[0].isupper())
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", workload], env=env, capture_output=True, text=True)
-        print("%-10s %s %s" % (n, out.stdout.strip(), out.stderr.strip()[-200:] if out.returncode else ""), flush=True)
+        print("%-34s %s %s" % (n, out.stdout.strip(), out.stderr.strip()[-200:] if out.returncode else ""), flush=True)

@@ -1211,16 +1211,19 @@ static CleanGeom clean_geom(int range_words_cap, int want)
 static int async_fold(vapor_plan* p);
 
 // Who cuts the served pairs' records out of the shared dot plots: the clean workgroup of each pair, or remap_kernel before the
-// cleaning.  Measured (profiles/r04_remap_experiments.txt): the clean workgroups win when all of them are resident at once - a
-// batch of the 10 kb shape, where a kernel boundary and a trip of the records through HBM is what the kernel of its own adds -
-// and lose when they run in several rounds (30 kb reads, two workgroups per CU: every target reading the shared plot again
-// costs more than the boundary).  "remap_in_clean": 1 = that rule, 0 = always the kernel, 2 = always the clean workgroups.
+// cleaning.  Measured (profiles/r04_remap_experiments.txt): the clean workgroups win when the plan is a couple of rounds of them
+// - a resident batch of the 10 kb shape, 4 000 pairs at seven workgroups per CU: such a launch is bound by its start, its tail
+// and the chains of loads in between, and a kernel boundary and a trip of the records through HBM is what the kernel of its own
+// adds (+3 % loci/s) - and lose when it is many rounds (cfg3, 15 kb reads: 80 000 pairs at five per CU, 62 rounds: a launch bound by
+// what its workgroups execute, and every target reads the shared plot and searches the interval table again; -3 %).  Between
+// the two measured shapes the rule is a guess: the clean workgroups up to four rounds.
+// "remap_in_clean": 1 = that rule, 0 = always the kernel, 2 = always the clean workgroups.
 static bool remap_in_clean(const vapor_plan* p)
 {
     if (p->n_dpairs <= 0 || p->ctx->remap_in_clean == 0) return false;
     if (p->ctx->remap_in_clean == 2) return true;
     const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
-    return p->n_pairs <= (int64_t)cg.per_cu * p->ctx->n_cus;
+    return p->n_pairs <= 4 * (int64_t)cg.per_cu * p->ctx->n_cus;
 }
 
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr, bool skip_big = false,
@@ -1352,9 +1355,10 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
 {
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
-    double v[8] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish,
-                   (double)p->n_served, (double)p->n_dpairs};
-    for (int i = 0; i < n && i < 8; ++i) ms[i] = v[i];
+    const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
+    double v[10] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish,
+                    (double)p->n_served, (double)p->n_dpairs, (double)cg.per_cu, remap_in_clean(p) ? 1.0 : 0.0};
+    for (int i = 0; i < n && i < 10; ++i) ms[i] = v[i];
     return VAPOR_OK;
 }
 

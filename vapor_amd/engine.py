@@ -198,10 +198,11 @@ class Plan:
         return self.stats[:self.n]
 
     def timings(self) -> dict:
-        ms = np.zeros(8, dtype=np.float64)
-        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 8))
+        ms = np.zeros(10, dtype=np.float64)
+        L.check(L.load().vapor_plan_timings(self._h, L.ptr(ms, ctypes.c_double), 10))
         return {"join_ms": ms[0], "clean_ms": ms[1], "total_ms": ms[2], "join_launches": int(ms[3]),
-                "retried_pairs": int(ms[4]), "finish_ms": ms[5], "pairs_served_by_shared_joins": int(ms[6]), "shared_joins": int(ms[7])}
+                "retried_pairs": int(ms[4]), "finish_ms": ms[5], "pairs_served_by_shared_joins": int(ms[6]), "shared_joins": int(ms[7]),
+                "clean_workgroups_per_cu": int(ms[8]), "remap_in_clean": int(ms[9])}
 
     def record_counts(self) -> np.ndarray:
         """Run records per pair of the last run (the device stores runs of consecutive dots as one record)."""
