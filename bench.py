@@ -538,28 +538,41 @@ def inclusive_rate(eng, w, wl, reps: int = 6):
     for _ in range(reps):
         times.append(batch(eng, parts)[0])
     t_one = float(np.median(times))
-    # several batches in flight: as many as cli.score_jobs keeps chunks of a run in flight (VAPOR_CHUNKS_IN_FLIGHT, default 3)
+    # several batches in flight: as many as cli.score_jobs keeps chunks of a run in flight (VAPOR_CHUNKS_IN_FLIGHT, default 3).
+    # A run keeps its contexts for all of its chunks, so the figure wanted is the steady one: every context is warmed with a
+    # few batches, the timed region lasts `in_flight_batches` batches per thread (about half a second), and the line carries
+    # the region's first eight batches per thread beside it (new contexts: staging buffers and device pools still growing -
+    # what the eight-batch region of rounds 3 and 4 measured, tools/inclusive_probe.py).
     n_fl = max(2, int(os.environ.get("VAPOR_CHUNKS_IN_FLIGHT", "3")))
     more = [Engine(eng.device) for _ in range(n_fl - 1)]
     for e in more:
         batch(e)
-    n_each = max(reps, 8)
+    n_each = max(reps, int(os.environ.get("VAPOR_BENCH_INFLIGHT_BATCHES", "150")))
     recs = [None] * n_fl
+    stamps = [[] for _ in range(n_fl)]
 
     def worker(k, e):
         for _ in range(n_each):
             recs[k] = batch(e)[1].copy()
+            stamps[k].append(time.perf_counter())
     th = [threading.Thread(target=worker, args=(k, e)) for k, e in enumerate([eng] + more)]
     t0 = time.perf_counter()
     for x in th:
         x.start()
     for x in th:
         x.join()
-    t_two = (time.perf_counter() - t0) / (n_fl * n_each)
+    t_two = (time.perf_counter() - t0) / (n_fl * n_each)                     # the whole region, its start included
+    n_first = min(8, n_each)
+    t_first = (max(st[n_first - 1] for st in stamps) - t0) / (n_fl * n_first)
+    half = n_each // 2
+    t_late = ((max(st[-1] for st in stamps) - min(st[half - 1] for st in stamps)) / (n_fl * (n_each - half))) if half >= 1 and n_each > half else t_two
     same = all(np.array_equal(np.isnan(recs[0]), np.isnan(r)) and np.array_equal(recs[0][~np.isnan(recs[0])], r[~np.isnan(r)]) for r in recs[1:])
     for e in more:
         e.close()
     return {"value": round(w.n_loci / t_two, 2), "unit": "loci/s", "batches_in_flight": n_fl, "ms_per_batch_in_flight": round(t_two * 1e3, 3),
+            "in_flight_batches_per_thread": n_each,
+            "first_8_batches": {"value": round(w.n_loci / t_first, 2), "ms_per_batch": round(t_first * 1e3, 3)},
+            "second_half": {"value": round(w.n_loci / t_late, 2), "ms_per_batch": round(t_late * 1e3, 3)},
             "one_at_a_time": {"value": round(w.n_loci / t_one, 2), "ms_per_batch": round(t_one * 1e3, 3),
                               "ms": dict(zip(("upload_pack", "window_selfplots", "plan", "join_clean_finish"), [round(x / reps * 1e3, 3) for x in parts]))},
             "records_equal": bool(same),
