@@ -247,6 +247,69 @@ def test_shared_join_overflow_is_resized(eng, oracle):
     assert st[0, 0] > 20000
 
 
+@pytest.mark.parametrize("route", [0, 2])
+def test_served_pairs_on_the_big_path_equal_pairs_joined_on_their_own(eng, oracle, route):
+    """Dot plots too large for a clean workgroup's LDS (more than 65 535 dots: clean_big_kernel) that are SERVED by a shared join,
+    cut out by either route: every statistic and every per-dot flag equals those of the same texts uploaded as bytes and joined
+    pair by pair, the dots equal the oracle's - for a deletion allele and for one with a reversed stretch."""
+    unit = "ACGGTCATTG"
+    ref = "TTGACCAGTCCATGGACTAGC" * 10 + unit * 300 + "GGATCCATTGACGTTAGCATC" * 10
+    n = len(ref)
+    del_segs = [(0, 0, 400, False), (0, 900, n - 900, False)]
+    inv_segs = [(0, 0, 500, False), (0, 500, 700, True), (0, 1200, n - 1200, False)]
+    del_txt = ref[:400] + ref[900:]
+    inv_txt = ref[:500] + _rc(ref[500:1200]) + ref[1200:]
+    reads = [(unit * 200)[:1900], ref[100:2100], _rc(ref[300:1700])]
+    rows_d, rows_l = [], []
+    for r in range(len(reads)):
+        for a in range(3):                                   # window, deletion allele, inversion allele
+            miss = (0, 13)[r % 2]
+            rows_d.append((1 + r, 0 if a == 0 else 3 + a, miss, 10, L.PF_C1 | L.PF_C2 | L.PF_DIR))
+            rows_l.append((1 + r, 0 if a == 0 else 3 + a, miss, 10, L.PF_C1 | L.PF_C2 | L.PF_DIR))
+    texts = [ref] + reads + [del_txt, inv_txt]
+
+    def run(ss, rows):
+        plan = eng.plan(ss, eng.make_pairs(rows))
+        try:
+            st = plan.run().copy()
+            hits, fl, off = plan.fetch_hits(range(plan.n), want_flags=True)
+            tm = plan.timings()
+            again = plan.run().copy()                         # (a second pass over sized slots gives the same)
+        finally:
+            plan.close()
+        assert np.array_equal(st, again)
+        per = []
+        for t in range(len(off) - 1):
+            h, f = hits[off[t]:off[t + 1]], fl[off[t]:off[t + 1]]
+            o = np.lexsort((f, h[:, 1], h[:, 0]))             # (a dot can lie on both strands: its two flags in a fixed order)
+            per.append((h[o], f[o]))
+        return st, per, tm
+
+    eng.set_param("remap_in_clean", route)
+    try:
+        ss = eng.seqset([ref] + reads, derived=[(del_segs, False), (inv_segs, False)])
+        try:
+            st, per, tm = run(ss, rows_d)
+        finally:
+            ss.close()
+    finally:
+        eng.set_param("remap_in_clean", 1)
+    assert tm["shared_joins"] == len(reads) and tm["pairs_served_by_shared_joins"] == 3 * len(reads)
+    assert tm["remap_in_clean"] == (1 if route == 2 else 0)
+    lit = eng.seqset(texts)
+    try:
+        st0, per0, tm0 = run(lit, rows_l)
+    finally:
+        lit.close()
+    assert tm0["shared_joins"] == 0
+    assert int(st0[:, 0].max()) > 65535                       # (the case is on the big path)
+    assert np.array_equal(st, st0), np.argwhere(st != st0)[:8]
+    for t, (s1, s2, off2, k, _f) in enumerate(rows_l):
+        assert np.array_equal(per[t][0], per0[t][0]) and np.array_equal(per[t][1], per0[t][1]), t
+        exp = oracle.dotdata_array(k, texts[s1], texts[s2][off2:]).reshape(-1, 2)
+        assert np.array_equal(per[t][0], exp), (t, len(per[t][0]), len(exp))
+
+
 def check_random_structures(eng, oracle, n_windows=6, seed=1234):
     """Random segment lists - two to six slices of a window (some reversed, some a few bases short, some overlapping, some
     from a second text) - as derived alleles: the dots of every (read, allele) pair equal the oracle's on the text the segments
