@@ -177,10 +177,11 @@ def main() -> None:
         if backend == "nccl" and os.environ.get("VAPOR_BENCH_NCCL_EAGER") == "1":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         elif backend == "nccl":
-            # (no device_id: with it torch creates the RCCL communicator eagerly, and from then on this process's clean and
-            # finish kernels - which write to pinned host memory - ran 1.5 x slower on the one-GPU box: 0.178 -> 0.267 ms per
-            # pass with not a single collective in the timed region; created at the first collective it costs nothing.
-            # VAPOR_BENCH_NCCL_EAGER=1 reproduces it.)
+            # (no device_id: with it torch creates the RCCL communicator - and its streams - at once, before the library makes
+            # its own; HIP runs a process's streams on at most GPU_MAX_HW_QUEUES (4) hardware queues, the library's two plans
+            # then share one and stop overlapping: 0.139 -> 0.235 ms per pass with not a single collective in the timed region,
+            # nothing with --plans 1, nothing with GPU_MAX_HW_QUEUES=8 (profiles/r04_eager_communicator.txt).  Created at the
+            # first collective it costs nothing.  VAPOR_BENCH_NCCL_EAGER=1 reproduces it.)
             dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
