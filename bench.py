@@ -314,7 +314,9 @@ def main() -> None:
         if not args.no_cpu:
             cpu = cpu_baseline(w, st, n_pairs, args.cpu_seconds)
     strong = None
-    if world > 1:
+    # (VAPOR_BENCH_FORCE_STRONG=1 with VAPOR_BENCH_FORCE_DIST=1: the same leg with a world of one - on a one-GPU box the only way
+    # to take the product's gather through RCCL: vapor_amd.dist on CUDA tensors, all_gather_object under nccl)
+    if world > 1 or (dist is not None and os.environ.get("VAPOR_BENCH_FORCE_STRONG") == "1"):
         # N > 1: the CPU baseline on rank 0 after the timed region (the other ranks wait at the next barrier), and the
         # fixed-size workload north_star's multi-GPU configurations describe: configs[3]'s 10 000-record VCF sharded over
         # the ranks by estimated cost, scored through the product drivers, one gather of the scores (strong scaling)
