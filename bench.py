@@ -136,7 +136,7 @@ def main() -> None:
     ap.add_argument("--passes-per-step", type=int, default=0, help="0: sized by a probe so that the timed region lasts >= --min-seconds")
     # (>= 6 s: the driver samples the GPU's busy state every 5 s - a 1.2 s timed region, as in rounds 1-3, fell between samples)
     ap.add_argument("--min-seconds", type=float, default=6.5)
-    ap.add_argument("--plans", type=int, default=0, help="plans in flight (0 = two when a join launch is one workgroup per CU, else one)")
+    ap.add_argument("--plans", type=int, default=0, help="plans in flight (0 = two)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inclusive rate and the cfg3 sub-record")
@@ -195,9 +195,11 @@ def main() -> None:
         eng.set_param(kv.split("=")[0], int(kv.split("=")[1]))
     spec = wl.WORKLOADS[args.workload]
     w = wl.make_workload(args.workload, seed=1000 + rank, **spec)
-    # A batch whose join is a single wave of workgroups (one per CU) leaves CUs idle at its tail, which the other plan's
-    # pass fills; a join of many waves of workgroups keeps the chip busy by itself.
-    n_plans = args.plans if args.plans > 0 else (2 if len(w.pairs) <= 64 * 256 else 1)
+    # Two plans in flight: one plan's join runs beside the other's clean, and the tail of either kernel is filled by the other
+    # plan's pass.  Measured on both shapes: cfg2 (4 000 pairs a pass) 0.193 -> 0.138 ms a pass, cfg3 (80 000 pairs, which
+    # this line ran with one plan until the end of round 4 on the assumption that a long join keeps the chip busy by itself)
+    # 3.68 -> 3.29 ms, +12 %; three or four plans lose on cfg2 (profiles/r04_remap_experiments.txt).
+    n_plans = args.plans if args.plans > 0 else 2
     res = Resident(eng, w, wl, n_plans, torch, dist, world, coll)
 
     def barrier():
