@@ -370,3 +370,20 @@ def check_random_structures(eng, oracle, n_windows=6, seed=1234):
 
 def test_shared_joins_on_random_segment_structures(eng, oracle):
     assert check_random_structures(eng, oracle) > 100        # (pairs that were served by shared joins: random structures do not all qualify)
+
+
+def test_shared_joins_fuzz_at_length(eng, oracle):
+    """The same check at the length asked for: VAPOR_FUZZ_WINDOWS windows for each seed of VAPOR_FUZZ_SEEDS (comma-separated),
+    under both routes of the cutting; by default one more seed of six windows per route.  Every (read, allele) pair's dots equal
+    the oracle's dotdata on the text the segments spell.  profiles/r04_fuzz_shared_joins.txt is the log of a long run."""
+    import os
+    n_win = int(os.environ.get("VAPOR_FUZZ_WINDOWS", "6"))
+    seeds = [int(x) for x in os.environ.get("VAPOR_FUZZ_SEEDS", "77").split(",")]
+    for route in (0, 2):
+        eng.set_param("remap_in_clean", route)
+        try:
+            for seed in seeds:
+                served = check_random_structures(eng, oracle, n_windows=n_win, seed=seed)
+                print("fuzz: route %d seed %d: %d windows x 3 derived alleles x 3 k, %d pairs served by shared joins, all dots = oracle's" % (route, seed, n_win, served), flush=True)
+        finally:
+            eng.set_param("remap_in_clean", 1)
