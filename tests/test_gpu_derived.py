@@ -355,13 +355,22 @@ def check_random_structures(eng, oracle, n_windows=6, seed=1234):
             for r in range(len(reads)):
                 miss = int(rng.integers(0, 60)) if r % 2 else 0
                 for a in [0] + [fd + d for d in range(len(der))]:
-                    rows.append((fr + r, a, miss, k, L.PF_C1 | L.PF_C2))
+                    rows.append((fr + r, a, miss, k, L.PF_C1 | L.PF_C2 | L.PF_DIR))
             ss = eng.seqset(seqs, derived=der)
             try:
                 st, dots, tm = _plots(eng, ss, eng.make_pairs(rows))
             finally:
                 ss.close()
             served += tm["pairs_served_by_shared_joins"]
+            # every statistic (both cleaners, the counts, the directed statistics) equals that of the same texts uploaded as
+            # bytes and joined pair by pair - the path tests/test_gpu_parity.py pins on the oracle
+            lit = eng.seqset(allt)
+            try:
+                st_lit, _d, tm_lit = _plots(eng, lit, eng.make_pairs(rows))
+            finally:
+                lit.close()
+            assert tm_lit["shared_joins"] == 0
+            assert np.array_equal(st, st_lit), (wi, k, np.argwhere(st != st_lit)[:6])
             for t, (s1, s2, off2, kk, _fl) in enumerate(rows):
                 exp = oracle.dotdata_array(kk, allt[s1], allt[s2][off2:]).reshape(-1, 2)
                 assert st[t, 15] == 0 and st[t, 0] == len(exp) and np.array_equal(dots[t], exp), (wi, k, t, der, len(dots[t]), len(exp))
@@ -375,7 +384,7 @@ def test_shared_joins_on_random_segment_structures(eng, oracle):
 def test_shared_joins_fuzz_at_length(eng, oracle):
     """The same check at the length asked for: VAPOR_FUZZ_WINDOWS windows for each seed of VAPOR_FUZZ_SEEDS (comma-separated),
     under both routes of the cutting; by default one more seed of six windows per route.  Every (read, allele) pair's dots equal
-    the oracle's dotdata on the text the segments spell.  profiles/r04_fuzz_shared_joins.txt is the log of a long run."""
+    the oracle's dotdata on the text the segments spell, and all sixteen statistics those of the same texts uploaded as bytes.  profiles/r04_fuzz_shared_joins.txt is the log of a long run."""
     import os
     n_win = int(os.environ.get("VAPOR_FUZZ_WINDOWS", "6"))
     seeds = [int(x) for x in os.environ.get("VAPOR_FUZZ_SEEDS", "77").split(",")]
@@ -384,6 +393,6 @@ def test_shared_joins_fuzz_at_length(eng, oracle):
         try:
             for seed in seeds:
                 served = check_random_structures(eng, oracle, n_windows=n_win, seed=seed)
-                print("fuzz: route %d seed %d: %d windows x 3 derived alleles x 3 k, %d pairs served by shared joins, all dots = oracle's" % (route, seed, n_win, served), flush=True)
+                print("fuzz: route %d seed %d: %d windows x 3 derived alleles x 3 k, %d pairs served by shared joins, all dots = oracle's, all statistics = the byte upload's" % (route, seed, n_win, served), flush=True)
         finally:
             eng.set_param("remap_in_clean", 1)
