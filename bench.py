@@ -46,15 +46,13 @@ def _load_json(name):
 
 
 def kernel_source_id() -> str:
-    """sha256 (16 hex digits) over the device code, the host code that launches it and the compiler flags: what a committed
-    counter summary must have been measured on (the host-only helpers - BAM reader, inflate - and the header's prose are not
-    part of it: they cannot move a kernel's counters)."""
-    import hashlib
-    h = hashlib.sha256()
-    for rel in ("vapor_amd/csrc/vapor_kernels.h", "vapor_amd/csrc/vapor_hip.hip", "vapor_amd/build.py"):
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    """The id of the kernel sources in the tree (vapor_amd/build.py) - and the LOADED library must carry it: what a committed
+    counter summary must have been measured on."""
+    from vapor_amd import _lib, build
+    sid = build.kernel_source_id()
+    have = _lib.load().vapor_source_id().decode()
+    assert have.split(":")[0] == sid, "the loaded library was built from other kernel sources (%s) than the tree holds (%s)" % (have, sid)
+    return sid
 
 
 class Resident:

@@ -8,7 +8,7 @@
  * and calls through this ABI with ctypes (INTEGRATION.md shows the binding).
  *
  * Conventions: plain pointers and sizes; all buffers caller-allocated and never retained;
- * every function returns 0 or a negative VAPOR_E_* code (vapor_abi_version, vapor_build_flags, the two *_last_error
+ * every function returns 0 or a negative VAPOR_E_* code (vapor_abi_version, vapor_build_flags, vapor_source_id, the two *_last_error
  * calls and vapor_crc32 return what their names say); vapor_last_error() gives a thread-local message (vapor_bam_last_error()
  * for the host helpers of the read extraction and the output table).  One host thread per context.  No exception crosses the
  * boundary.
@@ -92,6 +92,11 @@ typedef struct vapor_pair {
 /* ---- context --------------------------------------------------------------------------- */
 int vapor_abi_version(void);
 const char* vapor_build_flags(void);
+/* What the binary was built from: "<k>:<a>", k = sha256 (16 hex digits) over the kernel sources and the build recipe
+ * (vapor_kernels.h, vapor_hip.hip, build.py: the id profiles/ cites), a = the same over every source file of the library.  The
+ * loader compares it with the sources beside it and refuses a library that was built from other ones; "cpu-twin" for the
+ * CPU twin, "unknown" for a build outside vapor_amd/build.py. */
+const char* vapor_source_id(void);
 const char* vapor_last_error(void);
 int vapor_init(int device_ordinal, vapor_ctx** ctx);
 int vapor_destroy(vapor_ctx* ctx);

@@ -61,6 +61,7 @@ static bool in_alphabet(unsigned char c)        // invert_base's alphabet after 
 extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION; }
 // says what it is: the product loader (vapor_amd/_lib.py) refuses a library with build flags unless VAPOR_ALLOW_TWIN=1
 extern "C" const char* vapor_build_flags(void) { return "cpu-twin"; }
+extern "C" const char* vapor_source_id(void) { return "cpu-twin"; }
 extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
 extern "C" int vapor_init(int device_ordinal, vapor_ctx** ctx)
 {

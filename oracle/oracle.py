@@ -225,15 +225,21 @@ def dis_to_diagnal_most_abundant_defined(dots):
 
 
 def _as_list(h):
-    return [(int(a), int(b)) for a, b in h]
+    """(j, i) rows as Python ints (lists of two: the scorers only index them)."""
+    return np.asarray(h).tolist()
 
 
-def score_abs_dis_m1b(ref_seq, alt_seq, x, window_size):
-    """calcu_vapor_single_read_score_abs_dis_m1b, SF:182-203."""
+def score_abs_dis_m1b(ref_seq, alt_seq, x, window_size, plots=None):
+    """calcu_vapor_single_read_score_abs_dis_m1b, SF:182-203.  `plots` = (R, A): the two dotdata lists when the caller has
+    filled them already (tests that score thousands of reads fill each plot once for all three scorers; only valid when
+    the windows are upper-case already, which the function checks)."""
     ref_seq = ref_seq.upper()
     alt_seq = alt_seq.upper()
-    R = dotdata_array(window_size, x[0], ref_seq[x[1]:])
-    A = dotdata_array(window_size, x[0], alt_seq[x[1]:])
+    if plots is None:
+        R = dotdata_array(window_size, x[0], ref_seq[x[1]:])
+        A = dotdata_array(window_size, x[0], alt_seq[x[1]:])
+    else:
+        R, A = plots
     if len(R) > 2 and len(A) > 2:
         if float(len(R)) / min([float(len(ref_seq)), float(len(alt_seq))]) > 0.1:
             r_ok = float(R[-1][0] - R[0][0]) / float(len(ref_seq)) > 0.6
@@ -253,10 +259,13 @@ def score_abs_dis_m1b(ref_seq, alt_seq, x, window_size):
     return [0, 0]
 
 
-def score_within_10Perc_m1b(ref_seq, alt_seq, x, window_size):
+def score_within_10Perc_m1b(ref_seq, alt_seq, x, window_size, plots=None):
     """calcu_vapor_single_read_score_within_10Perc_m1b, SF:277-294 (returns alt first)."""
-    R = dotdata_array(window_size, x[0], ref_seq[x[1]:])
-    A = dotdata_array(window_size, x[0], alt_seq[x[1]:])
+    if plots is None:
+        R = dotdata_array(window_size, x[0], ref_seq[x[1]:])
+        A = dotdata_array(window_size, x[0], alt_seq[x[1]:])
+    else:
+        R, A = plots
     if max([float(len(R)) / float(len(ref_seq)), float(len(A)) / float(len(alt_seq))]) > 0.1:
         Rk = R[clean_c2_flags(R) > 0]
         Ak = A[clean_c2_flags(A) > 0]
@@ -266,10 +275,13 @@ def score_within_10Perc_m1b(ref_seq, alt_seq, x, window_size):
     return [0, 0]
 
 
-def score_directed_dis_m1b_redefine_diagnal(ref_seq, alt_seq, x, window_size):
+def score_directed_dis_m1b_redefine_diagnal(ref_seq, alt_seq, x, window_size, plots=None):
     """calcu_vapor_single_read_score_directed_dis_m1b_redefine_diagnal, SF:241-257."""
-    R = dotdata_array(window_size, x[0], ref_seq[x[1]:])
-    A = dotdata_array(window_size, x[0], alt_seq[x[1]:])
+    if plots is None:
+        R = dotdata_array(window_size, x[0], ref_seq[x[1]:])
+        A = dotdata_array(window_size, x[0], alt_seq[x[1]:])
+    else:
+        R, A = plots
     if (float(len(R)) / float(len(ref_seq)) > 0.1 and float(len(A)) / float(len(alt_seq)) > 0.1
             and float(R[-1][0] - R[0][0]) / float(len(ref_seq)) > 0.7
             and float(A[-1][0] - A[0][0]) / float(len(alt_seq)) > 0.7):

@@ -93,3 +93,34 @@ def test_a_stale_library_gets_the_rebuild_message(tmp_path):
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", so + "2", str(src)])
     with pytest.raises(RuntimeError, match="rebuild with"):          # right version, symbols missing
         _lib.checked(ctypes.CDLL(so + "2"), so + "2")
+
+
+def test_the_library_is_tied_to_its_sources_by_content(tmp_path, monkeypatch):
+    """the binary carries the sha of the sources it was built from (vapor_source_id); build() rebuilds on a
+    mismatch instead of on mtime, the loader refuses a library built from other sources, bench.py's kernel_source_id is the
+    loaded library's."""
+    import subprocess
+    import pytest
+    from vapor_amd import _lib, build
+    so = build.build()
+    sid = build.source_id()
+    assert re.fullmatch(r"[0-9a-f]{16}:[0-9a-f]{16}", sid) and sid.split(":")[0] == build.kernel_source_id()
+    assert build.embedded_source_id(so) == sid                            # read from the file, no dlopen
+    assert _lib.load().vapor_source_id().decode() == sid                  # and what the loaded library says
+    import bench
+    assert bench.kernel_source_id() == sid.split(":")[0]
+    # a library with the right ABI version and every symbol, built from "other sources", is refused by content
+    names = [n for n in _declared() if n not in ("vapor_abi_version", "vapor_build_flags", "vapor_source_id")]
+    src = tmp_path / "other.c"
+    src.write_text('int vapor_abi_version(void) { return %d; }\nconst char* vapor_build_flags(void) { return ""; }\n'
+                   'const char* vapor_source_id(void) { return "0123456789abcdef:0123456789abcdef"; }\n' % _lib.ABI_VERSION
+                   + "".join("int %s(void) { return -1; }\n" % n for n in names))
+    other = str(tmp_path / "libother.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", other, str(src)])
+    monkeypatch.delenv("VAPOR_HIP_LIB", raising=False)
+    with pytest.raises(RuntimeError, match="built from sources 0123456789abcdef"):
+        _lib.checked(ctypes.CDLL(other), other)
+    # an untouched source with a fresh mtime does not trigger a rebuild; the decision is the content's
+    before = os.path.getmtime(so)
+    os.utime(os.path.join(ROOT, "vapor_amd", "csrc", "vapor_kernels.h"))
+    assert build.build() == so and os.path.getmtime(so) == before

@@ -110,3 +110,39 @@ def test_error_codes_and_async_surface(eng):
     b = plan.sync().copy()
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     plan.close(); ss.close()
+
+
+def test_timed_workloads_body_on_the_twin(eng, oracle):
+    """The body of tests/test_gpu_workloads.py (the cfg2 / cfg3 batches bench.py times, against the oracle's scorers and
+    finish) on the twin, at a few loci of each shape: the twin's float64 finish and the oracle-side expectation agree."""
+    import test_gpu_workloads as W
+    for name, n in (("cfg2", 4), ("cfg3", 5)):
+        w = W.workload(name, n_loci=n)
+        n_pairs, n_loci, _routes = W.check_workload(eng, oracle, name, w, routes=(1,), want_shared=False)
+        assert n_loci == n and n_pairs == len(w.pairs)
+
+
+def test_allele_with_more_blocks_than_a_descriptor_holds(eng):
+    """a cannot_classify / SVelter alt allele of many blocks (the reference takes any number, SF:1490-1556) gives
+    more segments than VAPOR_MAX_SEGMENTS; the library refuses such a descriptor, so pipeline.describe() must send that allele
+    as bytes - same scores as the same text without segments - and _cat() merges slices that lie end to end."""
+    from vapor_amd import _lib as L
+    from vapor_amd import drivers, pipeline, synth
+    rng = np.random.default_rng(77)
+    ref = synth.random_dna(rng, 6000)
+    blocks = [(400 + 300 * t, 400 + 300 * (t + 1)) for t in range(17)]
+    order = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]        # no two neighbours lie end to end
+    parts = [(ref, None, 400)] + [(ref, blocks[t][0], blocks[t][1], t % 3 == 0) for t in order] + [(ref, 400 + 300 * 17, None)]
+    alt = drivers._cat(*parts)
+    assert alt.segs is not None and len(alt.segs) == 19 > L.MAX_SEGMENTS
+    plain = str(alt)
+    merged = drivers._cat((ref, None, 400), (ref, 400, 700), (ref, 700, 1000), (ref, 1000, 1300, True), (ref, 1300, None))
+    assert [(o, n, rc) for _p, o, n, rc in merged.segs] == [(0, 1000, False), (1000, 300, True), (1300, 4700, False)]
+    reads = [[synth.mutate(rng, src[200:3200], 0.01, 0.05, 0.03)[0], 0, "r%d" % t] for t, src in enumerate((ref, plain, ref, plain))]
+    got = pipeline.score_requests(eng, [drivers.Score("s1", ref, alt, reads, 10)])
+    want = pipeline.score_requests(eng, [drivers.Score("s1", ref, plain, reads, 10)])
+    assert got == want and any(v is not None for v in got[0])
+    # sixteen segments still travel as a descriptor
+    alt16 = drivers._cat(*(parts[:15] + [(ref, blocks[order[14]][0], None)]))
+    assert len(alt16.segs) == 16
+    assert pipeline.score_requests(eng, [drivers.Score("s1", ref, alt16, reads, 10)]) == pipeline.score_requests(eng, [drivers.Score("s1", ref, str(alt16), reads, 10)])

@@ -396,3 +396,47 @@ def test_shared_joins_fuzz_at_length(eng, oracle):
                 print("fuzz: route %d seed %d: %d windows x 3 derived alleles x 3 k, %d pairs served by shared joins, all dots = oracle's, all statistics = the byte upload's" % (route, seed, n_win, served), flush=True)
         finally:
             eng.set_param("remap_in_clean", 1)
+
+
+def test_shared_plot_beyond_max_pair_cap_marks_every_served_pair(eng, oracle):
+    """a SHARED dot plot that needs more records than max_pair_cap cannot grow; the pairs cut from it would be
+    cut from a truncated plot although their own slots do not overflow.  Every pair it serves keeps VAPOR_E_OVERFLOW
+    (include/vapor_hip.h, "max_pair_cap") through vapor_plan_run and vapor_plan_run_loci - which used to call itself without
+    end here - under both routes; with the default cap the same plan gives the oracle's dots."""
+    unit = "ACGGTCATTG"
+    ref = "TTGACCAGTCCATGGACTAGC" * 10 + unit * 150 + "GGATCCATTGACGTTAGCATC" * 10
+    n = len(ref)
+    a0, a1 = 215, 210 + 1495                                   # the deletion takes nearly all of the repeat
+    alt = ref[:a0] + ref[a1:]
+    read = (unit * 120)[:1100]
+    rows = [(1, 0, 0, 10, 3), (1, 2, 0, 10, 3)]
+    table = np.zeros(1, dtype=L.READ_DTYPE)
+    table["ref_a"] = table["ref_b"] = 0
+    table["alt_a"] = table["alt_b"] = 1
+    table["kind"], table["len_ref"], table["len_alt"] = 1, n, len(alt)
+    exp_alt = oracle.dotdata_array(10, read, alt)
+    for route in (0, 2):
+        eng.set_param("remap_in_clean", route)
+        eng.set_param("max_pair_cap", 3000)
+        try:
+            ss = eng.seqset([ref, read], derived=[([(0, 0, a0, False), (0, a1, n - a1, False)], False)])
+            plan = eng.plan(ss, eng.make_pairs(rows))
+            plan.set_reads(table, 1)
+            st = plan.run().copy()
+            tm = plan.timings()
+            assert tm["shared_joins"] == 1
+            assert len(exp_alt) < 3000                            # (the alt pair's own slot is large enough ...)
+            assert st[:, 15].tolist() == [L.E_OVERFLOW, L.E_OVERFLOW], (route, st[:, 15])     # (... its source is not)
+            loci = plan.run_loci(want_scores=True).copy()         # terminates, and scores nothing from a truncated plot
+            assert np.isnan(loci[0, 0]) and np.isnan(plan.read_scores[0])
+            again = plan.run_loci().copy()
+            assert np.isnan(again[0, 0])
+            plan.close(); ss.close()
+        finally:
+            eng.set_param("max_pair_cap", 1 << 28)
+            eng.set_param("remap_in_clean", 1)
+    ss = eng.seqset([ref, read], derived=[([(0, 0, a0, False), (0, a1, n - a1, False)], False)])
+    st, dots, tm = _plots(eng, ss, eng.make_pairs(rows))
+    ss.close()
+    assert tm["shared_joins"] == 1 and st[:, 15].tolist() == [0, 0]
+    assert np.array_equal(dots[1], exp_alt.reshape(-1, 2)) and st[0, 0] > 20000

@@ -1110,3 +1110,24 @@ def test_alleles_travel_as_descriptors_not_as_bytes(fake, tmp_path):
     (seqs, der), = seen
     assert seqs.count(ref) == 1 and alt not in seqs and len(seqs) == 1 + len(reads)
     assert sorted((len(sg), up) for sg, up in der) == [(1, True), (2, False), (2, True)]
+
+
+def test_three_threads_into_a_cold_repeat_check():
+    """the hang of gpurun_out/r4_hang.log (three chunk threads in concurrent first imports of scikit-learn /
+    SciPy inside repeat_qc; fixed in 8596378 by repeat_qc._warm) has a regression test: a fresh interpreter, three threads
+    into a cold cluster_sizes at once, finished within the timeout, never more than one thread inside a first import of the
+    clustering libraries - and without the fix (the negative control) the same harness sees all three in there together."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, VAPOR_QC_SEED="7", HANG_CASE_SECONDS="100")
+    case = os.path.join(ROOT, "tests", "hang_case.py")
+    r = subprocess.run([sys.executable, case], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["threads_importing_at_once"] == 1, got
+    assert got["sizes"][0] == got["sizes"][1] == got["sizes"][2] and len(got["sizes"][0]) >= 1
+    r = subprocess.run([sys.executable, case, "nowarm"], capture_output=True, text=True, timeout=120, env=env)
+    if r.returncode == 0:                                    # (without the fix it may also hang: the dump timer then ends it)
+        assert json.loads(r.stdout.strip().splitlines()[-1])["threads_importing_at_once"] > 1

@@ -38,7 +38,7 @@ ABI_VERSION = 3
 ABI_DEV_OFFSET = 1000000
 
 EXPORTS = [
-    "vapor_abi_version", "vapor_build_flags", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
+    "vapor_abi_version", "vapor_build_flags", "vapor_source_id", "vapor_last_error", "vapor_init", "vapor_destroy", "vapor_set_param",
     "vapor_seqset_create", "vapor_seqset_create_ptrs", "vapor_seqset_create_derived", "vapor_seqset_planes", "vapor_seqset_destroy", "vapor_plan_create", "vapor_plan_destroy",
     "vapor_plan_run", "vapor_plan_timings", "vapor_plan_record_counts", "vapor_plan_algorithmic_bytes", "vapor_plan_fetch_hits",
     "vapor_dotplot_batch", "vapor_score_batch", "vapor_selfplot_qc", "vapor_clean_hits",
@@ -115,6 +115,17 @@ def checked(raw: ctypes.CDLL, lib_path: str) -> ctypes.CDLL:
                                "no CPU fallback (tests set VAPOR_ALLOW_TWIN=1 beside VAPOR_HIP_LIB)" % lib_path)
     elif flags and not dev_ok:
         raise RuntimeError("%s carries developer switches (%s)" % (lib_path, flags))
+    elif not dev_ok:
+        # the product library must be the one built from the sources beside it (content, not mtime: a stale binary newer
+        # than the sources it travelled with would otherwise run - and be profiled - under the new sources' name)
+        from . import build as _build
+        try:
+            raw.vapor_source_id.restype = ctypes.c_char_p
+            have = raw.vapor_source_id().decode()
+        except AttributeError as e:
+            raise RuntimeError(stale % e) from e
+        if os.path.exists(_build.KERNEL_FILES[0]) and have != _build.source_id():
+            raise RuntimeError(stale % ("built from sources %s, the tree holds %s" % (have, _build.source_id())))
     try:
         return bind(raw)
     except AttributeError as e:
@@ -132,6 +143,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_abi_version.restype = ctypes.c_int
     L.vapor_last_error.restype = ctypes.c_char_p
     L.vapor_build_flags.restype = ctypes.c_char_p
+    L.vapor_source_id.restype = ctypes.c_char_p
     L.vapor_init.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.vapor_destroy.argtypes = [vp]
     L.vapor_set_param.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
@@ -174,7 +186,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_plan_set_reads.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, f64p]
     L.vapor_plan_run_loci.argtypes = [vp, vp, f64p, f64p]
     for name in EXPORTS:
-        if name not in ("vapor_last_error", "vapor_bam_last_error", "vapor_build_flags", "vapor_crc32"):
+        if name not in ("vapor_last_error", "vapor_bam_last_error", "vapor_build_flags", "vapor_source_id", "vapor_crc32"):
             getattr(L, name).restype = ctypes.c_int
     return L
 

@@ -1,7 +1,9 @@
 """In-tree build of libvapor_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -25,10 +27,47 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+KERNEL_FILES = [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(HERE, "csrc", "vapor_hip.hip"), os.path.abspath(__file__)]
+_ID_RE = re.compile(rb"VAPOR_SOURCE_ID=([0-9a-f]{16}:[0-9a-f]{16})")
+
+
+def _sha16(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_source_id() -> str:
+    """sha256 (16 hex digits) over the device code, the host code that launches it and this file (the compiler flags): what a
+    committed counter summary must have been measured on.  The host-only helpers (BAM reader, inflate) and the header's
+    prose are not part of it: they cannot move a kernel's counters."""
+    return _sha16(KERNEL_FILES)
+
+
+def source_id() -> str:
+    """`<kernel_source_id>:<sha over every file the library is built from>` - compiled into the library (vapor_source_id())."""
+    return kernel_source_id() + ":" + _sha16(sorted(set(DEPS + [os.path.abspath(__file__)])))
+
+
+def embedded_source_id(so: str = SO):
+    """The id a built library carries, read from the file itself (no dlopen); None for a library built without one."""
+    try:
+        with open(so, "rb") as f:
+            m = _ID_RE.search(f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in DEPS):
+    # (the binary is tied to its sources by content, not by mtime: a library travels to the GPU box in the working tree, and
+    # one that is newer than sources it was not built from would be quoted against fresh counters silently)
+    sid = source_id()
+    if not force and os.path.exists(SO) and embedded_source_id() == sid:
         return SO
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared"] + EXTRA_FLAGS + [
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", '-DVAPOR_SOURCE_ID="%s"' % sid] + EXTRA_FLAGS + [
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            "-Wall", "-Wno-unused-function", "-o", SO] + SOURCES + ["-lz"]
     if verbose:

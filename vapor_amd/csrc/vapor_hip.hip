@@ -277,6 +277,13 @@ extern "C" int vapor_abi_version(void) { return VAPOR_ABI_VERSION; }
 extern "C" const char* vapor_build_flags(void) { return ""; }
 #endif
 extern "C" const char* vapor_last_error(void) { return g_err.c_str(); }
+// what this binary was built from (vapor_amd/build.py: sha256 of the kernel sources ':' sha256 of every source file); the
+// marker in front lets the build read it out of the file without loading it
+#ifndef VAPOR_SOURCE_ID
+#define VAPOR_SOURCE_ID "unknown"
+#endif
+static const char g_source_id[] = "VAPOR_SOURCE_ID=" VAPOR_SOURCE_ID;
+extern "C" const char* vapor_source_id(void) { return g_source_id + 16; }
 
 #define JOIN_DYN_LDS(BPS) 0            // the join's LDS is a static array of the kernel
 
@@ -1338,6 +1345,18 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
         rc = plan_alloc_hits(p);
         if (rc != VAPOR_OK) return rc;
     }
+    if (p->n_dpairs) {
+        // A shared dot plot that needs more than max_pair_cap cannot grow: the records its targets were cut from are a
+        // truncated plot, although the targets' own slots did not overflow.  Every pair it serves keeps VAPOR_E_OVERFLOW
+        // (include/vapor_hip.h, "max_pair_cap") - as a host-side status, so that every later run reports it as well and
+        // vapor_plan_run_loci takes the path that hands the statuses to the finish kernel.
+        std::vector<unsigned long long> dc((size_t)p->n_dpairs);
+        HIPCHK(hipMemcpy(dc.data(), p->d_nhits + p->n_pairs, sizeof(unsigned long long) * dc.size(), hipMemcpyDeviceToHost));
+        for (int64_t t = 0; t < p->n_dpairs; ++t)
+            if ((uint32_t)dc[(size_t)t] > p->hp[(size_t)(p->n_pairs + t)].cap)
+                for (int32_t tg : p->shares[(size_t)t].target)
+                    if (tg >= 0 && p->status[(size_t)tg] == 0) p->status[(size_t)tg] = VAPOR_E_OVERFLOW;
+    }
     for (int64_t i = 0; i < p->n_pairs; ++i) {
         long long* s = p->h_stats + 16 * i;
         if (p->status[i] != 0) {
@@ -1655,6 +1674,9 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
         // first run, or pairs the host marked as failed: full path once (statistics to the host, slots grown)
         rc = vapor_plan_run(p, p->last_stats.data());
         if (rc != VAPOR_OK) return rc;
+        // (the run itself may have given pairs a host-side status: the targets of a shared dot plot beyond max_pair_cap)
+        for (int64_t i = 0; i < p->n_pairs && !host_status; ++i)
+            if (p->status[i] != 0) host_status = true;
         if (host_status)
             HIPCHK(hipMemcpyAsync(p->d_stats, p->h_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyHostToDevice, st));
     } else {

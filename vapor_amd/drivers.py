@@ -112,11 +112,17 @@ def _cat(*parts) -> Allele:
         if segs is not None and n:
             base = getattr(src, "segs", None)
             if base is not None and not rc and len(base) == 1 and not base[0][3]:
-                segs.append((base[0][0], base[0][1] + i0, n, False))      # (a slice of a one-slice allele: of its parent)
+                seg = (base[0][0], base[0][1] + i0, n, False)             # (a slice of a one-slice allele: of its parent)
             elif type(src) is str:
-                segs.append((src, i0, n, rc))
+                seg = (src, i0, n, rc)
             else:
                 segs = None
+                continue
+            last = segs[-1] if segs else None
+            if last is not None and not seg[3] and not last[3] and last[0] is seg[0] and last[1] + last[2] == seg[1]:
+                segs[-1] = (last[0], last[1], last[2] + n, False)         # (two forward slices that lie end to end: one slice)
+            else:
+                segs.append(seg)
     out = Allele("".join(text))
     out.segs = segs
     return out

@@ -250,6 +250,8 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
         """Index of `sq` (upper-cased when `up`) in the set: a literal, or - (d + 1) for derived sequence d (their place behind
         the literals is known when all literals are)."""
         segs = getattr(sq, "segs", None)
+        if segs is not None and len(segs) > L.MAX_SEGMENTS:
+            segs = None               # (more blocks than a descriptor holds, include/vapor_hip.h: this allele travels as bytes)
         if segs is not None and segs:
             # (a reversed slice needs a parent complementary() keeps whole, SF:471-478: the library checks the same)
             for par, _o, _n, rc in segs:
