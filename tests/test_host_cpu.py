@@ -1131,3 +1131,41 @@ def test_three_threads_into_a_cold_repeat_check():
     r = subprocess.run([sys.executable, case, "nowarm"], capture_output=True, text=True, timeout=120, env=env)
     if r.returncode == 0:                                    # (without the fix it may also hang: the dump timer then ends it)
         assert json.loads(r.stdout.strip().splitlines()[-1])["threads_importing_at_once"] > 1
+
+
+def test_sort_rows_is_gnu_sort_version_order():
+    """ConcatVaPoR's `sort -Vk1,1 -k2,2n -k3,3n` (wdl/TasksBenchmark.wdl:286-301) is pinned on the real
+    thing - coreutils' sort (LC_ALL=C) over a table of 12 000 contigs with the names genomes really carry (chr2_alt,
+    chrUn_*, *_random, GL000207.1, HLA-A*01:01, leading zeros, suffixes, '~') - not on workflow's own reader."""
+    import random
+    import shutil
+    import subprocess
+    from vapor_amd import workflow
+    if not shutil.which("sort"):
+        pytest.skip("no coreutils sort")
+    random.seed(5)
+    names = ["chr%d" % i for i in range(1, 23)] + [
+        "chrX", "chrY", "chrM", "chrEBV", "chr2_alt", "chr2_KI270715v1_random", "chr10_alt", "chr1_alt", "chrUn_KI270302v1", "chrUn_GL000195v1",
+        "chrUn_KI270302v2", "chr11_KI270721v1_random", "GL000207.1", "KI270728.1", "HLA-A*01:01:01:01", "HLA-DRB1*15:01:01:01", "1", "2", "10",
+        "X", "MT", "chr01", "chr1a", "chr1_", "chr1-2", "chr1~x", "chr1.fa", "chr1.2.fa", "Chr1", "chr", "chr00", "chr1.10", "chr1.9", "chr1.fa.gz",
+        "chr1.fa~", ".hidden", ".hidden2", "chr1.a1", "chr1.1a", "a.b.c", "a.b", "a", "a.0", "a.00", "a.b~", "000", "0", "00x", "x00", "x0", "x"]
+    names += ["ctg%06d" % random.randrange(10 ** 6) for _ in range(6000)] + ["scaf_%d.%d" % (random.randrange(300), random.randrange(30)) for _ in range(3000)]
+    names += ["chrUn_%s%06dv%d" % (random.choice(["KI", "GL", "JH"]), random.randrange(10 ** 6), random.randrange(1, 4)) for _ in range(3000)]
+    assert len(set(names)) > 11000
+    rows = []
+    for n in names:
+        for _ in range(random.choice([1, 1, 2, 3])):
+            a = random.randrange(0, 10 ** 8)
+            rows.append("%s\t%d\t%d\tDEL\t0.5" % (n, a, a + random.randrange(1, 10 ** 5)))
+    rows += ["chr1\t100\t200\tDEL\t1", "chr1\t100\t200\tDEL\t0", "chr1\t100\t150\tINV\t1", "chr1\t99\t1000\tINV\t1", "chr1\t0100\t120\tX\t1",
+             "chr1\t-5\t10\tX\t1", "chr1\t1e3\t10\tX\t1", "chr1\t12.5\t10\tX\t1", "chr1\t.5\t10\tX\t1", "chr1\tNA\t10\tX\t1"]
+    random.shuffle(rows)
+    want = subprocess.run(["sort", "-Vk1,1", "-k2,2n", "-k3,3n"], input="\n".join(rows) + "\n", capture_output=True, text=True,
+                          env=dict(os.environ, LC_ALL="C"), check=True).stdout.splitlines()
+    got = workflow.sort_rows(rows)
+    bad = [t for t in range(len(want)) if got[t] != want[t]]
+    assert not bad, (len(bad), [(got[t][:40], want[t][:40]) for t in bad[:5]])
+    # and name against name, both ways round
+    some = names[:80]
+    srt = subprocess.run(["sort", "-V"], input="\n".join(sorted(set(some))) + "\n", capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout.splitlines()
+    assert sorted(set(some), key=workflow.version_key) == srt

@@ -183,69 +183,56 @@ def write_output_main(out_name, out_list):
         print(format_output_row(out_list), file=fo)
 
 
+def _info_field(pin, test, take, default):
+    """One accessor for the INFO column (pin[7], ';'-separated) behind the seven reference functions below.  Each of them
+    walks the entries and lets every entry that passes its test overwrite the answer - so the LAST such entry decides, a
+    malformed earlier one still raises where the reference would (every hit is converted), and `default` stands when none
+    passes.  `test`: a substring that must occur anywhere in the entry (str) or a prefix it must start with (('prefix',))."""
+    if isinstance(test, tuple):
+        hits = [x for x in pin[7].split(';') if x[:len(test[0])] == test[0]]
+    else:
+        hits = [x for x in pin[7].split(';') if test in x]
+    vals = [take(x) for x in hits]
+    return vals[-1] if vals else default
+
+
+def _after_equals(x):
+    return x.split('=')[1]
+
+
 def svtype_extract(pin):
-    """SF:1424-1431."""
-    svtype = ''
-    for x in pin[7].split(';'):
-        if 'SVTYPE' in x:
-            svtype = x.split('=')[1]
-    if svtype == '':
-        svtype = pin[4].replace('<', '').replace('>', '')
-    return svtype
+    """SF:1424-1431: SVTYPE from INFO, else the ALT column without its angle brackets."""
+    return _info_field(pin, 'SVTYPE', _after_equals, '') or pin[4].replace('<', '').replace('>', '')
 
 
 def chr_start_end_extract(pin):
-    """SF:365-370."""
-    out = [pin[0], int(pin[1])]
-    for x in pin[7].split(';'):
-        if x[:4] == 'END=' and x.split('=')[0] == 'END':
-            out.append(int(x.split('=')[1]))
-    return out
+    """SF:365-370: [chrom, pos] and an entry for EVERY END= of INFO (the reference appends each)."""
+    return [pin[0], int(pin[1])] + [int(_after_equals(x)) for x in pin[7].split(';') if x[:4] == 'END=']
 
 
 def sv_len_extract(pin):
-    """SF:1433-1440."""
-    v = ''
-    for x in pin[7].split(';'):
-        if 'SVLEN' in x:
-            v = x.split('=')[1]
-    return 0 if v == '' else v
+    """SF:1433-1440: the text behind SVLEN (a str), the int 0 when there is none or it is empty."""
+    return _info_field(pin, 'SVLEN', _after_equals, '') or 0
 
 
 def sv_seq_extract(pin):
     """SF:1442-1447."""
-    seq = ''
-    for x in pin[7].split(';'):
-        if x[:4] == 'SEQ=':
-            seq = x.split('=')[1]
-    return seq
+    return _info_field(pin, ('SEQ=',), _after_equals, '')
 
 
 def sv_insert_point_define(pin):
-    """SF:1449-1456."""
-    v = [0, 0]
-    for x in pin[7].split(';'):
-        if 'insert_point=' in x:
-            v = x.split('=')[1].split(':')
-    return v
+    """SF:1449-1456: insert_point=chrom:pos as a two-element list of str; [0, 0] without one."""
+    return _info_field(pin, 'insert_point=', lambda x: _after_equals(x).split(':'), [0, 0])
 
 
 def INS_length_detect(pin):
     """SF:833-838."""
-    out = 0
-    for x in pin[7].split(';'):
-        if 'SVLEN=' in x:
-            out = int(x.split('=')[1])
-    return out
+    return _info_field(pin, 'SVLEN=', lambda x: int(_after_equals(x)), 0)
 
 
 def polarity_detect(pin):
-    """SF:1147-1152."""
-    out = '+'
-    for x in pin[7].split(';'):
-        if 'MEIINFO=' in x:
-            out = x.split(',')[-1]
-    return out
+    """SF:1147-1152: the last comma-separated piece of the MEIINFO entry."""
+    return _info_field(pin, 'MEIINFO=', lambda x: x.split(',')[-1], '+')
 
 
 def vcf_rec_hash_modify(vcf_rec_hash):

@@ -34,23 +34,127 @@ _NUM = re.compile(r"(\d+)")
 # ---------------------------------------------------------------------------------------------
 # sort -Vk1,1 -k2,2n -k3,3n
 # ---------------------------------------------------------------------------------------------
+def _order(c: str) -> int:
+    """filevercmp's order(): digits 0, letters their code, '~' before everything, the rest after the letters."""
+    if c.isdigit():
+        return 0
+    if c.isalpha():
+        return ord(c)
+    return -1 if c == "~" else ord(c) + 256
+
+
+def _match_suffix(s: str) -> int:
+    """filevercmp's match_suffix(): where a trailing run of `.[A-Za-z~][A-Za-z0-9~]*` groups starts, -1 when there is none."""
+    match, read_alpha = -1, False
+    for t, c in enumerate(s):
+        if read_alpha:
+            read_alpha = False
+            if not (c.isalpha() or c == "~"):
+                match = -1
+        elif c == ".":
+            read_alpha = True
+            if match < 0:
+                match = t
+        elif not (c.isalnum() or c == "~"):
+            match = -1
+    return match
+
+
+def _verrevcmp(a: str, la: int, b: str, lb: int) -> int:
+    """filevercmp's verrevcmp() on a[:la], b[:lb]; like the C, the digit loops look at the characters behind those lengths
+    (the strings end at their NUL there: an index past the end reads as a non-digit here)."""
+    def dig(s, t):
+        return t < len(s) and s[t].isdigit()
+    pa = pb = 0
+    while pa < la or pb < lb:
+        first = 0
+        while (pa < la and not a[pa].isdigit()) or (pb < lb and not b[pb].isdigit()):
+            ca = 0 if pa == la else _order(a[pa])
+            cb = 0 if pb == lb else _order(b[pb])
+            if ca != cb:
+                return ca - cb
+            pa += 1
+            pb += 1
+        while pa < len(a) and a[pa] == "0":
+            pa += 1
+        while pb < len(b) and b[pb] == "0":
+            pb += 1
+        while dig(a, pa) and dig(b, pb):
+            if not first:
+                first = ord(a[pa]) - ord(b[pb])
+            pa += 1
+            pb += 1
+        if dig(a, pa):
+            return 1
+        if dig(b, pb):
+            return -1
+        if first:
+            return first
+    return 0
+
+
+def filevercmp(a: str, b: str) -> int:
+    """GNU `sort -V`'s comparison (gnulib filevercmp.c as of coreutils 8.32, the version in the reference's images), restated:
+    digit runs compare as numbers without their leading zeros, letters sort before other characters, '~' before everything,
+    a trailing `.suffix` run is set aside unless the names are equal without it, names that compare equal fall back to
+    strcmp().  ASCII names (LC_ALL=C), which contig names are."""
+    simple = (a > b) - (a < b)
+    if simple == 0:
+        return 0
+    if not a:
+        return -1
+    if not b:
+        return 1
+    for dots in (".", ".."):
+        if a == dots:
+            return -1
+        if b == dots:
+            return 1
+    if a[0] == "." and b[0] != ".":
+        return -1
+    if a[0] != "." and b[0] == ".":
+        return 1
+    if a[0] == "." and b[0] == ".":
+        a, b = a[1:], b[1:]
+    sa, sb = _match_suffix(a), _match_suffix(b)
+    la = sa if sa >= 0 else len(a)
+    lb = sb if sb >= 0 else len(b)
+    if (sa >= 0 or sb >= 0) and la == lb and a[:la] == b[:lb]:
+        la, lb = len(a), len(b)
+    r = _verrevcmp(a, la, b, lb)
+    return r if r else simple
+
+
 def version_key(s: str):
-    """GNU `sort -V` on contig names: digit runs compare as numbers, the rest byte-wise (chr2 < chr10 < chrX)."""
-    parts = _NUM.split(s)
-    return [(0, int(p)) if k % 2 else (1, p) for k, p in enumerate(parts) if p != ""]
+    """A sort key with filevercmp's order (for callers that sort names by themselves)."""
+    import functools
+    return functools.cmp_to_key(filevercmp)(s)
 
 
 def _num(field: str) -> float:
-    """`sort -n`: leading number, 0 when there is none."""
-    m = re.match(r"\s*-?\d+(\.\d+)?", field)
-    return float(m.group(0)) if m else 0.0
+    """`sort -n`: leading blanks, an optional '-', digits with an optional fraction; 0 when there is no number."""
+    m = re.match(r"[ \t]*(-?\d*\.?\d*)", field)
+    txt = m.group(1) if m else ""
+    try:
+        return float(txt) if any(ch.isdigit() for ch in txt) else 0.0
+    except ValueError:
+        return 0.0
 
 
 def sort_rows(lines: Iterable[str]) -> List[str]:
+    """`sort -Vk1,1 -k2,2n -k3,3n` (wdl/TasksBenchmark.wdl:286-301, LC_ALL=C) of tab-separated rows without blanks inside
+    their first three fields: version order on the contig name, numeric on start and end, the whole line byte-wise as the
+    last resort (sort's default when -s is not given).  The distinct contig names are ranked once with filevercmp (a
+    comparison function is slow in Python; a table has few names and many rows), the rows sort on plain tuples."""
+    import functools
+    rows = [ln for ln in lines if ln]
+    names = sorted({ln.split("\t", 1)[0] for ln in rows}, key=functools.cmp_to_key(filevercmp))
+    rank = {n: t for t, n in enumerate(names)}
+
     def key(ln: str):
         f = ln.split("\t")
-        return (version_key(f[0]), _num(f[1]) if len(f) > 1 else 0.0, _num(f[2]) if len(f) > 2 else 0.0, ln)
-    return sorted((ln for ln in lines if ln), key=key)
+        return (rank[f[0]], _num(f[1]) if len(f) > 1 else 0.0, _num(f[2]) if len(f) > 2 else 0.0, ln)
+    return sorted(rows, key=key)
 
 
 # ---------------------------------------------------------------------------------------------
