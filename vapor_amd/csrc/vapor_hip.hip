@@ -225,6 +225,7 @@ struct vapor_plan {
     double t_join = 0, t_clean = 0, t_total = 0;
     int n_retried = 0;
     bool ran = false;
+    bool flags_valid = false;                  // the last run wrote the per-record flag bytes (vapor_plan_fetch_hits hands them out)
     // optional per-read / per-locus finishing on the device
     int64_t n_reads = 0, n_loci = 0;
     DRead* d_reads = nullptr;
@@ -986,12 +987,15 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             memset(&sh, 0, sizeof sh);
             sh.dpair = (int32_t)p->hp.size();
             sh.iv_first = mp.first; sh.n_iv = mp.second;
+            bool counted = false;
             for (int t = 0; t < 4; ++t) {
                 sh.target[t] = tgt[t];
                 if (tgt[t] >= 0) {
                     served[(size_t)tgt[t]] = 1; ++p->n_served;
                     DServe& sv = p->serve[(size_t)tgt[t]];
                     sv.dpair = sh.dpair; sv.iv_first = sh.iv_first; sv.n_iv = sh.n_iv; sv.slot = t;      // (slot and cap of the join: below)
+                    sv.pad = counted ? 0 : 1;          // (the target whose clean workgroup counts an overflow of the SHARED plot: once per plot)
+                    counted = true;
                 }
             }
             p->hp.push_back(d);
@@ -1233,8 +1237,10 @@ static bool remap_in_clean(const vapor_plan* p)
     return p->n_pairs <= 4 * (int64_t)cg.per_cu * p->ctx->n_cus;
 }
 
+// keep_flags: the clean kernel writes the per-record flag bytes beside the pairs' records - what vapor_plan_fetch_hits hands out;
+// the device-finished path (vapor_plan_run_loci*) needs the statistics only and leaves that pass out.
 static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs = nullptr, hipStream_t on = nullptr, bool skip_big = false,
-                         hipEvent_t before_clean = nullptr)
+                         hipEvent_t before_clean = nullptr, bool keep_flags = true)
 {
     vapor_ctx* c = p->ctx;
     hipStream_t st = on ? on : c->stream;
@@ -1283,8 +1289,9 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
                      (const DPair*)p->d_pairs, (const int32_t*)nullptr, p->d_nhits,
                      p->d_hits, p->d_hflags, p->d_stats, p->range_words_cap,
                      clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1, cg.dual ? 1 : 0,
-                     in_clean ? (const DServe*)p->d_serve : (const DServe*)nullptr, (const int32_t*)p->d_maps);
+                     in_clean ? (const DServe*)p->d_serve : (const DServe*)nullptr, (const int32_t*)p->d_maps, keep_flags ? 1 : 0);
         HIPCHK(hipGetLastError());
+        p->flags_valid = keep_flags;
         // (clean_big_kernel needs a CU with free LDS like any other clean workgroup: behind another plan's join it sits
         // on the stream until that join is over even with nothing to do, and holds back the finish kernel and the
         // plan's next step with it - so an asynchronous step leaves it out when the plan's blocking run left it no pair)
@@ -1415,6 +1422,11 @@ extern "C" int vapor_plan_fetch_hits(vapor_plan* p, int64_t n_sel, const int64_t
     if (!p || n_sel < 0 || (n_sel && (!pair_idx || !hit_off))) return fail(VAPOR_E_ARG, "vapor_plan_fetch_hits: null argument");
     if (!p->ran) return fail(VAPOR_E_ARG, "vapor_plan_fetch_hits: plan has not been run");
     HIPCHK(hipSetDevice(p->ctx->device));
+    if (hit_flags && (!p->flags_valid || p->ring_n > 0)) {
+        // the last pass was a device-finished one (vapor_plan_run_loci*), which writes no per-record flags: run once more, with them
+        int rc0 = vapor_plan_run(p, p->last_stats.data());
+        if (rc0 != VAPOR_OK) return rc0;
+    }
     std::vector<long long> off((size_t)n_sel + 1, 0), sel((size_t)std::max<int64_t>(n_sel, 1), 0);
     for (int64_t q = 0; q < n_sel; ++q) {
         int64_t i = pair_idx[q];
@@ -1578,7 +1590,7 @@ extern "C" int vapor_clean_hits(vapor_ctx* ctx, int64_t n_lists, const int32_t* 
         launch_clean(rw, (unsigned)n_lists, clean_lds_bytes(rw, hcap, cg.dual), st, (const DPair*)d_dp, (const int32_t*)nullptr,
                      d_nh, d_hits, d_fl, d_st, rw,
                      clean_groups_lds(rw, hcap), hcap, d_ov, d_big, 1, cg.dual ? 1 : 0,
-                     (const DServe*)nullptr, (const int32_t*)nullptr);
+                     (const DServe*)nullptr, (const int32_t*)nullptr, 1);
         chk(hipGetLastError(), "clean launch");
         hipLaunchKernelGGL(clean_big_kernel, dim3((unsigned)std::min<int64_t>(n_lists, CLEAN_BIG_GRID)), dim3(CLEAN_THREADS),
                            clean_fixed_bytes(rw, true), st, d_dp, d_nh, d_hits, d_fl, d_st, rw, clean_groups_cap(rw), d_ov, d_big);
@@ -1680,7 +1692,7 @@ extern "C" int vapor_plan_run_loci(vapor_plan* p, void* d_loci_out, double* loci
         if (host_status)
             HIPCHK(hipMemcpyAsync(p->d_stats, p->h_stats, sizeof(long long) * 16 * (size_t)p->n_pairs, hipMemcpyHostToDevice, st));
     } else {
-        rc = plan_run_once(p, false);
+        rc = plan_run_once(p, false, nullptr, nullptr, false, nullptr, false);
         if (rc != VAPOR_OK) return rc;
     }
     hipEvent_t e1 = p->ev_f[1];                  // the finish kernel starts where the clean kernels end (ev[2])
@@ -1870,7 +1882,7 @@ extern "C" int vapor_plan_run_loci_async(vapor_plan* p, void* d_loci_out)
     // run counted before it resized the slots is not theirs
     if (p->ring_n == 0 && p->acc_n == 0) HIPCHK(hipMemsetAsync(p->d_overflow + 2, 0, sizeof(unsigned int), st));
     hipEvent_t* ev = p->ring[(size_t)p->ring_n].data();
-    rc = plan_run_once(p, false, ev, st, p->big_known && p->n_big == 0, (fs != st && p->have_fin) ? p->ev_fin : nullptr);
+    rc = plan_run_once(p, false, ev, st, p->big_known && p->n_big == 0, (fs != st && p->have_fin) ? p->ev_fin : nullptr, false);
     if (rc != VAPOR_OK) return rc;
     double* d_out = d_loci_out ? static_cast<double*>(d_loci_out) : p->d_loci;
     if (fs != st) {

@@ -1996,7 +1996,7 @@ template <bool IN_LDS, int PER_MAX>
 __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh, const DPair& pr, int n, int n_dots, int len2,
                                            int range_words, const unsigned long long* __restrict__ recs_all,
                                            uint8_t* __restrict__ hflags_all, long long* __restrict__ stats,
-                                           int range_words_cap, int groups_cap, int hcap, bool dual_layout)
+                                           int range_words_cap, int groups_cap, int hcap, bool dual_layout, bool keep_flags = true)
 {
     const int tid = threadIdx.x;
     long long* st = stats + (size_t)p * 16;
@@ -2077,7 +2077,9 @@ __device__ __forceinline__ void clean_pair(int p, uint32_t* lds, CleanShared& sh
         // four flag bytes per store (the pair's slot is padded to a multiple of four): the public bits of four records
         // (a thread takes the flags of ONE record - consecutive lanes read consecutive records - and the four lanes of a
         // quad put their bytes together with two quad permutes; the quad's first lane stores the word)
-        {
+        // (keep_flags: only a run whose dots a caller may fetch - vapor_plan_run - writes them; the device-finished path needs the
+        // statistics alone)
+        if (keep_flags) {
             const uint32_t* hi = reinterpret_cast<const uint32_t*>(lrecs) + 1;
             uint32_t* gf4 = reinterpret_cast<uint32_t*>(gflags);
             const int n4 = (n + 3) & ~3;
@@ -2121,7 +2123,8 @@ __device__ __forceinline__ unsigned long long remap_for_target(int p, const DPai
     if (tid < 2 * n_iv) s_ops[tid] = (uint32_t)tb[n_iv + 1 + (tid >> 1) * REMAP_OPS + slot * 2 + (tid & 1)];
     if (tid == 255) { c[0] = 0u; c[1] = 0u; c[2] = 0u; }
     if (nrec > sv.cap) {
-        if (tid == 0 && overflow) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
+        // (counted once per shared plot, as remap_kernel does: by the workgroup of the target the host marked)
+        if (tid == 0 && overflow && sv.pad) { atomicAdd(&overflow[0], 1u); atomicAdd(&overflow[2], 1u); }
         nrec = sv.cap;
     }
     __syncthreads();
@@ -2224,7 +2227,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
     unsigned long long* n_hits, unsigned long long* recs_all,
     uint8_t* __restrict__ hflags_all, long long* __restrict__ stats, int range_words_cap, int groups_cap, int hcap,
     unsigned int* __restrict__ overflow, int32_t* __restrict__ big_list, int big_follows, int dual_layout,
-    const DServe* __restrict__ serve, const int32_t* __restrict__ share_tables)
+    const DServe* __restrict__ serve, const int32_t* __restrict__ share_tables, int keep_flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ CleanShared sh;
@@ -2261,7 +2264,7 @@ __global__ __launch_bounds__(CLEAN_THREADS, 8) void clean_kernel(
         return;
     }
     clean_pair<true, PER_MAX>(p, lds, sh, pr, n, (int)ndots, pr.len2, min((pr.len1 + pr.len2 + 2 + 31) >> 5, range_words_cap),
-                     recs_all, hflags_all, stats, range_words_cap, groups_cap, hcap, dual_layout != 0);
+                     recs_all, hflags_all, stats, range_words_cap, groups_cap, hcap, dual_layout != 0, keep_flags != 0);
 }
 
 // The pairs clean_kernel left (more records than the LDS copy holds, or too many dots for 16-bit counters): the
