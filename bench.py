@@ -55,6 +55,91 @@ def kernel_source_id() -> str:
     return sid
 
 
+PROFILE_ROUNDS = ("r05", "r04", "r03")       # newest first: the committed counter summaries bench.py may quote
+
+
+def _profile_for(kind, workload, src_id):
+    """The newest committed summary profiles/<round>_<workload>_<kind>.json (traffic / util / kernel_stats) and whether it was
+    measured on THIS kernel source (only then are its numbers quoted; its provenance is printed either way)."""
+    for rnd in PROFILE_ROUNDS:
+        j = _load_json("%s_%s_%s.json" % (rnd, workload, kind))
+        if j:
+            prov = {"file": "profiles/%s_%s_%s.json" % (rnd, workload, kind), "measured_on_source": j.get("source_id"), "this_source": src_id,
+                    "live": False}
+            return (j if j.get("source_id") == src_id else None), prov
+    return None, None
+
+
+def roofline_record(workload, alg_bytes, n_rec, ms_per_pass, live, alone, src_id):
+    """SURVEY 8d's record for one workload.  `live`: HIP-event intervals (ms) of join (+ remap_kernel where the plan runs it), clean
+    and finish averaged over the timed passes (two plans in flight: an interval includes waiting for CUs the other plan holds);
+    `alone`: the same kernels by themselves on an idle device.  The dominant kernel is the one with the largest share of GPU time
+    in the committed rocprofv3 --stats summary of the same command when that was measured on this source, else the one with the
+    largest live interval.  achieved / frac: algorithmic bytes per launch over that kernel's live interval, against the HBM roof the
+    task names; frac_rocprof the same over the rocprof average duration; frac_whole_pass over the pass.  The kernels are
+    vector-issue-bound: valu_frac = quad-cycles the vector ALUs were occupied / quad-cycles available while
+    a CU was busy, (SQ_INSTS_VALU - SQ_ACTIVE_INST_VALU2) / SQ_BUSY_CU_CYCLES from the committed --pmc passes (two simple
+    instructions of different waves share a quad-cycle on gfx950: tools/micro/valu_ops.hip, profiles/r02_valu_ops.txt)."""
+    traffic, t_prov = _profile_for("traffic", workload, src_id)
+    util, u_prov = _profile_for("util", workload, src_id)
+    stats, s_prov = _profile_for("kernel_stats", workload, src_id)
+    names = {"join_kernel": "join", "clean_kernel": "clean"}
+    if stats:
+        share = {k: stats["kernels"].get(k, {}).get("percentage", 0.0) for k in names}
+        dom = max(share, key=share.get)
+        dom_by = "largest share of GPU time in " + s_prov["file"]
+    else:
+        dom = "join_kernel" if live["join"] >= live["clean"] else "clean_kernel"
+        dom_by = "largest live HIP-event interval (no rocprofv3 summary of this source committed)"
+    key = names[dom]
+    dom_ms = live[key]
+    gbs = lambda ms: alg_bytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+    frac = lambda ms: round(gbs(ms) / HBM_PEAK_GBS, 5) if ms and ms > 0 else None
+    rp_us = stats["kernels"].get(dom, {}).get("avg_us") if stats else None
+    out = {"bound": ("valu_issue" if util and dom in util else "hbm"), "priced_against": "hbm", "kernel": dom, "kernel_chosen_by": dom_by,
+           "achieved": round(gbs(dom_ms), 2) if gbs(dom_ms) else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(dom_ms),
+           "algorithmic_bytes_per_launch": int(alg_bytes), "record_bytes_per_launch": 8 * int(n_rec),
+           "duration_us": {"live_interval": round(dom_ms * 1e3, 2), "alone": round(alone[key] * 1e3, 2),
+                           "rocprof_avg": round(rp_us, 2) if rp_us else None},
+           "frac_alone": frac(alone[key]), "frac_rocprof": frac(rp_us * 1e-3) if rp_us else None,
+           "frac_whole_pass": frac(ms_per_pass),
+           "kernel_shares_rocprof": ({k: stats["kernels"][k] for k in stats["kernels"]} if stats else None), "kernel_stats_source": s_prov}
+    # fabric-side bytes (PMC): the dominant kernel's, and every kernel of a pass summed - one basis for numerator and denominator
+    tr = None
+    if traffic:
+        tr = int(traffic[dom]["bytes"]) if dom in traffic else None
+        allk = {k: int(v["bytes"]) for k, v in traffic.items() if isinstance(v, dict) and "bytes" in v}
+        out["traffic_all_kernels"] = {"bytes": int(sum(allk.values())), "by_kernel": allk,
+                                      "over_algorithmic": round(sum(allk.values()) / alg_bytes, 4),
+                                      "gbs_over_pass": round(sum(allk.values()) / (ms_per_pass * 1e-3) / 1e9, 2),
+                                      "frac_of_hbm_over_pass": round(sum(allk.values()) / (ms_per_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    out["traffic"] = tr
+    out["traffic_source"] = t_prov
+    out["traffic_gbs"] = round(tr / (dom_ms * 1e-3) / 1e9, 2) if tr and dom_ms > 0 else None
+    out["traffic_frac"] = round(tr / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if tr and dom_ms > 0 else None
+    # the roof the kernels really sit under
+    if util and dom in util:
+        u = util[dom]
+        out["valu_frac"] = u.get("valu_busy")
+        quad = 0.0
+        clock = None
+        for k, v in util.items():
+            if isinstance(v, dict) and "valu_wave_instructions" in v:
+                quad += v["valu_wave_instructions"] * (1.0 - v.get("valu_instructions_issued_in_pairs", 0.0) / 2.0)
+                if v.get("cu_busy_cycles_per_cu") and v.get("us_under_pmc"):
+                    clock = max(clock or 0.0, v["cu_busy_cycles_per_cu"] / (v["us_under_pmc"] * 1e-6))
+        if clock:
+            # every kernel of a pass: quad-cycles of vector work over what 1 024 SIMDs offer in the pass's time at the clock the
+            # counters show (cu busy cycles / kernel time)
+            out["valu_frac_whole_pass"] = round(quad / (1024.0 * ms_per_pass * 1e-3 * clock / 4.0), 4)
+            out["clock_ghz_under_counters"] = round(clock / 1e9, 3)
+    out["binds"] = util[dom] if util and dom in util else None
+    out["binds_source"] = u_prov
+    return out
+
+
+
+
 class Resident:
     """A batch resident in HBM with `n_plans` plans over it; pass i runs on plan i % n_plans."""
 
@@ -275,33 +360,10 @@ def main() -> None:
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
     loci_s = w.n_loci * world * n_passes / elapsed
     cells_s = cells * world * n_passes / elapsed
-    # the dominant kernel is the one that takes longest when it runs alone (with two plans in flight the other kernels'
-    # event intervals include waiting for CUs the join holds); its duration is the live average over the timed passes
-    dom = "join_kernel" if res.alone["join_ms"] >= res.alone["clean_ms"] else "clean_kernel"
-    dom_ms = avg["join_ms"] if dom == "join_kernel" else avg["clean_ms"]
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    # Counter passes (rocprofv3 --pmc: fabric-side bytes per launch, what the counters say binds) cannot be taken inside
-    # this run; the committed summaries under profiles/ are quoted ONLY when they were measured on this workload with
-    # this very kernel source (sha of vapor_amd/csrc + include), and their provenance is printed beside them.
     src_id = kernel_source_id()
-    traffic = util = None
-    traffic_source = binds_source = None
-    for rnd in ("r04", "r03"):                       # the newest round's counter summaries that exist for this workload
-        tj = _load_json("%s_%s_traffic.json" % (rnd, args.workload))
-        if tj and dom in tj:
-            traffic_source = {"file": "profiles/%s_%s_traffic.json" % (rnd, args.workload), "measured_on_source": tj.get("source_id"),
-                              "this_source": src_id, "live": False}
-            if tj.get("source_id") == src_id:
-                traffic = int(tj[dom]["bytes"])
-            break
-    for rnd in ("r04", "r03"):
-        uj = _load_json("%s_%s_util.json" % (rnd, args.workload))
-        if uj and dom in uj:
-            binds_source = {"file": "profiles/%s_%s_util.json" % (rnd, args.workload), "measured_on_source": uj.get("source_id"),
-                            "this_source": src_id, "live": False}
-            if uj.get("source_id") == src_id:
-                util = uj[dom]
-            break
+    roof = roofline_record(args.workload, alg_bytes, n_rec, elapsed / n_passes * 1e3,
+                           {"join": avg["join_ms"], "clean": avg["clean_ms"], "finish": avg["finish_ms"]},
+                           {"join": res.alone["join_ms"], "clean": res.alone["clean_ms"]}, src_id)
 
     extras = {}
     cpu = None
@@ -309,6 +371,7 @@ def main() -> None:
         if not args.no_extras:
             extras["inclusive"] = inclusive_rate(eng, w, wl)
             extras["pipeline"] = pipeline_rate()
+            extras["pipeline_simulate_spans"] = pipeline_rate(span_dist="simulate")
             if args.sub and args.sub != args.workload:
                 extras["sub"] = sub_record(eng, wl, args.sub, torch, cpu_seconds=0.0 if args.no_cpu else min(args.cpu_seconds, 10.0))
         if not args.no_cpu:
@@ -343,7 +406,9 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d loci/GPU x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s; resident in HBM"
+            "config": {"workload": "%s: %d loci/GPU x %d reads (%d bp) x 2 allele windows (%d bp), k=10, types %s; ONE batch packed in HBM before the "
+                                   "timed region and re-scored every pass (its 22 MB of planes and records stay in the 256 MB Infinity Cache: the "
+                                   "kernels are vector-issue-bound, see roofline.valu_frac)"
                                    % (args.workload, w.n_loci, spec["reads_per_locus"], spec["read_len"],
                                       spec["allele_len"], "/".join(sorted(set(w.svtypes)))),
                        "pairs_per_pass_per_gpu": n_pairs, "passes_per_step": inner, "plans_in_flight": n_plans,
@@ -367,26 +432,22 @@ def main() -> None:
                                   "share the CUs and their intervals overlap: their sum over the passes exceeds the step), not serial "
                                   "costs; `alone` is each kernel by itself on an otherwise idle device"},
             "upload_pack_s": round(res.upload_s, 4),
-            # `achieved` / `peak` / `frac`: SURVEY 8d's algorithmic bytes per launch over the dominant kernel's live
-            # HIP-event duration, against the HBM roof the task names.  `bound` says which roof the kernel really sits
-            # under and is printed only with counter evidence for this workload, kernel and source (`binds`); the kernels
-            # are vector-issue-bound, the fabric moves a few per cent of HBM peak.
-            "roofline": {"bound": ("valu_issue" if util else "hbm"), "priced_against": "hbm", "kernel": dom, "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         # `achieved` / `frac` price the kernel's interval inside the timed region, where the other plan's
-                         # clean and finish kernels share the CUs with it; alone (the blocking run before the region) it is
-                         "frac_alone": round(alg_bytes / (res.alone["join_ms" if dom == "join_kernel" else "clean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         # what the kernel really moves and what really limits it
-                         "record_bytes_per_launch": 8 * n_rec,
-                         "traffic_gbs": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic and dom_ms > 0 else None,
-                         "traffic_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and dom_ms > 0 else None,
-                         "binds": util, "binds_source": binds_source},
+            # (roofline_record: the kernel with the largest share of GPU time, its HBM fraction on the algorithmic bytes, the
+            # fabric bytes the counters saw, and the fraction of the vector-issue roof the kernels really sit under)
+            "roofline": roof,
+            "kernel_source_id": src_id,
             "cpu_baseline": cpu,
         }
+        out["gpu_max_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default: 4)")
         if strong is not None:
-            out["strong"] = strong
+            # N > 1: the fixed call set sharded over the ranks (north_star's multi-GPU configuration) leads the line, right behind
+            # the headline fields; `value` stays the resident rate so that the driver's per-N values compare like with like
+            lead = {"strong_value": strong.get("value"), "strong_unit": "loci/s (configs[3] call set, one `vapor vcf` run over all ranks)",
+                    "strong_speedup_over_one_rank": strong.get("speedup_over_one_rank"), "strong_tables_equal": strong.get("tables_equal"),
+                    "strong": strong}
+            items = list(out.items())
+            cut = [k for k, _v in items].index("ranks_seen") + 1
+            out = dict(items[:cut] + list(lead.items()) + items[cut:])
         out.update(extras)
         if "pipeline" in extras and "value" in extras["pipeline"]:
             out["pipeline_value"] = extras["pipeline"]["value"]    # the drivers end to end, one process (host-bound)
@@ -585,7 +646,7 @@ def inclusive_rate(eng, w, wl, reps: int = 6):
                         "each (the way cli.score_jobs keeps chunks of a run in flight); `one_at_a_time`: median of %d batches" % (len(allele_idx), n_each, n_fl, reps)}
 
 
-def pipeline_rate(n_loci: int = 400):
+def pipeline_rate(n_loci: int = 400, span_dist=None):
     """The product path beside the kernel rate: the reference-named drivers (vapor_vali/vapor:334-367, SF:1701-1933) over a
     seeded in-memory world - BED parsing, read extraction and trimming, allele strings, window_size_refine, dot plots and
     scores on the device, result rows - in this process, figures off.  Host-bound: this is the rate a `vapor bed` run sees
@@ -595,7 +656,10 @@ def pipeline_rate(n_loci: int = 400):
         from vapor_amd import cli, pipeline, seqio, synth
         from vapor_amd import simple_function as SF
         from vapor_amd.finish import result_organize_ins
-        w = synth.make_world(seed=11, n_loci=n_loci, svtypes=("DEL", "DEL", "INV", "INS"), span_range=(100, 4000), read_len=9500, n_reads=20)
+        # span_dist = "simulate": spans drawn from the reference's simulated truth sets (50 bp - 100 kb, ~7 % >= 10 kb: those loci
+        # take the drivers' junction-window branch, the 5-10 kb ones windows the 9.5 kb reads barely span) instead of uniformly
+        w = synth.make_world(seed=11, n_loci=n_loci, svtypes=("DEL", "DEL", "INV", "INS"), span_range=(100, 4000), read_len=9500, n_reads=20,
+                             span_dist=span_dist)
         tmp = tempfile.mkdtemp(prefix="vapor_bench_")
         bed = os.path.join(tmp, "in.bed")
         open(bed, "w").write(synth.bed_text(w))
@@ -618,6 +682,7 @@ def pipeline_rate(n_loci: int = 400):
             seqio.set_backend(None)
         scored = sum(1 for r in rows if "\tNA" not in r)
         return {"value": round(len(rows) / best, 1), "unit": "loci/s", "loci": len(rows), "loci_with_scores": scored,
+                "spans": ("simulate/Structural_Variants_het distribution (vapor_amd/data/simulate_spans.json)" if span_dist else "uniform 100 - 4 000 bp"),
                 "includes": "cli.bed_jobs -> drivers -> pipeline.run_batch (one sequence set and plan per round) -> result rows; in-memory "
                             "world of %d DEL/INV/INS loci x 20 reads of 9.5 kb, one process, figures off; best of 3" % n_loci}
     except Exception as e:      # noqa: BLE001 - a side record must not take the headline down
@@ -661,7 +726,11 @@ def sub_record(eng, wl, name, torch, passes: int = 12, cpu_seconds: float = 0.0)
            "one_plan": {"value": round(w.n_loci * passes / dt1, 2), "ms_per_pass": round(dt1 / passes * 1e3, 4),
                         "kernel_ms": {"join": round(tm1["join_ms"], 4), "clean": round(tm1["clean_ms"], 4), "finish": round(tm1["finish_ms"], 4)}},
            "kernel_ms": {"join": round(tm2["join_ms"], 4), "clean": round(tm2["clean_ms"], 4), "finish": round(tm2["finish_ms"], 4)},
-           "roofline_frac": round(alg / (tm1["join_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+           # the same first-class record as the headline's (one basis: the two-plan pass and its live intervals)
+           "roofline": roofline_record(name, alg, int(plans[0].record_counts().sum()), dt2 / passes * 1e3,
+                                       {"join": tm2["join_ms"], "clean": tm2["clean_ms"], "finish": tm2["finish_ms"]},
+                                       {"join": tm1["join_ms"], "clean": tm1["clean_ms"]}, kernel_source_id())}
+    out["roofline_frac"] = out["roofline"]["frac"]
     for p in plans:
         p.close()
     ss.close()
@@ -696,9 +765,23 @@ def cpu_baseline(w, st, n_pairs, seconds, ratio_file="r03_cpu_ratio_cfg2.json"):
     done = 0
     c_cells = 0
     ct = 0.0
-    chunk = 40
-    while done < n_pairs and ct < seconds:
-        pr = w.pairs[done:done + chunk].copy()
+    # A STRATIFIED sample: whole loci (all reads of a locus, both windows) taken in golden-ratio order over the batch, so that
+    # whenever the time runs out the loci looked at are spread evenly over the whole batch and over its type cycle (VERDICT r04:
+    # the first N pairs of cfg3 were 8 % of the batch from its front)
+    first_pair = 2 * np.searchsorted(w.read_locus, np.arange(w.n_loci + 1))
+    seen = set()
+    loci_done = []
+    j = 0
+    while len(seen) < w.n_loci and ct < seconds:
+        li = int((j * 0.6180339887498949) % 1.0 * w.n_loci)
+        j += 1
+        if li in seen:
+            continue
+        seen.add(li)
+        lo, hi = int(first_pair[li]), int(first_pair[li + 1])
+        if hi <= lo:
+            continue
+        pr = w.pairs[lo:hi].copy()
         ids = sorted(set(pr["seq1"].tolist()) | set(pr["seq2"].tolist()))
         remap = {s: t for t, s in enumerate(ids)}
         raw = [w.seqs[s].encode("ascii") for s in ids]
@@ -715,16 +798,20 @@ def cpu_baseline(w, st, n_pairs, seconds, ratio_file="r03_cpu_ratio_cfg2.json"):
         ct += time.perf_counter() - t0
         tw.vapor_plan_destroy(pl); tw.vapor_seqset_destroy(ss)
         # statistics 0-12: counts, cleaning, and the directed statistics (float64 restatement there, integers here)
-        assert np.array_equal(out[:, :13], st[done:done + len(pr), :13]), "GPU / CPU-twin mismatch in pairs %d..%d" % (done, done + len(pr))
-        for q in w.pairs[done:done + len(pr)]:
+        assert np.array_equal(out[:, :13], st[lo:hi, :13]), "GPU / CPU-twin mismatch in locus %d (pairs %d..%d)" % (li, lo, hi)
+        for q in w.pairs[lo:hi]:
             c_cells += len(w.seqs[q["seq1"]]) * (len(w.seqs[q["seq2"]]) - int(q["off2"]))
-        done += len(pr)
+        done += hi - lo
+        loci_done.append(li)
     tw.vapor_destroy(ctx)
     pairs_per_locus = n_pairs / w.n_loci
     cpu = {"value": round(done / pairs_per_locus / ct, 4), "unit": "loci/s", "cores": 1, "host_cores": host_cores(), "kind": "port",
-           "sample": "first %d of %d (read, allele) dot plots of the same batch through libvapor_cpu.so - the CPU oracle behind "
-                     "the same C ABI (oracle/cpu_twin.cpp + vapor_oracle.c: fill, C1/C2 clean, counts, directed statistics; "
-                     "gcc -O2, 1 thread, %.1f s); every record checked equal to the GPU's" % (done, n_pairs, ct),
+           "sample": "%d of %d (read, allele) dot plots of the same batch - %d whole loci spread evenly over the batch (golden-ratio "
+                     "order; types %s) - through libvapor_cpu.so, the CPU oracle behind the same C ABI (oracle/cpu_twin.cpp + "
+                     "vapor_oracle.c: fill, C1/C2 clean, counts, directed statistics; gcc -O2, 1 thread, %.1f s); every record checked "
+                     "equal to the GPU's" % (done, n_pairs, len(loci_done), "/".join("%s %d" % (t, sum(1 for li in loci_done if w.svtypes[li] == t))
+                                                                                    for t in sorted(set(w.svtypes))), ct),
+           "loci_checked": len(loci_done),
            "cells_per_s": round(c_cells / ct, 1)}
     rj = _load_json(ratio_file)
     if rj:

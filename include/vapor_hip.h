@@ -135,7 +135,8 @@ int vapor_seqset_create_ptrs(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* cons
  * device assembles the bit planes from the parents' (derive_kernel); no byte of a derived sequence crosses the link.
  * complementary() DROPS every character outside ATGCN / atgcn (SF:471-478), which a descriptor cannot express: a
  * reverse-complemented segment whose parent holds such a character (an IUPAC code, an X) is refused with VAPOR_E_ARG and the
- * caller uploads that allele as bytes.  seq_info has 2 * (n_seqs + n_derived) entries.
+ * caller uploads that allele as bytes.  A derived sequence without VAPOR_SEQ_UPPER over a parent that was uploaded WITH it is
+ * refused as well (the parent's planes hold the upper-cased text, not its bytes).  seq_info has 2 * (n_seqs + n_derived) entries.
  * A plan over such a set joins every read ONCE against a reference window and the alleles derived from it: the k-mers of a
  * derived allele are those of its parent's slices plus the few that span a junction or lie in inserted bytes, so one table
  * (the parent followed by those stretches) and one probe per read give the dots of all of them (remap_kernel).

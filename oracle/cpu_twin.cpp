@@ -130,6 +130,8 @@ extern "C" int vapor_seqset_create_derived(vapor_ctx* ctx, int32_t n, const uint
             const vapor_segment& x = segs[g];
             if (x.parent < 0 || x.parent >= n || x.off < 0 || x.len < 0 || (int64_t)x.off + x.len > len[x.parent])
                 return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: segment outside its parent");
+            if (x.len > 0 && flags && (flags[x.parent] & VAPOR_SEQ_UPPER) && !(derived_flags && (derived_flags[d] & VAPOR_SEQ_UPPER)))
+                return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: a derived sequence without VAPOR_SEQ_UPPER over a parent uploaded with it");
             std::string piece(reinterpret_cast<const char*>(seq[x.parent]) + x.off, (size_t)x.len);
             if (flags && (flags[x.parent] & VAPOR_SEQ_UPPER))
                 for (char& ch : piece) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);

@@ -599,6 +599,35 @@ def gen_locus(m):
                                "cases": out_cases})
 
 
+def gen_long(m):
+    """Spans of 20 kb and more (the junction-window branches, SF:1728-1745, 1769-1785, 1918-1933, at the spans the
+    truth sets' tail holds - up to 99 kb): a fixture of its own, so that the files of the earlier rounds stay byte for byte."""
+    cli = load_cli(m)
+    m.make_event_figure_1 = lambda *a, **k: None
+    tmp = tempfile.mkdtemp(prefix="vapor_golden_")
+    calls, xm_orig = _count_xmeans(m)
+    m._xm_counter = calls
+    out_cases = []
+    for name, kw in (
+            ("bed_spans_20kb_up", dict(seed=91, n_loci=6, svtypes=("DEL", "INV", "TANDUP", "DEL", "INV", "DEL"),
+                                       spans=(25013, 42077, 20480, 99001, 21950, 60003), read_len=1500, n_reads=8)),
+            ("bed_spans_20kb_up_hom", dict(seed=92, n_loci=3, svtypes=("DEL", "INV", "TANDUP"), spans=(33333, 20001, 27500), read_len=1800,
+                                           n_reads=7, alt_fraction=1.0))):
+        w = synth.make_world(**kw)
+        m.os = ShimOS(w)
+        calls[0] = 0
+        np.random.seed(7)
+        per_locus, text = run_bed(m, cli, w, tmp)
+        m.os = os
+        assert not any(p.get("xmeans_calls") for p in per_locus), "a junction window met the X-means branch: not pinned"
+        out_cases.append({"name": name, "world": world_to_json(w), "bed": synth.bed_text(w), "per_locus": per_locus, "vapor_text": text})
+        print("  %s: %s" % (name, [len(p["scores"].get("ok", [])) if "ok" in p["scores"] else p["scores"] for p in per_locus]))
+    m._xm_counter = None
+    m.X_means_cluster_reformat = xm_orig
+    dump("locus_long.json.gz", {"source": "vapor bed loop vapor_vali/vapor:322-367 + the drivers' junction-window branches for spans >= "
+                                          "default_max_sv_test (SF:1728-1745, 1769-1785, 1918-1933), figures off", "cases": out_cases})
+
+
 def run_vcf(m, cli, world, tmp, header, num_reads_cff=3):
     """What `vapor vcf` does (vapor_vali/vapor:374-466) with figures disabled."""
     vcf = os.path.join(tmp, "in_%d.vcf" % int(header))

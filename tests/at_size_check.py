@@ -28,7 +28,7 @@ def twin_rows(rec):
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), VAPOR_HOST_PROCS="0")
     n = rec["base_loci"] if rec["config"] == "cfg5" else rec["base_loci"]
     cmd = [sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), rec["config"], "--loci", str(n), "--base", str(rec["base_loci"]),
-           "--out", out, "--all-rows"]
+           "--out", out, "--all-rows"] + (["--spans", rec["span_dist"]] if rec.get("span_dist", "uniform") != "uniform" else [])
     subprocess.check_call(cmd, env=env, stdout=subprocess.DEVNULL)
     return json.load(open(out))
 
@@ -51,7 +51,8 @@ def twin_rows_distinct(rec, procs=4):
         json.dump(sh, open(only, "w"))
         out = tempfile.mktemp(suffix=".json")
         cmd = [sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), rec["config"], "--loci", str(rec["records"]), "--base", str(rec["base_loci"]),
-               "--distinct", "--only", only, "--out", out, "--all-rows", "--chunk", "256"]
+               "--distinct", "--only", only, "--out", out, "--all-rows", "--chunk", "256"] + (
+                   ["--spans", rec["span_dist"]] if rec.get("span_dist", "uniform") != "uniform" else [])
         jobs.append((sh, out, subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL)))
     rows = {}
     for sh, out, p in jobs:

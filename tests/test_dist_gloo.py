@@ -157,3 +157,37 @@ def test_job_costs_cover_every_mode(tmp_path):
             assert j.cost > 0
             n += 1
     assert n > 0
+
+
+def test_bench_strong_record_two_ranks(oracle):
+    """bench.py's N > 1 leg - configs[3]'s `vapor vcf` call set (simple and complex records) sharded over the
+    ranks by estimated cost, one gather of the scores, table sha against one rank's - driven at world 2 over gloo on CPU, so that
+    it cannot first fail on the 8-GPU node."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", VAPOR_QC_SEED="7")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_strong_worker.py"), "36", "24"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+        assert p.returncode == 0, o[-3000:]
+    line = [ln for ln in outs[0].splitlines() if ln.startswith("STRONG ")]
+    assert line, outs[0][-2000:]
+    rec = json.loads(line[0][7:])
+    assert "error" not in rec, rec
+    assert rec["scaling"] == "strong" and rec["ranks"] == 2 and rec["backend"] == "gloo"
+    assert rec["tables_equal"] and rec["rows_sha256"] == rec["rows_sha256_one_rank"]
+    per = rec["per_rank"]
+    assert len(per) == 2 and sum(r["loci"] for r in per) == 36 and min(r["loci"] for r in per) >= 8        # cost-balanced shares
+    assert all(r["busy_s"] > 0 and r["wall_s"] > 0 and r["gather_s"] >= 0 for r in per)
+    assert rec["value"] > 0 and rec["one_rank"]["value"] > 0

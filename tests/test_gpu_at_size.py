@@ -40,3 +40,19 @@ def test_distinct_world_runner_and_twin_check(tmp_path):
     assert len({row.split("\t", 5)[-1] for _t, row in rec["sample"] if "\tNA" not in row}) > 30          # different loci, different scores
     c = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "at_size_check.py"), out], env=env, capture_output=True, text=True, timeout=900)
     assert c.returncode == 0 and " 0 differ" in c.stdout, (c.stdout[-1500:], c.stderr[-1500:])
+
+
+def test_at_size_runner_with_the_truth_sets_span_distribution(tmp_path):
+    """VERDICT r04 missing 2: a world whose spans follow the reference's simulated truth sets (simulate/Structural_Variants_het:
+    50 bp - 100 kb, 7-10 % of the deletions and inversions >= 10 kb - the drivers' junction-window branch at depth) through the
+    product CLI on the GPU; every row equals the CPU twin's."""
+    out = str(tmp_path / "at_size_sim.json")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_at_size.py"), "cfg5", "--loci", "120", "--base", "120", "--spans", "simulate",
+                        "--all-rows", "--out", out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    assert rec["span_dist"] == "simulate" and rec["records"] == 120 and rec["spans"]["max"] >= 20000 and rec["spans"]["frac_ge_10kb"] >= 0.03
+    assert rec["rows_with_scores"] >= 60
+    c = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "at_size_check.py"), out], env=env, capture_output=True, text=True, timeout=900)
+    assert c.returncode == 0 and " 0 differ" in c.stdout, (c.stdout[-1500:], c.stderr[-1500:])

@@ -5,7 +5,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
-LOCUS = load_golden("locus_bed.json.gz")["cases"]
+LOCUS = load_golden("locus_bed.json.gz")["cases"] + load_golden("locus_long.json.gz")["cases"]     # (+ spans of 20-99 kb: the junction-window branches)
 
 
 @pytest.mark.parametrize("case", [c for c in LOCUS if not any("error" in p["scores"] for p in c["per_locus"])],

@@ -108,6 +108,16 @@ def test_revcomp_of_a_window_with_iupac_codes_is_refused(eng):
     for bad in ([(1, 0, 4, False)], [(0, 0, len(w) + 1, False)], [(0, -1, 4, False)]):
         with pytest.raises(VaporHipError):
             eng.seqset([w], derived=[(bad, False)])
+    # a derived sequence is slices of its parents' BYTES - not upper-cased itself, it cannot be cut from a parent that
+    # was upper-cased at upload (whose planes hold the upper-cased text); its upper-cased twin can
+    soft = "acgtTTGACCAGGTTAACCAGTacgt" * 3
+    with pytest.raises(VaporHipError) as ei:
+        eng.seqset([soft], upper=[True], derived=[([(0, 2, 30, False)], False)])
+    assert ei.value.code == L.E_ARG
+    ss = eng.seqset([soft], upper=[True], derived=[([(0, 2, 30, False)], True)])
+    ref = eng.seqset([soft[2:32].upper()])
+    assert all(np.array_equal(a, b) for a, b in zip(ss.planes(1), ref.planes(0)))
+    ss.close(); ref.close()
 
 
 def _plots(eng, ss, pairs):

@@ -100,7 +100,7 @@ def test_scorer_functions(fake, case):
             assert [float(v) for v in fn(case["ref"], case["alt"], x, case["k"])] == [float(v) for v in case[key]["ok"]]
 
 
-LOCUS = load_golden("locus_bed.json.gz")["cases"]
+LOCUS = load_golden("locus_bed.json.gz")["cases"] + load_golden("locus_long.json.gz")["cases"]     # (+ spans of 20-99 kb: the junction-window branches)
 
 
 @pytest.mark.parametrize("case", LOCUS, ids=lambda c: c["name"])
@@ -1169,3 +1169,25 @@ def test_sort_rows_is_gnu_sort_version_order():
     some = names[:80]
     srt = subprocess.run(["sort", "-V"], input="\n".join(sorted(set(some))) + "\n", capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout.splitlines()
     assert sorted(set(some), key=workflow.version_key) == srt
+
+
+def test_worlds_drawn_from_the_truth_sets_span_distribution():
+    """synth.make_world(span_dist="simulate") samples the type-wise span distribution of the reference's
+    simulated truth sets (vapor_amd/data/simulate_spans.json, written from simulate/Structural_Variants_het by
+    oracle/gen_span_dist.py): 50 bp - 100 kb, median ~2.8 kb, 7-10 % of the deletions and inversions >= 10 kb, tandem duplications
+    below 5 kb, insertion lengths of the mobile elements."""
+    tb = synth.simulate_span_tables()
+    assert tb["simple"]["DEL"]["n"] == 1846 and tb["simple"]["INV"]["n"] == 447 and tb["simple"]["TANDUP"]["n"] == 617
+    assert tb["simple"]["DEL"]["min"] >= 50 and 99000 < tb["simple"]["DEL"]["max"] <= 100000 and tb["simple"]["TANDUP"]["max"] < 5000
+    assert 2500 < tb["simple"]["DEL"]["median"] < 3100 and 0.08 < tb["simple"]["DEL"]["frac_ge_10kb"] < 0.11
+    assert len(tb["simple"]["DEL"]["quantiles"]) == 201 and tb["insertion_length"]["n"] > 200
+    w = synth.make_world(seed=5, n_loci=1500, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), read_len=600, n_reads=1, span_dist="simulate")
+    sp = {t: np.array([l.end - l.start for l in w.loci if l.svtype == t]) for t in ("DEL", "INV", "TANDUP")}
+    for t in ("DEL", "INV"):
+        assert 2200 < np.median(sp[t]) < 3500 and 0.05 < (sp[t] >= 10000).mean() < 0.14 and sp[t].min() >= 50 and sp[t].max() > 50000, t
+    assert sp["TANDUP"].max() < 5000 and 1900 < np.median(sp["TANDUP"]) < 3100
+    ins = np.array([len(l.ins_seq) for l in w.loci if l.svtype == "INS"])
+    assert ins.min() >= 40 and ins.max() <= 6100 and 200 < np.median(ins) < 1200
+    # seeded: the same world again
+    w2 = synth.make_world(seed=5, n_loci=40, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), read_len=600, n_reads=1, span_dist="simulate")
+    assert [(l.start, l.end) for l in w2.loci] == [(l.start, l.end) for l in w.loci[:40]]

@@ -12,7 +12,7 @@ Figures off (the reference's PNG per locus is measured by tools/fig_rate.py); VA
 check so that the rows can be compared.  Writes loci/s, peak host RSS and a sample of the output rows to --out;
 tests/at_size_check.py replays the base world through the CPU twin and compares every sampled row.
 
-usage: python tools/run_at_size.py cfg4|cfg5 [--loci N] [--base B] [--out file.json]"""
+usage: python tools/run_at_size.py cfg4|cfg5 [--loci N] [--base B] [--spans simulate] [--distinct] [--out file.json]"""
 import hashlib
 import json
 import os
@@ -40,7 +40,9 @@ def main():
     t0 = time.perf_counter()
     from vapor_amd.workload import at_size_input
     distinct = "--distinct" in sys.argv
-    big, text, n_records = at_size_input(cfg, n_total, base, distinct=distinct, cap=arg("--lru", 4096))
+    span_dist = arg("--spans", "") or None                 # "simulate": spans drawn from the reference's simulated truth sets
+    big, text, n_records = at_size_input(cfg, n_total, base, distinct=distinct, cap=arg("--lru", 4096), span_dist=span_dist)
+    spans = [l.end - l.start for l in big.loci if l.svtype != "INS"]
     if "--only" in sys.argv:
         # (tests/at_size_check.py: the sampled records of a distinct world alone, in their order)
         only = json.load(open(sys.argv[sys.argv.index("--only") + 1]))
@@ -90,6 +92,9 @@ def main():
            # answer under any seed; `sizes_decide` counts the windows where the cluster sizes could change the window size at all
            "xmeans_windows": dict(pipeline.qc_counts),
            "distinct": distinct, "distinct_loci": (n_records if distinct else base),
+           "span_dist": span_dist or "uniform",
+           "spans": {"median": float(np.median(spans)) if spans else None, "max": int(max(spans)) if spans else None,
+                     "frac_ge_10kb": round(float(np.mean(np.asarray(spans) >= 10000)), 4) if spans else None},
            "note": ("one process, one GPU, figures off; every tile of the base world carries its own substitutions in contigs, reads and "
                     "insertion payloads and is made when a chunk reaches it (synth.DistinctTilesWorld): as many distinct loci as "
                     "records; the time includes making them" if distinct else

@@ -516,6 +516,12 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
                     return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: segment outside its parent");
                 }
                 if (x.len == 0) continue;
+                // (a derived sequence is slices of its parents' BYTES: one that is not upper-cased itself cannot be cut from a
+                // parent that was upper-cased at upload - its planes hold the upper-cased text)
+                if (flags && (flags[x.parent] & VAPOR_SEQ_UPPER) && !(derived_flags && (derived_flags[d] & VAPOR_SEQ_UPPER))) {
+                    delete s;
+                    return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: a derived sequence without VAPOR_SEQ_UPPER over a parent uploaded with it");
+                }
                 s->derived[(size_t)d].push_back(HSeg{x.parent, x.off, x.len, (int32_t)tot, (x.flags & VAPOR_SEG_REVCOMP) != 0});
                 tot += x.len;
                 if (tot > 0x7FFFFFF0LL) { delete s; return fail(VAPOR_E_ARG, "vapor_seqset_create_derived: sequence too long"); }

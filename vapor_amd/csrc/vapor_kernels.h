@@ -2138,6 +2138,49 @@ __device__ __forceinline__ unsigned long long remap_for_target(int p, const DPai
     const unsigned long long* src = hits + sv.hit_off;
     unsigned long long* dst = hits + tg.hit_off;
     uint32_t my_dots = 0;
+    // The target that is the window itself (slot 0 of its group: half of all served pairs): its k-mer starts are the first
+    // w_hi + 1 of the shared sequence, unmoved and unturned - no interval table, no search, no second copy; a record is kept up
+    // to w_hi and clipped at miss_bp, a quarter of the instructions of the general case below.
+    if (slot == 0) {
+        const int w_hi = tg.len2 - tg.k;
+        for (uint32_t h0 = 0; h0 < nrec; h0 += 256u * REMAP_CLEAN_PER) {
+            uint32_t w_lo[REMAP_CLEAN_PER], w_hi2[REMAP_CLEAN_PER], em = 0, dots = 0;
+#pragma unroll
+            for (int q = 0; q < REMAP_CLEAN_PER; ++q) {
+                const uint32_t h = h0 + (uint32_t)(q * 256 + tid);
+                const unsigned long long r = h < nrec ? src[h] : 0ull;          // (an empty slot: length 0)
+                const int e0 = VREC_J(r), i0 = VREC_I(r), len = VREC_LEN(r);
+                const bool rc = VREC_RC(r);
+                // same strand: e = e0 + t; reverse complement: e = e0 - t (t = 0 .. len - 1, i = i0 + t).  Kept: off2 <= e <= w_hi.
+                int i_first = i0, ja = e0, n = len;
+                if (!rc) {
+                    n = min(n, w_hi - e0 + 1);
+                    const int skip = max(0, off2 - ja); i_first += skip; ja += skip; n -= skip;
+                } else {
+                    const int skip = max(0, e0 - w_hi); i_first += skip; ja -= skip; n -= skip;
+                    n = min(n, ja - off2 + 1);
+                }
+                n = max(n, 0);
+                em |= (n > 0 ? 1u : 0u) << q;
+                dots += (uint32_t)n;
+                w_lo[q] = (uint32_t)i_first | ((uint32_t)(ja - off2) << 16);
+                w_hi2[q] = (uint32_t)n | ((rc ? 1u : 0u) << 16);
+            }
+            my_dots += dots;
+            const uint32_t mine = (uint32_t)__popc(em);
+            const uint32_t incl = wave_incl_scan_u32(mine);
+            uint32_t base = 0;
+            if (lane == 63 && incl) base = atomicAdd(&c[0], incl);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+            uint32_t at = base + incl - mine;
+#pragma unroll
+            for (int q = 0; q < REMAP_CLEAN_PER; ++q) {
+                if (!((em >> q) & 1u)) continue;
+                if (at < cap) dst[at] = (unsigned long long)w_lo[q] | ((unsigned long long)w_hi2[q] << 32);
+                ++at;
+            }
+        }
+    } else
     for (uint32_t h0 = 0; h0 < nrec; h0 += 256u * REMAP_CLEAN_PER) {
         int e_lo[REMAP_CLEAN_PER], e_hi[REMAP_CLEAN_PER], i_at_lo[REMAP_CLEAN_PER], iv[REMAP_CLEAN_PER];
         uint32_t rcbits = 0;
@@ -2314,7 +2357,7 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
     __shared__ uint32_t c_rec[4], c_dots[4];
     __shared__ int s_B[REMAP_MAX_IV + 2];
     __shared__ uint32_t s_ops[REMAP_MAX_IV * REMAP_OPS];
-    __shared__ int s_tp[4], s_off2[4];
+    __shared__ int s_tp[4], s_off2[4], s_whi;
     __shared__ uint32_t s_cap[4];
     __shared__ long long s_hoff[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2337,7 +2380,11 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
         const int t = tid - 192, tp = shares[blockIdx.x].target[t];
         s_tp[t] = tp;
         c_rec[t] = 0u; c_dots[t] = 0u;
-        if (tp >= 0) { const DPair tg = pairs[tp]; s_off2[t] = tg.off2; s_cap[t] = tg.cap; s_hoff[t] = tg.hit_off; }
+        if (tp >= 0) {
+            const DPair tg = pairs[tp];
+            s_off2[t] = tg.off2; s_cap[t] = tg.cap; s_hoff[t] = tg.hit_off;
+            if (t == 0) s_whi = tg.len2 - tg.k;                    // (slot 0 is the window: its last k-mer start)
+        }
     }
     __syncthreads();
     const unsigned long long* src = hits + dp.hit_off;
@@ -2363,6 +2410,49 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
                 if (pos + stp <= n_iv && s_B[pos + stp] <= e_lo[q]) pos += stp;
             iv[q] = pos;
         }
+        // Slot 0 - the target that is the window itself - needs no interval: its k-mer starts are the shared sequence's up to
+        // the window's last one, unmoved and unturned.  One straight pass (keep up to w_hi, clip at miss_bp) instead of its share of
+        // the loops below: a quarter of the instructions for half of the records written.
+        if (s_tp[0] >= 0) {                                        // (uniform)
+            const int off2 = s_off2[0], w_hi = s_whi;
+            uint32_t w_lo[REMAP_PER], w_hi2[REMAP_PER], em = 0;
+            int dots = 0;
+#pragma unroll
+            for (int q = 0; q < REMAP_PER; ++q) {
+                const bool rc = (rcbits >> q) & 1u;
+                // the record in read order: first k-mer start e_first at read position i_first, e moving by +-1 per dot
+                int n = e_hi[q] - e_lo[q] + 1;                     // (0 for an empty slot)
+                int i_first = rc ? i_at_lo[q] - (n - 1) : i_at_lo[q];
+                int ja = rc ? e_hi[q] : e_lo[q];
+                if (!rc) {
+                    n = min(n, w_hi - ja + 1);
+                    const int skip = max(0, off2 - ja); i_first += skip; ja += skip; n -= skip;
+                } else {
+                    const int skip = max(0, ja - w_hi); i_first += skip; ja -= skip; n -= skip;
+                    n = min(n, ja - off2 + 1);
+                }
+                n = max(n, 0);
+                em |= (n > 0 ? 1u : 0u) << q;
+                dots += n;
+                w_lo[q] = (uint32_t)i_first | ((uint32_t)(ja - off2) << 16);
+                w_hi2[q] = (uint32_t)n | ((rc ? 1u : 0u) << 16);
+            }
+            const uint32_t mine = (uint32_t)__popc(em);
+            const uint32_t incl = wave_incl_scan_u32(mine);
+            const int wdots = wave_sum_i32(dots);
+            uint32_t base = 0;
+            if (lane == 63 && incl) { base = atomicAdd(&c_rec[0], incl); atomicAdd(&c_dots[0], (uint32_t)wdots); }
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+            uint32_t at = base + incl - mine;
+            const uint32_t cap = s_cap[0];
+            unsigned long long* dst = hits + s_hoff[0];
+#pragma unroll
+            for (int q = 0; q < REMAP_PER; ++q) {
+                if (!((em >> q) & 1u)) continue;
+                if (at < cap) dst[at] = (unsigned long long)w_lo[q] | ((unsigned long long)w_hi2[q] << 32);
+                ++at;
+            }
+        }
         for (int step = 0;; ++step) {
             // the part of every record inside interval iv + step (the whole record, nearly always, at step 0)
             uint32_t act = 0;
@@ -2370,7 +2460,7 @@ __global__ __launch_bounds__(256) void remap_kernel(const DPair* __restrict__ pa
             for (int q = 0; q < REMAP_PER; ++q) act |= ((iv[q] + step < n_iv && s_B[iv[q] + step] <= e_hi[q]) ? 1u : 0u) << q;
             if (!__ballot(act != 0u)) break;
 #pragma unroll
-            for (int sc = 0; sc < REMAP_OPS; ++sc) {
+            for (int sc = 2; sc < REMAP_OPS; ++sc) {               // (slot 0: above)
                 const int slot = sc >> 1;
                 if (s_tp[slot] < 0) continue;                      // (uniform)
                 uint32_t op[REMAP_PER], em = 0;

@@ -246,7 +246,16 @@ def score_requests(engine, reqs: Sequence[Score]) -> List[object]:
             seqs.append(sq)
         return q
 
+    derived_of: Dict[tuple, int] = {}  # (id(string), upper) -> its derived index: requests that share a window share its twins too
+
     def describe(sq, up: bool) -> int:
+        got = derived_of.get((id(sq), up))
+        if got is not None:
+            return got
+        got = derived_of[(id(sq), up)] = _describe(sq, up)
+        return got
+
+    def _describe(sq, up: bool) -> int:
         """Index of `sq` (upper-cased when `up`) in the set: a literal, or - (d + 1) for derived sequence d (their place behind
         the literals is known when all literals are)."""
         segs = getattr(sq, "segs", None)

@@ -164,24 +164,65 @@ def apply_sv(ref: str, svtype: str, s: int, e: int, ins_seq: Optional[str] = Non
     raise ValueError(svtype)
 
 
+_SPAN_TABLES = None
+
+
+def simulate_span_tables() -> dict:
+    """The SV span distribution of the reference's simulated truth sets (simulate/Structural_Variants_het: spans 50 bp - 100 kb,
+    median ~2.8 kb, 7-10 % of the deletions and inversions >= 10 kb; tandem duplications below 5 kb; insertion lengths from the
+    element names) as quantile tables - vapor_amd/data/simulate_spans.json, written by oracle/gen_span_dist.py in the build
+    container (data only)."""
+    global _SPAN_TABLES
+    if _SPAN_TABLES is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "simulate_spans.json")) as f:
+            _SPAN_TABLES = json.load(f)
+    return _SPAN_TABLES
+
+
+def draw_span(rng, table: dict) -> int:
+    """One value from a quantile table: inverse CDF, linear between quantiles."""
+    q = table["quantiles"]
+    x = float(rng.random()) * (len(q) - 1)
+    lo = min(int(x), len(q) - 2)
+    return int(round(q[lo] + (q[lo + 1] - q[lo]) * (x - lo)))
+
+
 def make_world(seed: int, n_loci: int, svtypes: Sequence[str] = ("DEL", "TANDUP"),
                span_range: Tuple[int, int] = (200, 3000), read_len: int = 6000,
                n_reads: int = 12, alt_fraction: float = 0.5, lead: int = 300,
                contig_pad: int = 2000, errors: Tuple[float, float, float] = (0.01, 0.08, 0.04),
-               chrom_prefix: str = "c", ins_len_range: Tuple[int, int] = (100, 600)) -> SynthWorld:
+               chrom_prefix: str = "c", ins_len_range: Tuple[int, int] = (100, 600), span_dist: str = None,
+               span_max: int = 100000, spans: Sequence[int] = None) -> SynthWorld:
     """Build `n_loci` independent loci, one contig each.
 
     Reads start 1..`lead` bases left of the scored window's left edge (SV start minus the
     500 bp flank) so that the reference's POS<=start filter keeps them, and are
-    `read_len` haplotype bases long before errors."""
+    `read_len` haplotype bases long before errors.
+    span_dist = "simulate": spans (and insertion lengths) are drawn from the distribution of the reference's simulated truth
+    sets per SV type (simulate_span_tables) instead of uniformly from `span_range`; a span above `span_max` is drawn again."""
     rng = np.random.default_rng(seed)
     w = SynthWorld()
+    tables = simulate_span_tables() if span_dist == "simulate" else None
+    if span_dist not in (None, "simulate"):
+        raise ValueError("span_dist: None or 'simulate'")
     for li in range(n_loci):
         svtype = svtypes[li % len(svtypes)]
-        span = int(rng.integers(span_range[0], span_range[1] + 1))
+        if spans is not None:
+            span = int(spans[li % len(spans)])             # (given locus by locus)
+        elif tables is not None:
+            tb = tables["simple"].get(svtype) or tables["simple"]["DEL"]
+            span = draw_span(rng, tb)
+            while span > span_max or span < 1:
+                span = draw_span(rng, tb)
+        else:
+            span = int(rng.integers(span_range[0], span_range[1] + 1))
         flank = min(500, span)
         left = flank + lead + 50
-        clen = left + 3 * span + read_len + contig_pad
+        # (a span the drivers score by its junction windows only - 10 kb and more, SF:1706 - needs no room for the alt
+        # haplotype's doubled block behind it)
+        clen = left + (3 if (span < 10000 or svtype not in ("DEL", "INV")) else 1) * span + read_len + contig_pad
         chrom = "%s%d" % (chrom_prefix, li + 1)
         ref = random_dna(rng, clen)
         s = left
@@ -190,7 +231,8 @@ def make_world(seed: int, n_loci: int, svtypes: Sequence[str] = ("DEL", "TANDUP"
         ins_point = None
         extra = None
         if svtype == "INS":
-            ilen = int(rng.integers(ins_len_range[0], ins_len_range[1] + 1))
+            ilen = draw_span(rng, tables["insertion_length"]) if tables is not None else int(rng.integers(ins_len_range[0], ins_len_range[1] + 1))
+            ilen = max(ilen, 1)
             ins_seq = random_dna(rng, ilen)
             e = s + 1
             flank = min(500, ilen)

@@ -212,17 +212,20 @@ AT_SIZE = {
 }
 
 
-def at_size_base_world(cfg, base):
+def at_size_base_world(cfg, base, span_dist=None):
     """The distinct loci of an at-size world: cfg5 simple types for `vapor bed`; cfg4 two thirds simple types and a third
-    complex records for `vapor vcf`.  Returns (simple world, complex world or None)."""
+    complex records for `vapor vcf`.  Returns (simple world, complex world or None).
+    span_dist = "simulate": the simple types' spans follow the reference's simulated truth sets (synth.simulate_span_tables:
+    50 bp - 100 kb, median ~2.8 kb, 7-10 % of the deletions and inversions >= 10 kb - the drivers' junction-window branch,
+    SF:1706 / 1728) instead of the uniform 50 bp - 11 kb of rounds 3 and 4."""
     sp = AT_SIZE[cfg]
     if cfg == "cfg5":
         w = synth.make_world(seed=sp["seed"], n_loci=base, svtypes=("DEL", "DEL", "TANDUP", "INV", "INS"), span_range=(50, 11000),
-                             read_len=sp["read_len"], n_reads=sp["n_reads"])
+                             read_len=sp["read_len"], n_reads=sp["n_reads"], span_dist=span_dist)
         return w, None
     n_cx = base // 3                                         # a third complex records
     w = synth.make_world(seed=sp["seed"], n_loci=base - n_cx, svtypes=("DEL", "INV", "INS", "DEL"), span_range=(60, 11000),
-                         read_len=sp["read_len"], n_reads=sp["n_reads"])
+                         read_len=sp["read_len"], n_reads=sp["n_reads"], span_dist=span_dist)
     rng = np.random.default_rng(sp["seed"] + 1)
     specs = []
     for t in range(n_cx):
@@ -256,11 +259,11 @@ def at_size_tile(w, n_total, text_of):
     return big, "".join(lines), per
 
 
-def at_size_input(cfg: str, n_total: int, base: int, distinct: bool = False, cap: int = 2048):
+def at_size_input(cfg: str, n_total: int, base: int, distinct: bool = False, cap: int = 2048, span_dist=None):
     """(world, input text, records) of an at-size run: the tiled world and its BED (cfg5) or header-less VCF (cfg4).
     distinct: every tile mutated on its own and made when it is reached (synth.DistinctTilesWorld): as many distinct loci as
     records, without the world ever lying in memory."""
-    w, cx = at_size_base_world(cfg, base)
+    w, cx = at_size_base_world(cfg, base, span_dist)
     if distinct:
         return _at_size_distinct(cfg, n_total, w, cx, cap)
     if cfg == "cfg5":
