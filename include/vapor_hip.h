@@ -106,7 +106,11 @@ int vapor_destroy(vapor_ctx* ctx);
  * against a window and alleles derived from it - vapor_seqset_create_derived - is joined once for all of them; 0: one join per
  * pair), "remap_in_clean" (who cuts a served pair's records out of a shared dot plot.  1, the default: the workgroup that cleans
  * the pair when the plan's clean workgroups run in at most four rounds (a resident batch of a few thousand pairs), else a kernel
- * of its own before the cleaning, remap_kernel; 0: always that kernel; 2: always the clean workgroups), "stage_threads" (host threads that copy a
+ * of its own before the cleaning, remap_kernel; 0: always that kernel; 2: always the clean workgroups), "clean_order" (1, the default: the clean kernel's workgroups - one per
+ * pair - are dealt out longest pair first, so that the last round of a plan of a few rounds is made of its shortest pairs; 0: in
+ * pair order), "clean_fit" (1, the default: after a plan's first blocking run the clean workgroups' LDS copy is sized for the
+ * largest record count the pairs really have instead of the estimate made at vapor_plan_create - more workgroups per CU; 0: the
+ * estimate stays), "stage_threads" (host threads that copy a
  * sequence set's bytes into the pinned staging buffer, default 3).  Results do not depend on any of them. */
 int vapor_set_param(vapor_ctx* ctx, const char* name, int64_t value);
 

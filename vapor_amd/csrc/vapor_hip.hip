@@ -95,6 +95,8 @@ struct vapor_ctx {
     int64_t max_pair_cap = (int64_t)1 << 28;
     bool shared_join = true;                   // reads scored against a window and alleles derived from it: one join for all
     int remap_in_clean = 1;                    // ... and the clean workgroup of a target cuts its records out of the shared plot (0: remap_kernel)
+    int clean_order = 1;                       // 1: the clean workgroups are dealt out longest pair first (plan_clean_order); 0: in pair order
+    int clean_fit = 1;                         // 1: after a blocking run the clean kernel's LDS copy is sized for the records the pairs really hold
     int stage_threads = 3;                     // host threads that copy a large upload into the pinned staging buffer (measured:
                                                // two to four are as fast as it gets, more are slower - tools/upload_sweep.py)
     bool attrs_set = false;
@@ -195,6 +197,7 @@ struct vapor_plan {
     std::vector<int64_t> last_stats;
     int range_words_cap = 1;
     int hcap_want = 4096;
+    bool hcap_measured = false;                // hcap_want is the largest record count a blocking run saw (else: an estimate)
     int64_t total_cap = 0;
     DPair* d_pairs = nullptr;
     DTask* d_tasks = nullptr;
@@ -250,6 +253,7 @@ struct vapor_plan {
     int32_t* d_maps = nullptr;
     std::vector<DServe> serve;                 // per pair: where its records come from when a shared join serves it
     DServe* d_serve = nullptr;
+    int32_t* d_clean_order = nullptr;          // the pairs in the order their clean workgroups are dealt out (longest first)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -366,6 +370,14 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     if (!strcmp(name, "remap_in_clean")) {
         if (v < 0 || v > 2) return fail(VAPOR_E_ARG, "vapor_set_param: remap_in_clean is 0, 1 or 2");
         c->remap_in_clean = (int)v;
+        return VAPOR_OK;
+    }
+    if (!strcmp(name, "clean_order")) {
+        c->clean_order = v != 0 ? 1 : 0;
+        return VAPOR_OK;
+    }
+    if (!strcmp(name, "clean_fit")) {
+        c->clean_fit = v != 0;
         return VAPOR_OK;
     }
     if (!strcmp(name, "stage_threads")) {
@@ -767,6 +779,7 @@ static void plan_free_device(vapor_plan* p)
     dfree(p->ctx, p->d_shares); p->d_shares = nullptr;
     dfree(p->ctx, p->d_maps); p->d_maps = nullptr;
     dfree(p->ctx, p->d_serve); p->d_serve = nullptr;
+    dfree(p->ctx, p->d_clean_order); p->d_clean_order = nullptr;
 }
 
 extern "C" int vapor_plan_destroy(vapor_plan* p)
@@ -824,6 +837,34 @@ static int plan_alloc_hits(vapor_plan* p)
             if (sv.dpair >= 0) { sv.hit_off = p->hp[(size_t)sv.dpair].hit_off; sv.cap = p->hp[(size_t)sv.dpair].cap; }
         HIPCHK(hipMemcpyAsync(p->d_serve, p->serve.data(), sizeof(DServe) * p->serve.size(), hipMemcpyHostToDevice, p->ctx->stream));
     }
+    return VAPOR_OK;
+}
+
+// The clean kernel is one workgroup per pair, dealt out in grid order, a few per CU at a time: a plan of a couple of rounds of
+// them (4 000 pairs at seven or eight per CU: two rounds and a bit) ends when the LAST round's slowest workgroup does, so the
+// pairs that take longest go first and the tail is made of the shortest (longest-processing-time order; measured on cfg2: clean
+// 0.091 -> 0.079 ms, profiles/r05_clean_order.txt).  What a pair takes: its records - about the shorter sequence's length -
+// times the passes its flags ask for: C1 two clusterings, C2 one or two more, the directed statistics five passes over the kept
+// records, plus the cutting of a served pair.  Pairs of equal cost keep their order (a read's two pairs lie side by side and
+// read the same shared plot); sorting by the record counts a blocking run measured instead (`records`) was tried and is no
+// better - it scatters those neighbours (0.0738 -> 0.0749 ms) - so the library does not use it.
+static int plan_clean_order(vapor_plan* p, const unsigned long long* records)
+{
+    const int64_t n_pairs = p->n_pairs;
+    std::vector<std::pair<int64_t, int32_t>> cost((size_t)n_pairs);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const DPair& d = p->hp[(size_t)i];
+        const bool c1 = d.flags & VAPOR_PF_C1, c2 = d.flags & VAPOR_PF_C2, dir = (d.flags & VAPOR_PF_DIR) && c1;
+        int64_t w = 4 + (c1 ? 8 : 0) + (c2 ? (c1 ? 5 : 8) : 0) + (dir ? 7 : 0);
+        if (!p->serve.empty() && p->serve[(size_t)i].dpair >= 0) w += p->serve[(size_t)i].slot == 0 ? 2 : 4;
+        const int64_t size = records ? (int64_t)(uint32_t)records[(size_t)i] * 4 + 256
+                                     : std::min<int64_t>(d.len1, std::max(0, d.len2 - d.off2));
+        cost[(size_t)i] = {-(p->status[(size_t)i] == 0 ? w * size : 0), (int32_t)i};
+    }
+    std::stable_sort(cost.begin(), cost.end());
+    std::vector<int32_t> ord((size_t)n_pairs);
+    for (int64_t i = 0; i < n_pairs; ++i) ord[(size_t)i] = cost[(size_t)i].second;
+    HIPCHK(hipMemcpy(p->d_clean_order, ord.data(), sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
     return VAPOR_OK;
 }
 
@@ -1122,6 +1163,10 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         if (rc == VAPOR_OK && !p->tables.empty())
             chk(hipMemcpyAsync(p->d_maps, p->tables.data(), sizeof(int32_t) * p->tables.size(), hipMemcpyHostToDevice, ctx->stream), "copy maps");
     }
+    if (ctx->clean_order && n_pairs > 1) {
+        chk(dmalloc(ctx, (void**)&p->d_clean_order, sizeof(int32_t) * (size_t)n_pairs), "hipMalloc clean order");
+        if (rc == VAPOR_OK && plan_clean_order(p, nullptr) != VAPOR_OK) rc = VAPOR_E_HIP;
+    }
     for (auto& e : p->ev) chk(hipEventCreate(&e), "hipEventCreate");
     for (auto& e : p->ev_f) chk(hipEventCreate(&e), "hipEventCreate");
     chk(hipEventCreate(&p->ev_t0), "hipEventCreate");
@@ -1198,7 +1243,7 @@ static size_t clean_lds_bytes(int rw, int hcap, bool dual)
 // The kernel waits for memory and barriers more than it computes, so residency matters: take the largest number
 // of workgroups per CU (32 waves at most) whose share of the 160 KB still stages ~90 % of the expected records.
 struct CleanGeom { int hcap, per_cu; bool dual; };
-static CleanGeom clean_geom_for(int range_words_cap, int want, bool dual)
+static CleanGeom clean_geom_for(int range_words_cap, int want, bool dual, bool exact = false)
 {
     CleanGeom g{0, 1, dual};
 #ifdef VAPOR_DEV_BUILD
@@ -1208,7 +1253,9 @@ static CleanGeom clean_geom_for(int range_words_cap, int want, bool dual)
         const size_t share = (size_t)(160 * 1024) / per_cu - 512;
         int cap = std::min(want, CLEAN_HCAP_MAX) & ~3;
         while (cap > 0 && clean_lds_bytes(range_words_cap, cap, dual) + 512 > share) cap -= 4;
-        if (cap >= want * 9 / 10 || per_cu == 1) { g.hcap = std::max(cap, 0); g.per_cu = per_cu; break; }
+        // (an estimated `want`: nine tenths of it staged is enough; a measured one - the largest record count of the plan's
+        // pairs - is staged whole, so that no pair is left to clean_big_kernel for the sake of residency)
+        if (cap >= (exact ? want : want * 9 / 10) || per_cu == 1) { g.hcap = std::max(cap, 0); g.per_cu = per_cu; break; }
     }
     return g;
 }
@@ -1216,9 +1263,9 @@ static CleanGeom clean_geom_for(int range_words_cap, int want, bool dual)
 // profiles/r03_clean_variants.txt): the sweep wins where the extra LDS costs no residency (30 kb x 40 kb pairs, two workgroups
 // per CU either way: clean 1.87 -> 1.70 ms) and loses where it does (10 kb x 20 kb: 7 -> 6 per CU, 0.075 vs 0.078 ms; 15 kb x
 // 20 kb: 5 -> 4, 1.32 vs 1.42 ms) - so it is used exactly when it is free.
-static CleanGeom clean_geom(int range_words_cap, int want)
+static CleanGeom clean_geom(int range_words_cap, int want, bool exact = false)
 {
-    const CleanGeom seq = clean_geom_for(range_words_cap, want, false), dual = clean_geom_for(range_words_cap, want, true);
+    const CleanGeom seq = clean_geom_for(range_words_cap, want, false, exact), dual = clean_geom_for(range_words_cap, want, true, exact);
 #ifdef VAPOR_DEV_BUILD
     if (const char* e = getenv("VAPOR_DEV_CLEAN_DUAL")) return atoi(e) ? dual : seq;
 #endif
@@ -1239,7 +1286,7 @@ static bool remap_in_clean(const vapor_plan* p)
 {
     if (p->n_dpairs <= 0 || p->ctx->remap_in_clean == 0) return false;
     if (p->ctx->remap_in_clean == 2) return true;
-    const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
+    const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want, p->hcap_measured);
     return p->n_pairs <= 4 * (int64_t)cg.per_cu * p->ctx->n_cus;
 }
 
@@ -1284,7 +1331,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
     // (the clean kernels overwrite the statistics the previous step's finish kernel reads on its own stream)
     if (before_clean) HIPCHK(hipStreamWaitEvent(st, before_clean, 0));
     if (p->n_pairs > 0) {
-        const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
+        const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want, p->hcap_measured);
         const int hcap = cg.hcap;
         size_t lds = clean_lds_bytes(p->range_words_cap, hcap, cg.dual);
 #ifdef VAPOR_DEV_BUILD
@@ -1292,7 +1339,7 @@ static int plan_run_once(vapor_plan* p, bool fetch_stats = true, hipEvent_t* evs
 #endif
         const bool in_clean = remap_in_clean(p);
         launch_clean(p->range_words_cap, (unsigned)p->n_pairs, lds, st,
-                     (const DPair*)p->d_pairs, (const int32_t*)nullptr, p->d_nhits,
+                     (const DPair*)p->d_pairs, (const int32_t*)p->d_clean_order, p->d_nhits,
                      p->d_hits, p->d_hflags, p->d_stats, p->range_words_cap,
                      clean_groups_lds(p->range_words_cap, hcap), hcap, p->d_overflow, p->d_big_list, skip_big ? 0 : 1, cg.dual ? 1 : 0,
                      in_clean ? (const DServe*)p->d_serve : (const DServe*)nullptr, (const int32_t*)p->d_maps, keep_flags ? 1 : 0);
@@ -1358,6 +1405,22 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
         rc = plan_alloc_hits(p);
         if (rc != VAPOR_OK) return rc;
     }
+    if (p->ctx->clean_fit && p->n_pairs > 0) {
+        // The clean kernel's geometry from what the pairs really hold: a plan is created with an ESTIMATE of the records a pair
+        // will have (a tenth of the shorter sequence plus the chance dots), which sizes the LDS copy and with it the workgroups a
+        // CU holds; the join is deterministic, so after one blocking run the largest record count is known exactly and the copy
+        // is sized for that.  On the 10 kb x 20 kb shape that is eight workgroups per CU instead of seven - and 4 000 pairs are
+        // 1.95 rounds of 2 048 workgroups instead of 2.2 rounds of 1 792, i.e. two rounds instead of three.
+        std::vector<unsigned long long> cnt((size_t)p->n_pairs);
+        HIPCHK(hipMemcpy(cnt.data(), p->d_nhits, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost));
+        uint32_t most = 0;
+        for (int64_t i = 0; i < p->n_pairs; ++i)
+            if (p->status[(size_t)i] == 0 && (uint32_t)(cnt[(size_t)i] >> 32) <= 65535u) most = std::max(most, (uint32_t)cnt[(size_t)i]);
+        if (most > 0 && most <= (uint32_t)CLEAN_HCAP_MAX) {
+            p->hcap_want = (int)((most + 3u) & ~3u);
+            p->hcap_measured = true;
+        }
+    }
     if (p->n_dpairs) {
         // A shared dot plot that needs more than max_pair_cap cannot grow: the records its targets were cut from are a
         // truncated plot, although the targets' own slots did not overflow.  Every pair it serves keeps VAPOR_E_OVERFLOW
@@ -1387,7 +1450,7 @@ extern "C" int vapor_plan_run(vapor_plan* p, int64_t* stats)
 extern "C" int vapor_plan_timings(vapor_plan* p, double* ms, int32_t n)
 {
     if (!p || !ms) return fail(VAPOR_E_ARG, "vapor_plan_timings: null argument");
-    const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want);
+    const CleanGeom cg = clean_geom(p->range_words_cap, p->hcap_want, p->hcap_measured);
     double v[10] = {p->t_join, p->t_clean, p->t_total, (double)p->launches.size(), (double)p->n_retried, p->t_finish,
                     (double)p->n_served, (double)p->n_dpairs, (double)cg.per_cu, remap_in_clean(p) ? 1.0 : 0.0};
     for (int i = 0; i < n && i < 10; ++i) ms[i] = v[i];
