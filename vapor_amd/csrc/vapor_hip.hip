@@ -1093,7 +1093,15 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
             total += probe[t - q] + build[t - q];
             biggest = std::max(biggest, probe[t - q] + build[t - q]);
         }
-        const int64_t want = std::max<int64_t>(1, std::min<int64_t>((int64_t)n, ctx->join_tasks));
+        // `join_tasks` ranges (one per CU) - or, when the limit of reads per task asks for more than that, WHOLE ROUNDS of them: a
+        // launch of 625 tasks on 256 CUs takes three rounds' time for 2.44 rounds' work (BASELINE configs[2]: 40 000 reads in
+        // tasks of at most 64), 768 equal tasks take three rounds of 52 reads each - join 2.42 -> 2.10 ms with one plan in flight
+        // (profiles/r05_join_rounds.txt; with two plans in flight the other plan's clean kernel filled that tail already)
+        int64_t want = std::max<int64_t>(1, std::min<int64_t>((int64_t)n, ctx->join_tasks));
+        {
+            const int64_t need = ((int64_t)n + ctx->reads_per_task - 1) / ctx->reads_per_task;
+            if (need > want) want = std::min<int64_t>((int64_t)n, (need + want - 1) / want * want);
+        }
         // (what a pair adds to a range it does not start: its probe, and a table build when it brings a new allele)
         std::vector<int64_t> inside(n);
         for (size_t t = 0; t < n; ++t)
