@@ -37,7 +37,7 @@ NAMES = {0: "join: table build (+wait prev probe)", 1: "join: strip staging", 2:
 name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "cfg2"
 w = wl.make_workload(name, seed=1000, **wl.WORKLOADS[name])
 eng = Engine(0)
-ss = eng.seqset(w.seqs)
+ss = w.upload(eng)          # (derived alt windows: the plan shares its joins, as bench.py runs it)
 plan = eng.plan(ss, w.pairs)
 lib = L.load()
 lib.vapor_debug_phases.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int32]
