@@ -26,11 +26,13 @@
 
 using namespace vapor;
 
-// Cost of building an allele's table relative to probing one read base against it, in eighths.  Measured on cfg2
-// (tools/tasks_sweep.py, tools/block_times.py): a table of 20 000 positions builds in about 10 us, a 10 000-base
-// read is probed against it in about 12 us, i.e. 0.4 per allele base.
+// Cost of building an allele's table relative to probing one read base against it, in eighths.  Round 2 measured 0.4 per allele
+// base (a table of 20 000 positions ~10 us, a 10 000-base read ~12 us) when a task held sixteen reads; with shared joins a cfg2
+// task holds eight and the same measurement (tools/task_balance.py on a -DVAPOR_BLOCK_TIMING build: tasks with one table 71 us,
+// with two 82-85 us: a table 11 us = 1.5 reads of 7.5 us) gives 0.75: priced at 3 the tasks that straddle two windows were the
+// launch's longest by 15 %.  At 6: cfg2 join 0.0849 -> 0.0797 ms (5 .. 10 the same; profiles/r05_join_rounds.txt).
 #ifndef VAPOR_BUILD_COST_X8
-#define VAPOR_BUILD_COST_X8 3
+#define VAPOR_BUILD_COST_X8 6
 #endif
 
 
