@@ -1173,7 +1173,9 @@ extern "C" int vapor_plan_create(vapor_ctx* ctx, vapor_seqset* set, int64_t n_pa
         if (rc == VAPOR_OK && !p->tables.empty())
             chk(hipMemcpyAsync(p->d_maps, p->tables.data(), sizeof(int32_t) * p->tables.size(), hipMemcpyHostToDevice, ctx->stream), "copy maps");
     }
-    if (ctx->clean_order && n_pairs > 1) {
+    // (a plan of many rounds of clean workgroups has no tail worth ordering for - cfg3's 62 rounds gain nothing - and sorting
+    // 80 000 pairs costs a pipeline chunk's plan 3-4 ms: the order is made for plans of up to eight rounds)
+    if (ctx->clean_order && n_pairs > 1 && n_pairs <= (int64_t)8 * (2048 / CLEAN_THREADS) * ctx->n_cus) {
         chk(dmalloc(ctx, (void**)&p->d_clean_order, sizeof(int32_t) * (size_t)n_pairs), "hipMalloc clean order");
         if (rc == VAPOR_OK && plan_clean_order(p, nullptr) != VAPOR_OK) rc = VAPOR_E_HIP;
     }
