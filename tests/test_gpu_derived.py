@@ -450,3 +450,31 @@ def test_shared_plot_beyond_max_pair_cap_marks_every_served_pair(eng, oracle):
     ss.close()
     assert tm["shared_joins"] == 1 and st[:, 15].tolist() == [0, 0]
     assert np.array_equal(dots[1], exp_alt.reshape(-1, 2)) and st[0, 0] > 20000
+
+
+def test_a_second_upper_twin_of_a_window_takes_no_member_slot(eng, oracle):
+    """several requests of a batch may each describe the upper-cased twin of one window.  The first is the
+    group's identity; a second one must not take one of the three member slots (it would push a real allele out of the shared
+    join) - its pairs are joined on their own - and every pair's dots stay the oracle's."""
+    rng = np.random.default_rng(31)
+    g = synth.random_dna(rng, 2600)
+    win = g[:900] + g[900:1000].lower() + g[1000:]
+    n, f = len(win), 500
+    der = [([(0, 0, n, False)], True), ([(0, 0, n, False)], True),                                     # two whole upper twins
+           ([(0, 0, f, False), (0, n - f, f, False)], True),                                            # DEL, upper
+           ([(0, 0, f, False), (0, f, n - 2 * f, True), (0, n - f, f, False)], True),                   # INV, upper
+           ([(0, 0, n - f, False), (0, f, n - 2 * f, False), (0, n - f, f, False)], True)]              # TANDUP, upper
+    up = win.upper()
+    texts = [up, up, up[:f] + up[-f:], up[:f] + _rc(up[f:n - f]) + up[-f:], up[:n - f] + up[f:n - f] + up[-f:]]
+    reads = [synth.mutate(rng, t[:1900], 0.01, 0.05, 0.03)[0] for t in texts[1:]]
+    seqs = [win] + reads
+    fd = len(seqs)
+    rows = [(1 + r, fd + d, (0, 9)[r % 2], 10, L.PF_C1) for r in range(len(reads)) for d in range(len(der))]
+    ss = eng.seqset(seqs, derived=der)
+    st, dots, tm = _plots(eng, ss, eng.make_pairs(rows))
+    ss.close()
+    # every read shares one join for the identity twin and the three alleles; the second twin's pairs run joins of their own
+    assert tm["shared_joins"] == len(reads) and tm["pairs_served_by_shared_joins"] == 4 * len(reads), tm
+    for t, (s1, s2, off2, k, _fl) in enumerate(rows):
+        exp = oracle.dotdata_array(k, seqs[s1], texts[s2 - fd][off2:]).reshape(-1, 2)
+        assert st[t, 15] == 0 and np.array_equal(dots[t], exp), (t, len(dots[t]), len(exp))

@@ -436,7 +436,8 @@ static void build_share_groups(vapor_seqset* s, const std::vector<uint8_t>& dfla
         ShareGroup& g = s->groups[(size_t)it->second];
         const bool whole = sg.size() == 1 && sg[0].parent == par && sg[0].off == 0 && sg[0].len == s->h[(size_t)par].len && !sg[0].rc;
         if (whole && g.identity < 0) { g.identity = n_lit + d; continue; }
-        if (whole && g.identity >= 0 && !up) continue;              // (a plain copy of the literal: nothing to share)
+        if (whole && g.identity >= 0) continue;                     // (another copy of the window - plain, or a second upper-cased twin: it
+                                                                    // would only take one of the group's three member slots; its pairs are joined on their own)
         if (g.members.size() < 3) g.members.push_back(n_lit + d);
     }
     for (size_t q = 0; q < s->groups.size(); ++q) {
