@@ -654,3 +654,35 @@ def test_two_plans_in_flight_and_stream_ordering(eng):
         p.close()
     for ss in sets:
         ss.close()
+
+
+def test_join_tasks_in_whole_rounds_when_the_reads_per_task_limit_binds(eng, oracle):
+    """Round 5: when the limit of reads per task asks for more join tasks than `join_tasks` (= CUs), the partition aims for whole
+    rounds of them (BASELINE configs[2]: 625 -> 768 tasks).  The same rule at toy size - 3 "CUs", 5 reads per task, 60 reads of 6
+    windows - gives the statistics of the default partition and the oracle's dots."""
+    from vapor_amd import _lib as L
+    from vapor_amd import synth
+    rng = np.random.default_rng(66)
+    wins = [synth.random_dna(rng, 1800 + 100 * t) for t in range(6)]
+    reads, rows = [], []
+    for wi, wn in enumerate(wins):
+        for t in range(10):
+            a = int(rng.integers(0, 600))
+            reads.append(synth.mutate(rng, wn[a:a + 1100], 0.01, 0.05, 0.03)[0])
+            rows.append((len(wins) + len(reads) - 1, wi, (0, 11)[t % 2], (10, 20)[t % 3 == 0], L.PF_C1 | L.PF_C2 | L.PF_DIR))
+    seqs = wins + reads
+    pairs = eng.make_pairs(rows)
+    ss = eng.seqset(seqs)
+    want = eng.score(ss, pairs)
+    eng.set_param("join_tasks", 3)
+    eng.set_param("reads_per_task", 5)
+    try:
+        st, dots = eng.dotplots(ss, pairs)
+    finally:
+        eng.set_param("join_tasks", 256)
+        eng.set_param("reads_per_task", 64)
+    ss.close()
+    assert np.array_equal(st, want)
+    for t in range(0, len(rows), 7):
+        s1, s2, off2, k, _f = rows[t]
+        assert np.array_equal(dots[t], oracle.dotdata_array(k, seqs[s1], seqs[s2][off2:]).reshape(-1, 2)), t
