@@ -290,6 +290,42 @@ int vapor_bam_chop(vapor_bam* bam, int32_t tid, int64_t start, int64_t end, int6
                    const uint64_t* chunks, uint8_t* seq_out, int64_t seq_cap, char* names_out, int64_t names_cap,
                    int64_t* meta, int32_t max_reads, int32_t* n_reads, int64_t* need);
 /*
+ * The read extraction of MANY regions on the DEVICE (vapor_amd/csrc/vapor_bamdev.h): what vapor_bam_chop does for one region on
+ * host threads - and the reference as a `samtools view` process per locus piped into chop_pacbio_read_by_pos (SF:339-354) and
+ * minimize_pacbio_read_list (SF:1091-1102) - for n_regions regions of the open file `bam` in one call.  Region g =
+ * (tid[g], start[g], end[g], flank[g]); its .bai chunks are pairs chunk_first[g] .. chunk_first[g + 1] of `chunks` ((begin, end)
+ * virtual offsets).  The host reads the chunks' BGZF blocks with positioned reads and sends them compressed; the device
+ * inflates every block (one wavefront a block, CRC-32 checked against the block's trailer), walks the records of every region
+ * (one wavefront a region) and keeps what the reference keeps.  Region g's kept reads - at most max_keep (<= 256), the
+ * smallest miss_bp first, file order inside one value - are entries kept_first[g] .. kept_first[g + 1] of sq_addr (DEVICE
+ * address of the record's packed bases, 4 bits each as BAM stores them), q0 (first base of the read's part) and miss (miss_bp);
+ * the three have room for max_keep entries per region; the read is the end - start - miss_bp bases from q0 on
+ * (vapor_seqset_create_mixed takes it as it lies).  status[g] = 0, or a positive code where the device leaves the region to
+ * the host route (vapor_bam_chop, which also words the errors): a block whose Huffman code needs more table than the kernel
+ * keeps, a damaged block, a record that runs past the chunk's blocks, a malformed record, a record without CIGAR, a read offset
+ * before the record's first base, more than 256 kept reads.  `batch` owns the inflated data the addresses point into: destroy it
+ * (vapor_bam_batch_destroy) after the sequence sets made from them.  One host thread per context, as everywhere.
+ */
+typedef struct vapor_bam_batch vapor_bam_batch;
+int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_regions, const int32_t* tid, const int64_t* start,
+                          const int64_t* end, const int64_t* flank, const int32_t* chunk_first, const uint64_t* chunks,
+                          int32_t max_keep, int32_t* kept_first, uint64_t* sq_addr, int64_t* q0, int64_t* miss, int32_t* status,
+                          vapor_bam_batch** batch);
+int vapor_bam_batch_destroy(vapor_bam_batch* batch);
+/* the descriptor and the inflate-thread count of an open file (vapor_bam_chop_device reads with them) */
+int vapor_bam_fileno(vapor_bam* bam);
+int vapor_bam_threads(vapor_bam* bam);
+/*
+ * vapor_seqset_create_derived for a set some of whose sequences are on the device already: src_kind[i] = 1 says seq[i] is the
+ * DEVICE address of BAM-packed bases (4 bits a base, "=ACMGRSVTWYHKDBN", the first base of a byte in its high half) inside the
+ * data of a live vapor_bam_batch of this context, and the sequence is the len[i] bases from base src_first[i] on; src_kind[i] = 0
+ * (or src_kind == NULL): bytes on the host, as vapor_seqset_create_derived takes them.  Only the host bytes cross the link.
+ * VAPOR_E_ARG for a device source that does not lie inside a live batch.
+ */
+int vapor_seqset_create_mixed(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len, const uint8_t* flags,
+                              const uint8_t* src_kind, const int64_t* src_first, int32_t n_derived, const int32_t* seg_first,
+                              const vapor_segment* segs, const uint8_t* derived_flags, int32_t* seq_info, vapor_seqset** set);
+/*
  * chop_pacbio_read_by_pos (SF:339-354) over n alignment records the caller holds in memory (no file, no device):
  * pos 1-based leftmost aligned base, ref_span the reference bases a record is taken to cover (the region rule of
  * `samtools view`), cigar[r] the record's CIGAR as text (a C string, walked only as far as the window start), seq_len the

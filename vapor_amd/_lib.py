@@ -46,6 +46,7 @@ EXPORTS = [
     "vapor_cigar2alignstart", "vapor_cigar2alignstart_ops",
     "vapor_bam_open", "vapor_bam_close", "vapor_bam_set_threads", "vapor_bam_last_error", "vapor_bam_chop",
     "vapor_inflate_raw", "vapor_chop_records", "vapor_chop_records_many", "vapor_row_tails", "vapor_crc32",
+    "vapor_bam_chop_device", "vapor_bam_batch_destroy", "vapor_bam_fileno", "vapor_bam_threads", "vapor_seqset_create_mixed",
 ]
 
 _lib = None
@@ -171,6 +172,11 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.vapor_bam_last_error.restype = ctypes.c_char_p
     L.vapor_bam_chop.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp,
                                  vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), vp]
+    L.vapor_bam_chop_device.argtypes = [vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
+    L.vapor_bam_batch_destroy.argtypes = [vp]
+    L.vapor_bam_fileno.argtypes = [vp]
+    L.vapor_bam_threads.argtypes = [vp]
+    L.vapor_seqset_create_mixed.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, ctypes.POINTER(vp)]
     L.vapor_inflate_raw.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64]
     L.vapor_crc32.argtypes = [vp, ctypes.c_int64, ctypes.c_int32]
     L.vapor_crc32.restype = ctypes.c_uint32

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libvapor_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "vapor_hip.hip"), os.path.join(HERE, "csrc", "vapor_bam.cpp")]
 DEPS = SOURCES + [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(HERE, "csrc", "vapor_inflate.h"),
+                  os.path.join(HERE, "csrc", "vapor_bamdev.h"),
                   os.path.join(ROOT, "include", "vapor_hip.h")]
 
 
@@ -27,7 +28,8 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-KERNEL_FILES = [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(HERE, "csrc", "vapor_hip.hip"), os.path.abspath(__file__)]
+KERNEL_FILES = [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(HERE, "csrc", "vapor_bamdev.h"), os.path.join(HERE, "csrc", "vapor_hip.hip"),
+                os.path.abspath(__file__)]
 _ID_RE = re.compile(rb"VAPOR_SOURCE_ID=([0-9a-f]{16}:[0-9a-f]{16})")
 
 

@@ -68,6 +68,11 @@ extern "C" int vapor_bam_close(vapor_bam* b)
     return VAPOR_OK;
 }
 
+// the descriptor and inflate-thread count of an open file, for vapor_bam_chop_device (vapor_hip.hip: it reads the file's blocks with
+// positioned reads of its own and leaves the handle's buffers alone)
+extern "C" int vapor_bam_fileno(vapor_bam* b) { return b ? b->fd : -1; }
+extern "C" int vapor_bam_threads(vapor_bam* b) { return b ? b->n_threads : 1; }
+
 extern "C" int vapor_bam_set_threads(vapor_bam* b, int32_t n)
 {
     if (!b || n < 1 || n > 64) return bfail(VAPOR_E_ARG, "vapor_bam_set_threads: out of range");

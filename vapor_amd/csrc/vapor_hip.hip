@@ -6,7 +6,10 @@
 // Everything the GPU touches is resident in HBM between calls: a vapor_seqset holds the packed
 // bit planes, a vapor_plan holds pair/task descriptors, the hit workspace and the statistics.
 #include "vapor_kernels.h"
+#include "vapor_bamdev.h"
 #include "vapor_hip.h"
+
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -102,6 +105,10 @@ struct vapor_ctx {
     int stage_threads = 3;                     // host threads that copy a large upload into the pinned staging buffer (measured:
                                                // two to four are as fast as it gets, more are slower - tools/upload_sweep.py)
     bool attrs_set = false;
+    // vapor_bam_chop_device: the CRC combination constants on the device, and the arenas of the batches that are alive
+    // (vapor_seqset_create_mixed takes packed bases by device address: only addresses inside one of these are followed)
+    uint32_t* d_crc_pow = nullptr;
+    std::map<const uint8_t*, size_t> arenas;
     BlockPool pool;
 };
 
@@ -343,6 +350,7 @@ extern "C" int vapor_destroy(vapor_ctx* c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_gt) (void)hipFree(c->d_gt);
+    if (c->d_crc_pow) (void)hipFree(c->d_crc_pow);
     delete c;
     return VAPOR_OK;
 }
@@ -487,7 +495,8 @@ static void build_share_groups(vapor_seqset* s, const std::vector<uint8_t>& dfla
 template <typename SRC>
 static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int32_t* len, const uint8_t* flags,
                               int32_t* seq_info, vapor_seqset** out, int32_t n_derived = 0, const int32_t* seg_first = nullptr,
-                              const vapor_segment* segs = nullptr, const uint8_t* derived_flags = nullptr)
+                              const vapor_segment* segs = nullptr, const uint8_t* derived_flags = nullptr,
+                              const uint8_t* src_kind = nullptr, const int64_t* src_first = nullptr)
 {
     HIPCHK(hipSetDevice(ctx->device));
     const bool dbg_t = getenv("VAPOR_DEBUG_UPLOAD") != nullptr;
@@ -585,7 +594,12 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         size_t n_seg = 0;
         for (auto& v : s->derived) n_seg += v.size();
         for (auto& v : hidden) n_seg += v.size();
-        const size_t der_off = (n_asc * 36 + 63) & ~(size_t)63;
+        // (a mixed set - vapor_seqset_create_mixed - has sequences whose bases are on the device already, 4 bits each: their
+        // addresses and first bases travel instead of their bytes, bam_expand_kernel writes their part of the ASCII layout)
+        const bool mixed = src_kind != nullptr;
+        const size_t mix_off = (n_asc * 36 + 7) & ~(size_t)7;
+        const size_t mix_bytes = mixed ? (size_t)n_seqs * 12 : 0;
+        const size_t der_off = (mix_off + mix_bytes + 63) & ~(size_t)63;
         const size_t der_bytes = der_chunks ? sizeof(DSeg) * std::max<size_t>(n_seg, 1) + sizeof(int32_t) * (n_dseq + 1) + sizeof(uint32_t) * der_chunks : 0;
         const size_t need = std::max<size_t>(der_off + der_bytes, 64);
         if (need > ctx->stage_cap) {
@@ -608,12 +622,21 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
             for (int32_t i = i0; i < i1; ++i) {
                 const SeqDesc& d = s->h[i];
                 size_t ch = ((size_t)d.len + 31) / 32;
+                for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
+                if (mixed && src_kind[i]) continue;
                 uint8_t* dst = h_asc + (size_t)d.asc0 * 32;
                 if (d.len) memcpy(dst, src(i), (size_t)d.len);
                 memset(dst + d.len, 0, ch * 32 - (size_t)d.len);
-                for (size_t c = 0; c < ch; ++c) h_map[d.asc0 + c] = (uint32_t)i;
             }
         };
+        // the chunks the host has bytes for end here (the reads of a chunk of loci lie behind its windows: the usual mixed set
+        // sends the windows alone over the link)
+        size_t host_end = n_asc;
+        if (mixed) {
+            host_end = 0;
+            for (int32_t i = 0; i < n_seqs; ++i)
+                if (!src_kind[i] && s->h[i].len > 0) host_end = std::max(host_end, (size_t)s->h[i].asc0 + ((size_t)s->h[i].len + 31) / 32);
+        }
         SS_CHK(dmalloc(ctx, (void**)&s->d_seqs, sizeof(SeqDesc) * s->h.size()));
         SS_CHK(dmalloc(ctx, (void**)&s->d_p2, pl * 2 * sizeof(uint32_t)));
         SS_CHK(dmalloc(ctx, (void**)&s->d_e1, pl * sizeof(uint32_t)));
@@ -623,8 +646,26 @@ static int seqset_create_impl(vapor_ctx* ctx, int32_t n_seqs, SRC src, const int
         SS_CHK(hipMemsetAsync(s->d_x4, 0, pl * 4 * sizeof(uint32_t), ctx->stream));
         SS_CHK(hipMemcpyAsync(s->d_seqs, s->h.data(), sizeof(SeqDesc) * s->h.size(), hipMemcpyHostToDevice, ctx->stream));
         tq[2] = now();
-        const int n_thr = (n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? ctx->stage_threads : 1;
-        if (n_thr == 1) {
+        const int n_thr = (!mixed && n_asc * 32 >= ((size_t)4 << 20) && n_seqs >= 8) ? ctx->stage_threads : 1;
+        if (mixed) {
+            stage_range(0, n_seqs);
+            unsigned long long* h_src = reinterpret_cast<unsigned long long*>(ctx->h_stage + mix_off);
+            int32_t* h_first = reinterpret_cast<int32_t*>(ctx->h_stage + mix_off + (size_t)n_seqs * 8);
+            for (int32_t i = 0; i < n_seqs; ++i) {
+                h_src[i] = src_kind[i] ? (unsigned long long)reinterpret_cast<uintptr_t>(src(i)) : 0ull;
+                h_first[i] = src_kind[i] ? (int32_t)src_first[i] : 0;
+            }
+            if (host_end) SS_CHK(hipMemcpyAsync(d_asc, h_asc, host_end * 32, hipMemcpyHostToDevice, ctx->stream));
+            if (n_asc) SS_CHK(hipMemcpyAsync(d_map, h_map, n_asc * 4, hipMemcpyHostToDevice, ctx->stream));
+            SS_CHK(hipMemcpyAsync(ctx->d_stage + mix_off, ctx->h_stage + mix_off, mix_bytes, hipMemcpyHostToDevice, ctx->stream));
+            if (n_asc) {
+                hipLaunchKernelGGL(vapor_bamdev::bam_expand_kernel, dim3((unsigned)((n_asc + 255) / 256)), dim3(256), 0, ctx->stream, d_asc, d_map,
+                                   (uint32_t)n_asc, reinterpret_cast<const uint32_t*>(s->d_seqs),
+                                   reinterpret_cast<const unsigned long long*>(ctx->d_stage + mix_off),
+                                   reinterpret_cast<const int32_t*>(ctx->d_stage + mix_off + (size_t)n_seqs * 8));
+                SS_CHK(hipGetLastError());
+            }
+        } else if (n_thr == 1) {
             stage_range(0, n_seqs);
             if (n_asc) SS_CHK(hipMemcpyAsync(d_asc, h_asc, n_asc * 36, hipMemcpyHostToDevice, ctx->stream));
         } else {
@@ -761,6 +802,395 @@ extern "C" int vapor_seqset_planes(vapor_seqset* s, int32_t seq, uint32_t* p2, u
     if (e1) HIPCHK(hipMemcpy(e1, s->d_e1 + (size_t)d.chunk0, ch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (x4) HIPCHK(hipMemcpy(x4, s->d_x4 + (size_t)d.chunk0 * 4, ch * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VAPOR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Read extraction on the device (vapor_bamdev.h): the host side reads the regions' BGZF blocks as they lie in the file, lays
+// out where every block's data goes, sends the compressed bytes and runs the kernels.
+// ------------------------------------------------------------------------------------------
+extern "C" int vapor_bam_fileno(vapor_bam* b);
+extern "C" int vapor_bam_threads(vapor_bam* b);
+
+struct vapor_bam_batch {
+    vapor_ctx* ctx = nullptr;
+    int device = 0;
+    uint8_t* d_arena = nullptr;
+    size_t arena_bytes = 0;
+};
+
+extern "C" int vapor_bam_batch_destroy(vapor_bam_batch* b)
+{
+    if (!b) return VAPOR_OK;
+    if (b->d_arena) {
+        (void)hipSetDevice(b->device);
+        if (b->ctx && ctx_alive(b->ctx)) {
+            // (kernels that read the arena - bam_expand_kernel of a set made from it - are on the context's stream)
+            (void)hipStreamSynchronize(b->ctx->stream);
+            b->ctx->arenas.erase(b->d_arena);
+        }
+        dfree(b->ctx, b->d_arena);
+    }
+    delete b;
+    return VAPOR_OK;
+}
+
+namespace {
+struct HostSpan {                  // one index chunk of a region on the host side
+    int32_t region;
+    uint64_t cs, ce;
+    int64_t file_off;              // compressed range read from the file
+    size_t want, got;
+    size_t stage_off;              // ... into the pinned staging buffer here
+    std::vector<vapor_bamdev::BgzfBlk> blks;   // c_off relative to the staging buffer, u_off relative to the span's data
+    uint32_t u_begin = 0, u_end = 0, u_total = 0;
+    bool bad = false;              // not BGZF, or a begin offset outside its block: the host route words the error
+};
+
+// the whole blocks of a span, through the block that holds the chunk's end
+void scan_span(HostSpan& sp, const uint8_t* stage)
+{
+    const uint8_t* base = stage + sp.stage_off;
+    const int64_t end_coff = (int64_t)(sp.ce >> 16);
+    const uint32_t end_uoff = (uint32_t)(sp.ce & 0xFFFFu);
+    size_t p = 0;
+    uint32_t u = 0;
+    bool have_end = false;
+    sp.u_end = 0;
+    while (p + 18 <= sp.got) {
+        const int64_t coff = sp.file_off + (int64_t)p;
+        if (coff > end_coff || (coff == end_coff && end_uoff == 0)) break;
+        const uint8_t* h = base + p;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { sp.bad = true; return; }
+        const int xlen = h[10] | (h[11] << 8);
+        if (p + 12 + (size_t)xlen > sp.got) break;
+        int bsize = -1;
+        for (int q = 0; q + 4 <= xlen;) {
+            const uint8_t* e = h + 12 + q;
+            const int slen = e[2] | (e[3] << 8);
+            if (e[0] == 66 && e[1] == 67 && slen == 2) bsize = (e[4] | (e[5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 0 || bsize < xlen + 20) { sp.bad = true; return; }
+        if (p + (size_t)bsize > sp.got) break;
+        const uint8_t* t = h + bsize - 8;
+        const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (isize > 65536u) { sp.bad = true; return; }
+        if (coff == end_coff) { have_end = true; sp.u_end = u + std::min(end_uoff, isize); }
+        if (isize == 0) {
+            if (crc != 0) { sp.bad = true; return; }        // (the CRC-32 of no bytes)
+        } else {
+            vapor_bamdev::BgzfBlk k;
+            k.c_off = (uint32_t)(sp.stage_off + p + 12 + (size_t)xlen);
+            k.c_len = (uint32_t)(bsize - xlen - 20);
+            k.u_off = u;
+            k.u_len = isize;
+            k.crc = crc;
+            k.pad = 0;
+            sp.blks.push_back(k);
+        }
+        u += isize;
+        p += (size_t)bsize;
+    }
+    sp.u_total = u;
+    if (!have_end) sp.u_end = u;                            // the chunk ends on a block boundary (or the file ends inside it)
+    const uint32_t b0 = (uint32_t)(sp.cs & 0xFFFFu);
+    // the first record's offset must lie inside the first block
+    uint32_t first_usize = 0;
+    {
+        // (the first block in the file order, empty ones included, is the one `cs` names)
+        const uint8_t* h = base;
+        if (sp.got >= 18) {
+            const int xlen = h[10] | (h[11] << 8);
+            int bsize = -1;
+            if (12 + (size_t)xlen <= sp.got)
+                for (int q = 0; q + 4 <= xlen;) {
+                    const uint8_t* e = h + 12 + q;
+                    const int slen = e[2] | (e[3] << 8);
+                    if (e[0] == 66 && e[1] == 67 && slen == 2) bsize = (e[4] | (e[5] << 8)) + 1;
+                    q += 4 + slen;
+                }
+            if (bsize >= xlen + 20 && (size_t)bsize <= sp.got) {
+                const uint8_t* t = h + bsize - 4;
+                first_usize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            }
+        }
+    }
+    if (b0 > first_usize) { sp.bad = true; return; }
+    sp.u_begin = b0;
+}
+}   // namespace
+
+extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_regions, const int32_t* tid, const int64_t* start,
+                                     const int64_t* end, const int64_t* flank, const int32_t* chunk_first, const uint64_t* chunks,
+                                     int32_t max_keep, int32_t* kept_first, uint64_t* sq_addr, int64_t* q0, int64_t* miss,
+                                     int32_t* status, vapor_bam_batch** out)
+{
+    using namespace vapor_bamdev;
+    if (!ctx || !bam || !out || n_regions < 0 || max_keep < 1 || max_keep > KEPT_CAP ||
+        (n_regions && (!tid || !start || !end || !flank || !chunk_first || !kept_first || !sq_addr || !q0 || !miss || !status)))
+        return fail(VAPOR_E_ARG, "vapor_bam_chop_device: bad argument");
+    const int fd = vapor_bam_fileno(bam);
+    if (fd < 0) return fail(VAPOR_E_ARG, "vapor_bam_chop_device: the file is not open");
+    HIPCHK(hipSetDevice(ctx->device));
+    *out = nullptr;
+    const bool dbg_t = getenv("VAPOR_DEBUG_BAMDEV") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq[8] = {now(), 0, 0, 0, 0, 0, 0, 0};
+    try {
+        // ---- what to read ---------------------------------------------------------------------------------------------------
+        std::vector<HostSpan> spans;
+        std::vector<int32_t> span_first((size_t)n_regions + 1, 0);
+        size_t stage_bytes = 0;
+        for (int32_t g = 0; g < n_regions; ++g) {
+            span_first[(size_t)g] = (int32_t)spans.size();
+            status[g] = 0;
+            const int32_t c0 = chunk_first[g], c1 = chunk_first[g + 1];
+            // (positions are 32-bit in a BAM file; a region that is not is the host route's to refuse)
+            bool ok = c1 >= c0 && (c0 == c1 || chunks) && start[g] >= 0 && end[g] >= start[g] && end[g] < ((int64_t)1 << 31) && flank[g] >= 0 && tid[g] >= 0;
+            for (int32_t c = c0; ok && c < c1; ++c) {
+                const uint64_t cs = chunks[2 * (size_t)c], ce = chunks[2 * (size_t)c + 1];
+                if (ce < cs || (ce >> 16) - (cs >> 16) > ((uint64_t)1 << 27)) { ok = false; break; }
+                HostSpan sp;
+                sp.region = g; sp.cs = cs; sp.ce = ce;
+                sp.file_off = (int64_t)(cs >> 16);
+                sp.want = (size_t)((int64_t)(ce >> 16) - sp.file_off) + ((ce & 0xFFFFu) ? ((size_t)1 << 16) + 64 : 0);
+                sp.got = 0;
+                sp.stage_off = stage_bytes;
+                stage_bytes += (sp.want + 63) & ~(size_t)63;
+                spans.push_back(std::move(sp));
+            }
+            if (!ok) {
+                status[g] = REG_MALFORMED;
+                while (!spans.empty() && spans.back().region == g) { stage_bytes = spans.back().stage_off; spans.pop_back(); }
+            }
+        }
+        span_first[(size_t)n_regions] = (int32_t)spans.size();
+        if (stage_bytes > ((size_t)3 << 29)) return fail(VAPOR_E_ARG, "vapor_bam_chop_device: more than 1.5 GB of blocks in one call (use smaller batches)");
+        vapor_bam_batch* B = new vapor_bam_batch();
+        B->ctx = ctx;
+        B->device = ctx->device;
+        uint8_t* h_comp = nullptr;
+        uint8_t *d_comp = nullptr, *h_meta = nullptr, *d_meta = nullptr;
+        int rc = VAPOR_OK;
+        auto cleanup = [&](int code) {
+            if (h_comp) hfree(ctx, h_comp);
+            if (d_comp) dfree(ctx, d_comp);
+            if (h_meta) hfree(ctx, h_meta);
+            if (d_meta) dfree(ctx, d_meta);
+            if (code != VAPOR_OK) { vapor_bam_batch_destroy(B); B = nullptr; }
+            return code;
+        };
+#define BD_CHK(expr)                                                                                                  \
+    do {                                                                                                              \
+        hipError_t _e = (expr);                                                                                       \
+        if (_e != hipSuccess) return cleanup(fail(VAPOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)));   \
+    } while (0)
+        BD_CHK(hmalloc(ctx, (void**)&h_comp, std::max<size_t>(stage_bytes, 64)));
+        // ---- read and scan, a few threads -------------------------------------------------------------------------------------
+        {
+            const int n_thr = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(vapor_bam_threads(bam), 1) * 2, spans.size() / 8 + 1));
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (;;) {
+                    const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                    if (i >= spans.size()) break;
+                    HostSpan& sp = spans[i];
+                    size_t got = 0;
+                    while (got < sp.want) {
+                        const ssize_t r = pread(fd, h_comp + sp.stage_off + got, sp.want - got, (off_t)(sp.file_off + (int64_t)got));
+                        if (r <= 0) break;
+                        got += (size_t)r;
+                    }
+                    sp.got = got;
+                    scan_span(sp, h_comp);
+                }
+            };
+            if (n_thr <= 1) {
+                work();
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < n_thr; ++t) th.emplace_back(work);
+                work();
+                for (auto& x : th) x.join();
+            }
+        }
+        tq[1] = now();
+        // ---- layout of the arena and the tables -------------------------------------------------------------------------------
+        for (const HostSpan& sp : spans)
+            if (sp.bad) status[sp.region] = REG_MALFORMED;
+        std::vector<BgzfBlk> blks;
+        std::vector<BamSpan> dspans;
+        std::vector<BamRegion> regs((size_t)std::max(n_regions, 1));
+        size_t arena = 0;
+        uint32_t max_usize = 0;
+        for (int32_t g = 0; g < n_regions; ++g) {
+            BamRegion& R = regs[(size_t)g];
+            R.start = start[g]; R.end = end[g]; R.flank = flank[g]; R.tid = tid[g]; R.pad = 0;
+            R.span_first = (int32_t)dspans.size();
+            R.span_n = 0;
+            if (status[g]) continue;
+            for (int32_t si = span_first[(size_t)g]; si < span_first[(size_t)g + 1]; ++si) {
+                const HostSpan& sp = spans[(size_t)si];
+                if (arena + sp.u_total + 64 > ((size_t)1 << 31)) return cleanup(fail(VAPOR_E_ARG, "vapor_bam_chop_device: more than 2 GB of block data in one call (use smaller batches)"));
+                BamSpan d;
+                d.u_begin = (uint32_t)arena + sp.u_begin;
+                d.u_end = (uint32_t)arena + sp.u_end;
+                d.u_limit = (uint32_t)arena + sp.u_total;
+                d.blk_first = (uint32_t)blks.size();
+                d.blk_n = (uint32_t)sp.blks.size();
+                d.pad = 0;
+                for (BgzfBlk k : sp.blks) {
+                    k.u_off += (uint32_t)arena;
+                    max_usize = std::max(max_usize, k.u_len);
+                    blks.push_back(k);
+                }
+                dspans.push_back(d);
+                ++R.span_n;
+                arena += ((size_t)sp.u_total + 63) & ~(size_t)63;
+            }
+        }
+        const size_t n_blks = blks.size();
+        // metadata in one block: blocks, spans, regions in; block status, kept counts, region status, kept reads out
+        const size_t o_blk = 0, o_span = o_blk + ((sizeof(BgzfBlk) * std::max<size_t>(n_blks, 1) + 63) & ~(size_t)63);
+        const size_t o_reg = o_span + ((sizeof(BamSpan) * std::max<size_t>(dspans.size(), 1) + 63) & ~(size_t)63);
+        const size_t in_bytes = o_reg + ((sizeof(BamRegion) * regs.size() + 63) & ~(size_t)63);
+        const size_t o_bst = in_bytes, o_nk = o_bst + ((4 * std::max<size_t>(n_blks, 1) + 63) & ~(size_t)63);
+        const size_t o_rst = o_nk + ((4 * regs.size() + 63) & ~(size_t)63), o_kept = o_rst + ((4 * regs.size() + 63) & ~(size_t)63);
+        const size_t meta_bytes = o_kept + sizeof(BamKept) * KEPT_CAP * regs.size();
+        BD_CHK(hmalloc(ctx, (void**)&h_meta, meta_bytes));
+        BD_CHK(dmalloc(ctx, (void**)&d_meta, meta_bytes));
+        BD_CHK(dmalloc(ctx, (void**)&d_comp, std::max<size_t>(stage_bytes, 64)));
+        BD_CHK(dmalloc(ctx, (void**)&B->d_arena, arena + 64));
+        B->arena_bytes = arena + 64;
+        ctx->arenas[B->d_arena] = B->arena_bytes;
+        if (n_blks) memcpy(h_meta + o_blk, blks.data(), sizeof(BgzfBlk) * n_blks);
+        if (!dspans.empty()) memcpy(h_meta + o_span, dspans.data(), sizeof(BamSpan) * dspans.size());
+        memcpy(h_meta + o_reg, regs.data(), sizeof(BamRegion) * regs.size());
+        if (!ctx->d_crc_pow) {
+            // x^(8 * 1024 * (63 - l)) mod P, l = 0 .. 63 (bit 31 = x^0): what lane l's slice CRC is multiplied by
+            uint32_t pw[64];
+            auto mul = [](uint32_t a, uint32_t b) {
+                uint32_t m = 1u << 31, p = 0;
+                for (int i = 0; i < 32; ++i) { if (a & m) p ^= b; m >>= 1; b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+                return p;
+            };
+            for (int l = 0; l < 64; ++l) {
+                uint64_t e = (uint64_t)8 * 1024 * (uint64_t)(63 - l);
+                uint32_t r = 0x80000000u, b = 0x40000000u;
+                while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; }
+                pw[l] = r;
+            }
+            BD_CHK(hipMalloc((void**)&ctx->d_crc_pow, sizeof pw));
+            BD_CHK(hipMemcpy(ctx->d_crc_pow, pw, sizeof pw, hipMemcpyHostToDevice));
+        }
+        hipStream_t st = ctx->stream;
+        tq[2] = now();
+        if (stage_bytes) BD_CHK(hipMemcpyAsync(d_comp, h_comp, stage_bytes, hipMemcpyHostToDevice, st));
+        if (dbg_t) { BD_CHK(hipStreamSynchronize(st)); tq[3] = now(); }
+        BD_CHK(hipMemcpyAsync(d_meta, h_meta, in_bytes, hipMemcpyHostToDevice, st));
+        if (n_blks) {
+            hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n_blks + INFLATE_WAVES - 1) / INFLATE_WAVES)), dim3(64 * INFLATE_WAVES), 0, st, d_comp, reinterpret_cast<const BgzfBlk*>(d_meta + o_blk),
+                               (int)n_blks, B->d_arena, ctx->d_crc_pow, reinterpret_cast<int32_t*>(d_meta + o_bst));
+            BD_CHK(hipGetLastError());
+        }
+        if (dbg_t) { BD_CHK(hipStreamSynchronize(st)); tq[4] = now(); }
+        if (n_regions) {
+            hipLaunchKernelGGL(bam_chop_kernel, dim3((unsigned)n_regions), dim3(64), 0, st, B->d_arena, reinterpret_cast<const BamRegion*>(d_meta + o_reg),
+                               reinterpret_cast<const BamSpan*>(d_meta + o_span), reinterpret_cast<const int32_t*>(d_meta + o_bst), (int)n_regions,
+                               reinterpret_cast<BamKept*>(d_meta + o_kept), reinterpret_cast<int32_t*>(d_meta + o_nk), reinterpret_cast<int32_t*>(d_meta + o_rst));
+            BD_CHK(hipGetLastError());
+        }
+        // (counts and statuses first; the kept reads of a region are read where its count says)
+        BD_CHK(hipMemcpyAsync(h_meta + o_bst, d_meta + o_bst, meta_bytes - o_bst, hipMemcpyDeviceToHost, st));
+        BD_CHK(hipStreamSynchronize(st));
+        tq[5] = now();
+        if (dbg_t)
+            fprintf(stderr, "bam_chop_device: %d regions, %zu blocks, %.1f MB compressed -> %.1f MB; read+scan %.2f  layout+alloc %.2f  h2d %.2f  inflate %.2f  chop+d2h %.2f ms\n",
+                    n_regions, n_blks, stage_bytes / 1e6, arena / 1e6, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
+#ifdef VBD_TIMING
+        if (dbg_t && n_blks) {
+            std::vector<uint8_t> back(stage_bytes);
+            BD_CHK(hipMemcpy(back.data(), d_comp, stage_bytes, hipMemcpyDeviceToHost));
+            double sum[13] = {0};
+            size_t cnt = 0;
+            for (const BgzfBlk& k : blks) {
+                if (k.c_len < 128) continue;
+                const long long* d = reinterpret_cast<const long long*>(back.data() + ((k.c_off + 7u) & ~7u));
+                for (int t = 0; t < 13; ++t) sum[t] += (double)d[t];
+                ++cnt;
+            }
+            fprintf(stderr, "  per block (shader clocks, mean of %zu): top-up %.0f  decode %.0f (tables %.0f)  matches %.0f  crc %.0f  all %.0f\n"
+                            "  counts: fast literal steps %.0f, fast general symbols %.0f, careful symbols %.0f, matches %.0f (fills %.0f), batches %.0f; clocks in the fast loop's general symbols %.0f\n", cnt,
+                    sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[10] / cnt, sum[7] / cnt, sum[8] / cnt,
+                    sum[11] / cnt, sum[9] / cnt, sum[12] / cnt);
+        }
+#endif
+        // ---- minimize_pacbio_read_list (SF:1091-1102): at most max_keep, the smallest miss_bp first, file order inside one value
+        const int32_t* nk = reinterpret_cast<const int32_t*>(h_meta + o_nk);
+        const int32_t* rst = reinterpret_cast<const int32_t*>(h_meta + o_rst);
+        const BamKept* kept = reinterpret_cast<const BamKept*>(h_meta + o_kept);
+        int32_t w = 0;
+        std::vector<int32_t> order;
+        for (int32_t g = 0; g < n_regions; ++g) {
+            kept_first[g] = w;
+            if (status[g]) continue;
+            if (rst[g] != REG_OK) { status[g] = rst[g]; continue; }
+            const int32_t n = nk[g];
+            const BamKept* k = kept + (size_t)g * KEPT_CAP;
+            order.resize((size_t)n);
+            for (int32_t i = 0; i < n; ++i) order[(size_t)i] = i;
+            if (n > max_keep) {
+                std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return k[a].miss < k[b].miss; });
+                order.resize((size_t)max_keep);
+            }
+            for (int32_t i : order) {
+                sq_addr[w] = (uint64_t)reinterpret_cast<uintptr_t>(B->d_arena + k[i].sq_off);
+                q0[w] = k[i].q0;
+                miss[w] = k[i].miss;
+                ++w;
+            }
+        }
+        kept_first[n_regions] = w;
+        rc = cleanup(VAPOR_OK);
+        *out = B;
+        return rc;
+#undef BD_CHK
+    } catch (const std::bad_alloc&) {
+        return fail(VAPOR_E_NOMEM, "vapor_bam_chop_device: out of memory");
+    }
+}
+
+// vapor_seqset_create_derived with sequences whose bases are on the device already (vapor_bam_chop_device's reads): src_kind[i] = 1
+// says seq[i] is the DEVICE address of BAM-packed bases (4 bits each, high nibble first) inside the arena of a live batch of this
+// context and src_first[i] the first base; len[i] bases from there are the sequence.  0: bytes on the host, as ever.
+extern "C" int vapor_seqset_create_mixed(vapor_ctx* ctx, int32_t n_seqs, const uint8_t* const* seq, const int32_t* len,
+                                         const uint8_t* flags, const uint8_t* src_kind, const int64_t* src_first,
+                                         int32_t n_derived, const int32_t* seg_first, const vapor_segment* segs,
+                                         const uint8_t* derived_flags, int32_t* seq_info, vapor_seqset** out)
+{
+    if (!ctx || !out || n_seqs < 0 || n_derived < 0 || (n_seqs && (!seq || !len)) || (n_derived && (!seg_first || !segs)))
+        return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: null argument");
+    if ((int64_t)n_seqs + n_derived > 0x7FFFFFF0LL) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: too many sequences");
+    bool any_dev = false;
+    for (int32_t i = 0; i < n_seqs; ++i) {
+        if (len[i] < 0) return fail(VAPOR_E_ARG, "negative sequence length");
+        if (len[i] > 0 && !seq[i]) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: null sequence");
+        if (!src_kind || !src_kind[i]) continue;
+        if (src_kind[i] != 1 || !src_first || src_first[i] < 0 || src_first[i] > 0x7FFFFFF0LL)
+            return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: bad source description");
+        any_dev = true;
+        if (len[i] == 0) continue;
+        // the bytes that will be read must lie inside the arena of a batch that is alive
+        const uint8_t* a = seq[i] + (src_first[i] >> 1);
+        const uint8_t* b = seq[i] + ((src_first[i] + len[i] - 1) >> 1);
+        auto it = ctx->arenas.upper_bound(a);
+        if (it == ctx->arenas.begin()) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: a device source outside every live batch");
+        --it;
+        if (b >= it->first + it->second) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: a device source outside every live batch");
+    }
+    return seqset_create_impl(ctx, n_seqs, [&](int32_t i) { return seq[i]; }, len, flags, seq_info, out, n_derived, seg_first, segs,
+                              derived_flags, any_dev ? src_kind : nullptr, src_first);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -122,10 +122,13 @@ class SeqSet:
         self.n_invalid = info[1::2][:self.n].copy()
 
     @classmethod
-    def from_addresses(cls, engine: "Engine", addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None) -> "SeqSet":
+    def from_addresses(cls, engine: "Engine", addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None,
+                       src_kind=None, src_first=None) -> "SeqSet":
         """A set whose byte sequences are given as (address, length) pairs - slices of strings and buffers the caller keeps
         alive (`keepalive`) until this returns: a read is a slice of its record's sequence, a window a slice of its contig;
-        nothing is copied on the Python side.  `derived` as (seg_first, segs, flags) arrays."""
+        nothing is copied on the Python side.  `derived` as (seg_first, segs, flags) arrays.  `src_kind` (uint8 per sequence;
+        vapor_seqset_create_mixed): 1 where `addr` is the DEVICE address of BAM-packed bases inside a live BamBatch and the
+        sequence the `lens` bases from base `src_first` on (Engine.bam_chop_device's reads); those never cross the link."""
         self = cls.__new__(cls)
         self.engine = engine
         self.n_lit = self.n = int(len(addr))
@@ -140,7 +143,25 @@ class SeqSet:
             nd = len(seg_first) - 1
         info = np.zeros(2 * max(self.n + nd, 1), dtype=np.int32)
         lens_p = L.ptr(self.lens if self.n else np.zeros(1, np.int32), ctypes.c_int32)
-        if nd:
+        if src_kind is not None:
+            kind = np.ascontiguousarray(src_kind, dtype=np.uint8)
+            first = np.ascontiguousarray(src_first, dtype=np.int64)
+            if len(kind) != self.n or len(first) != self.n:
+                raise ValueError("src_kind / src_first: one entry per sequence")
+            if nd:
+                seg_first = np.ascontiguousarray(seg_first, dtype=np.int32)
+                segs = np.ascontiguousarray(segs, dtype=L.SEG_DTYPE)
+                dfl = np.ascontiguousarray(dflags, dtype=np.uint8)
+            L.check(lib.vapor_seqset_create_mixed(engine._ctx, self.n, ptrs, lens_p, None, L.ptr(kind, ctypes.c_uint8), first.ctypes.data_as(ctypes.c_void_p),
+                                                  nd, L.ptr(seg_first, ctypes.c_int32) if nd else None,
+                                                  segs.ctypes.data_as(ctypes.c_void_p) if nd else None,
+                                                  L.ptr(dfl, ctypes.c_uint8) if nd else None, L.ptr(info, ctypes.c_int32), ctypes.byref(h)))
+            if nd:
+                dl = np.zeros(nd, dtype=np.int32)
+                np.add.at(dl, np.repeat(np.arange(nd), np.diff(seg_first)), segs["len"][:int(seg_first[-1])])
+                self.lens = np.concatenate([self.lens, dl])
+                self.n += nd
+        elif nd:
             seg_first = np.ascontiguousarray(seg_first, dtype=np.int32)
             segs = np.ascontiguousarray(segs, dtype=L.SEG_DTYPE)
             L.check(lib.vapor_seqset_create_derived(engine._ctx, self.n, ptrs, lens_p, None, nd, L.ptr(seg_first, ctypes.c_int32),
@@ -176,6 +197,24 @@ class SeqSet:
         try:
             self.close()
         except Exception:
+            pass
+
+
+class BamBatch:
+    """The inflated blocks of one vapor_bam_chop_device call on the device (the reads' packed bases lie in them)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def close(self) -> None:
+        if self._h:
+            L.load().vapor_bam_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
             pass
 
 
@@ -299,9 +338,37 @@ class Engine:
     def seqset(self, seqs: Sequence, upper: Optional[Sequence[bool]] = None, derived=None) -> SeqSet:
         return SeqSet(self, seqs, upper, derived)
 
-    def seqset_raw(self, addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None) -> SeqSet:
+    def bam_chop_device(self, native_bam, tids, starts, ends, flanks, chunk_first, chunks, max_keep: int = 20):
+        """vapor_bam_chop_device: the read selection of many regions of an open BAM file on the device.  Returns (kept_first,
+        device addresses of the kept reads' packed bases, q0, miss_bp, status per region, BamBatch); the batch owns the data the
+        addresses point into - close it after the sequence sets made from them."""
+        n = len(tids)
+        tids = np.ascontiguousarray(tids, dtype=np.int32)
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        ends = np.ascontiguousarray(ends, dtype=np.int64)
+        flanks = np.ascontiguousarray(flanks, dtype=np.int64)
+        chunk_first = np.ascontiguousarray(chunk_first, dtype=np.int32)
+        chunks = np.ascontiguousarray(chunks, dtype=np.uint64).reshape(-1)
+        if len(chunk_first) != n + 1 or len(chunks) != 2 * int(chunk_first[-1]):
+            raise ValueError("chunk_first / chunks do not describe %d regions" % n)
+        kept_first = np.zeros(n + 1, dtype=np.int32)
+        cap = max(n * max_keep, 1)
+        addr = np.zeros(cap, dtype=np.uint64)
+        q0 = np.zeros(cap, dtype=np.int64)
+        miss = np.zeros(cap, dtype=np.int64)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        h = ctypes.c_void_p()
+        vp = ctypes.c_void_p
+        L.check(L.load().vapor_bam_chop_device(self._ctx, native_bam, n, tids.ctypes.data_as(vp), starts.ctypes.data_as(vp), ends.ctypes.data_as(vp),
+                                               flanks.ctypes.data_as(vp), chunk_first.ctypes.data_as(vp), chunks.ctypes.data_as(vp) if len(chunks) else None,
+                                               int(max_keep), kept_first.ctypes.data_as(vp), addr.ctypes.data_as(vp), q0.ctypes.data_as(vp),
+                                               miss.ctypes.data_as(vp), status.ctypes.data_as(vp), ctypes.byref(h)))
+        w = int(kept_first[n])
+        return kept_first, addr[:w], q0[:w], miss[:w], status[:n], BamBatch(h)
+
+    def seqset_raw(self, addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None, src_kind=None, src_first=None) -> SeqSet:
         """A set from (address, length) pairs - slices of strings the caller keeps alive - and derived sequences as arrays."""
-        return SeqSet.from_addresses(self, addr, lens, derived, keepalive)
+        return SeqSet.from_addresses(self, addr, lens, derived, keepalive, src_kind, src_first)
 
     def plan(self, seqset: SeqSet, pairs: np.ndarray) -> Plan:
         return Plan(self, seqset, pairs)

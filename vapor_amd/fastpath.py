@@ -57,6 +57,15 @@ def capable(backend, bam_in, engine=None) -> bool:
 def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: int) -> List[object]:
     """specs: (type, chrom, start, end, ins_seq) per locus (`end` unused for INS, `start` its position).  Returns per locus the
     list of read scores the driver would return, or FALLBACK."""
+    held: list = []                       # device batches of the read selection: closed on this thread on every way out
+    try:
+        return _run(engine, specs, bam_in, ref, num_reads_cff, held)
+    finally:
+        for bt in held:
+            bt.close()
+
+
+def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
     from . import pipeline
     from .engine import _ASCII_OFF
     be = seqio.get_backend()
@@ -78,10 +87,22 @@ def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: in
     if len(idx) == 0:
         return out
     chroms = [specs[t][1] for t in idx.tolist()]
-    try:
-        kf, addr, q0, miss, status, keepalive = be.chop_many(bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
-    except NotImplementedError:
-        return out
+    # reads by device address (4-bit bases in the inflated blocks of a vapor_bam_chop_device batch) where the backend and the
+    # engine do that, else by host address (ASCII)
+    on_device = False
+    kf = None
+    if hasattr(be, "chop_many_device") and hasattr(engine, "bam_chop_device"):
+        try:
+            kf, addr, q0, miss, status, keepalive = be.chop_many_device(engine, bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
+            held.extend(keepalive)
+            on_device = True
+        except NotImplementedError:
+            kf = None
+    if kf is None:
+        try:
+            kf, addr, q0, miss, status, keepalive = be.chop_many(bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
+        except NotImplementedError:
+            return out
     n_reads = np.diff(kf).astype(np.int64)
     # (a read that starts before its record: Python's negative slice - the drivers' way)
     neg = np.zeros(len(idx), dtype=bool)
@@ -178,13 +199,17 @@ def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: in
     # reads of the live loci behind the windows: slices of the records' own sequences
     n_lit_w = len(lit_addr)
     rd_first = []
-    parts_a, parts_l, parts_m = [], [], []
+    parts_a, parts_l, parts_m, parts_f = [], [], [], []
     kfl = kf.tolist()
     at = n_lit_w
     for (j, t, *_rest) in loc:
         a, b = kfl[j], kfl[j + 1]
         rd_first.append(at)
-        parts_a.append(addr[a:b] + q0[a:b].astype(np.uint64))
+        if on_device:
+            parts_a.append(addr[a:b])                    # (the record's packed bases; the read starts at base q0 of them)
+            parts_f.append(q0[a:b])
+        else:
+            parts_a.append(addr[a:b] + q0[a:b].astype(np.uint64))
         parts_l.append((r_end[t] - r_start[t]) - miss[a:b])
         parts_m.append(miss[a:b])
         at += b - a
@@ -192,6 +217,11 @@ def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: in
     all_len = np.concatenate([np.asarray(lit_len, dtype=np.int64)] + parts_l)
     rd_miss = np.concatenate(parts_m)
     n_lit = len(all_addr)
+    src_kind = src_first = None
+    if on_device:
+        src_kind = np.zeros(n_lit, dtype=np.uint8)
+        src_kind[n_lit_w:] = 1
+        src_first = np.concatenate([np.zeros(n_lit_w, dtype=np.int64)] + parts_f)
     segs_a = np.zeros(max(len(seg_rows), 1), dtype=L.SEG_DTYPE)
     if seg_rows:
         sr = np.asarray(seg_rows, dtype=np.int64)
@@ -199,8 +229,14 @@ def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: in
 
     def place(v):
         return n_lit - 1 - v if v < 0 else v
-    ss = engine.seqset_raw(all_addr, all_len, (np.asarray(seg_first, dtype=np.int32), segs_a, np.asarray(dflags, dtype=np.uint8)),
-                           keepalive=(keep, keepalive))
+    if on_device:
+        ss = engine.seqset_raw(all_addr, all_len, (np.asarray(seg_first, dtype=np.int32), segs_a, np.asarray(dflags, dtype=np.uint8)),
+                               keepalive=(keep, keepalive), src_kind=src_kind, src_first=src_first)
+        for bt in keepalive:                              # (the planes are made: the inflated blocks can go)
+            bt.close()
+    else:
+        ss = engine.seqset_raw(all_addr, all_len, (np.asarray(seg_first, dtype=np.int32), segs_a, np.asarray(dflags, dtype=np.uint8)),
+                               keepalive=(keep, keepalive))
     try:
         n_exc, n_inv, lens = ss.n_exc, ss.n_invalid, ss.lens
         # ---- window_size_refine's first self dot plot for every window (k = 10), in one plan -------------------------------

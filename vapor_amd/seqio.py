@@ -195,6 +195,43 @@ class InProcessBam(SamtoolsHybrid):
         miss_a = np.concatenate(pm).astype(np.int64) if pm else np.zeros(0, dtype=np.int64)
         return kept_first, addr, np.zeros(w, dtype=np.int64), miss_a, status, keep
 
+    def chop_many_device(self, engine, bam: str, chroms, starts, ends, flanks, max_keep: int = 20):
+        """chop_many with the work on the device (vapor_bam_chop_device: the regions' BGZF blocks go over the link compressed,
+        one wavefront inflates a block, one walks a region's records): (kept_first, DEVICE addresses of the kept reads' packed
+        bases, q0 = first base of each read's part, miss, status, keepalive).  A region the device leaves to the host route
+        (status != 0: a damaged block, a record without CIGAR, ...) is answered by the caller's per-locus route, which words
+        the reference's errors."""
+        import numpy as np
+        if _env_is(b"VAPOR_BAM_NATIVE", b"0") or _env_is(b"VAPOR_BAM_DEVICE", b"0") or not hasattr(engine, "bam_chop_device"):
+            raise NotImplementedError("no device reader")
+        from . import _lib
+        lib = _lib.load()
+        if not hasattr(lib, "vapor_bam_chop_device"):
+            raise NotImplementedError("no device reader")
+        b = self._open(bam)
+        n = len(chroms)
+        tids = np.zeros(n, dtype=np.int32)
+        chunk_first = np.zeros(n + 1, dtype=np.int32)
+        flat = []
+        index_chunks = b.index.chunks
+        tid_of = b.tid
+        for g in range(n):
+            t = tid_of.get(chroms[g])
+            if t is not None:
+                tids[g] = t
+                for c in index_chunks(t, max(int(starts[g]) - 1, 0), int(ends[g])):
+                    flat.append(c[0])
+                    flat.append(c[1])
+            chunk_first[g + 1] = len(flat) >> 1
+        tl = b._take_handle(lib)
+        try:
+            kf, addr, q0, miss, status, batch = engine.bam_chop_device(tl["native"], tids, starts, ends, flanks, chunk_first,
+                                                                       np.asarray(flat, dtype=np.uint64), max_keep)
+        finally:
+            with b._lock:
+                b._free.append(tl)
+        return kf, addr, q0, miss, status, [batch]
+
     def isfile(self, path: str) -> bool:
         # (bam_in_decide, SF:69-89, asks once per locus: a file this reader holds open is a file - no stat, and no release of
         # the interpreter lock around one, for the loci after the first)
