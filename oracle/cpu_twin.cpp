@@ -604,3 +604,88 @@ extern "C" int vapor_cigar2alignstart_ops(const uint32_t* ops, int64_t n_ops, in
     for (int64_t t = 0; t < n_ops; ++t) text += std::to_string(ops[t] >> 4) + ((ops[t] & 15u) <= 8u ? "MIDNSHP=X"[ops[t] & 15u] : '?');
     return vapor_cigar2alignstart(text.c_str(), align_start, start, out);
 }
+
+// ---- read extraction "on the device" (vapor_bam_chop_device, vapor_seqset_create_mixed) ---------------------------------
+// The twin has no device: a batch is host memory, the regions go through the host reader (vapor_bam_chop, compiled into this
+// library from vapor_amd/csrc/vapor_bam.cpp) one by one, and the kept reads are packed four bits a base the way a BAM record
+// holds them - starting at an odd base for every other read, so that callers meet both nibble phases.
+struct vapor_bam_batch { std::vector<std::vector<uint8_t>> packed; };
+
+extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_regions, const int32_t* tid, const int64_t* start,
+                                     const int64_t* end, const int64_t* flank, const int32_t* chunk_first, const uint64_t* chunks,
+                                     int32_t max_keep, int32_t* kept_first, uint64_t* sq_addr, int64_t* q0, int64_t* miss,
+                                     int32_t* status, vapor_bam_batch** out)
+{
+    if (!ctx || !bam || !out || n_regions < 0 || max_keep < 1 || max_keep > 256 ||
+        (n_regions && (!tid || !start || !end || !flank || !chunk_first || !kept_first || !sq_addr || !q0 || !miss || !status)))
+        return fail(VAPOR_E_ARG, "vapor_bam_chop_device: bad argument");
+    vapor_bam_batch* B = new vapor_bam_batch();
+    std::vector<uint8_t> seq((size_t)1 << 20);
+    std::vector<char> names((size_t)1 << 16);
+    std::vector<int64_t> meta(4 * 1024);
+    int32_t w = 0;
+    for (int32_t g = 0; g < n_regions; ++g) {
+        kept_first[g] = w;
+        status[g] = 0;
+        const int32_t nc = chunk_first[g + 1] - chunk_first[g];
+        int32_t n = 0;
+        int64_t need[3] = {0, 0, 0};
+        int rc;
+        for (;;) {
+            rc = vapor_bam_chop(bam, tid[g], start[g], end[g], flank[g], nc, nc ? chunks + 2 * (size_t)chunk_first[g] : nullptr, seq.data(),
+                                (int64_t)seq.size(), names.data(), (int64_t)names.size(), meta.data(), (int32_t)(meta.size() / 4), &n, need);
+            if (rc != VAPOR_E_OVERFLOW) break;
+            seq.resize((size_t)need[0] * 2 + 1024); names.resize((size_t)need[1] * 2 + 256); meta.resize(4 * ((size_t)need[2] * 2 + 16));
+        }
+        if (rc != VAPOR_OK) { status[g] = 1; continue; }        // (the host route words the error)
+        std::vector<int32_t> order((size_t)n);
+        for (int32_t i = 0; i < n; ++i) order[(size_t)i] = i;
+        if (n > max_keep) {
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return meta[4 * (size_t)a + 2] < meta[4 * (size_t)b + 2]; });
+            order.resize((size_t)max_keep);
+        }
+        for (int32_t i : order) {
+            const uint8_t* s = seq.data() + meta[4 * (size_t)i];
+            const int64_t len = meta[4 * (size_t)i + 1];
+            const int64_t first = w & 1;
+            std::vector<uint8_t> pk((size_t)((first + len + 1) / 2) + 1, 0);
+            for (int64_t t = 0; t < len; ++t) {
+                const char* at = strchr("=ACMGRSVTWYHKDBN", (char)s[t]);
+                const uint8_t code = at && s[t] ? (uint8_t)(at - "=ACMGRSVTWYHKDBN") : 15;
+                const int64_t b = first + t;
+                pk[(size_t)(b >> 1)] |= (b & 1) ? code : (uint8_t)(code << 4);
+            }
+            B->packed.push_back(std::move(pk));
+            sq_addr[w] = (uint64_t)reinterpret_cast<uintptr_t>(B->packed.back().data());
+            q0[w] = first;
+            miss[w] = meta[4 * (size_t)i + 2];
+            ++w;
+        }
+    }
+    kept_first[n_regions] = w;
+    *out = B;
+    return VAPOR_OK;
+}
+extern "C" int vapor_bam_batch_destroy(vapor_bam_batch* b) { delete b; return VAPOR_OK; }
+
+extern "C" int vapor_seqset_create_mixed(vapor_ctx* ctx, int32_t n, const uint8_t* const* seq, const int32_t* len, const uint8_t* flags,
+                                         const uint8_t* src_kind, const int64_t* src_first, int32_t n_derived, const int32_t* seg_first,
+                                         const vapor_segment* segs, const uint8_t* derived_flags, int32_t* info, vapor_seqset** out)
+{
+    if (!ctx || !out || n < 0 || (n && (!seq || !len))) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: null argument");
+    std::vector<std::string> text((size_t)n);
+    std::vector<const uint8_t*> ptr((size_t)std::max(n, 1));
+    for (int32_t i = 0; i < n; ++i) {
+        ptr[(size_t)i] = seq[i];
+        if (!src_kind || !src_kind[i]) continue;
+        if (src_kind[i] != 1 || !src_first || src_first[i] < 0 || len[i] < 0 || (len[i] && !seq[i]))
+            return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: bad source description");
+        for (int64_t t = 0; t < len[i]; ++t) {
+            const int64_t b = src_first[i] + t;
+            const uint8_t byte = seq[i][b >> 1];
+            text[(size_t)i] += "=ACMGRSVTWYHKDBN"[(b & 1) ? (byte & 15) : (byte >> 4)];
+        }
+        ptr[(size_t)i] = reinterpret_cast<const uint8_t*>(text[(size_t)i].data());
+    }
+    return vapor_seqset_create_derived(ctx, n, ptr.data(), len, flags, n_derived, seg_first, segs, derived_flags, info, out);
+}

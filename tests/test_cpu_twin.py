@@ -146,3 +146,59 @@ def test_allele_with_more_blocks_than_a_descriptor_holds(eng):
     alt16 = drivers._cat(*(parts[:15] + [(ref, blocks[order[14]][0], None)]))
     assert len(alt16.segs) == 16
     assert pipeline.score_requests(eng, [drivers.Score("s1", ref, alt16, reads, 10)]) == pipeline.score_requests(eng, [drivers.Score("s1", ref, str(alt16), reads, 10)])
+
+
+def test_reads_by_device_address_through_the_object_layer(eng, tmp_path):
+    """vapor_bam_chop_device / vapor_seqset_create_mixed through Engine, InProcessBam.chop_many_device and the fast route, on the
+    twin (its "device" addresses are host memory; every other read starts at an odd base): the kept reads and miss_bp of
+    chop_many, the bit planes of the same reads uploaded as text, and the same table from the CLI as with VAPOR_BAM_DEVICE=0."""
+    from vapor_amd import cli, pipeline, seqio, synth
+    w = synth.make_world(seed=53, n_loci=14, svtypes=("DEL", "INV", "INS", "TANDUP", "DEL"), span_range=(80, 1500), read_len=5200, n_reads=24)
+    for c in w.reads:
+        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+    fa, bam = synth.write_world_files(w, str(tmp_path), block_size=0xFF00)
+    be = seqio.InProcessBam()
+    loci = w.loci
+    chroms = [l.chrom for l in loci] + ["no_such_contig"]
+    starts = np.asarray([l.start - 300 for l in loci] + [100], dtype=np.int64)
+    ends = np.asarray([l.start + 300 for l in loci] + [700], dtype=np.int64)
+    fl = np.full(len(chroms), 300, dtype=np.int64)
+    kf, addr, q0, miss, status, keep = be.chop_many(bam, chroms, starts, ends, fl)
+    dkf, daddr, dq0, dmiss, dstatus, batches = be.chop_many_device(eng, bam, chroms, starts, ends, fl)
+    assert dstatus.tolist() == [0] * len(chroms) and dkf.tolist() == kf.tolist() and dmiss.tolist() == miss.tolist() and int(kf[-1]) > 100
+    assert set(dq0.tolist()) == {0, 1}
+    lens = np.concatenate([np.full(kf[g + 1] - kf[g], ends[g] - starts[g], dtype=np.int64) for g in range(len(chroms))]) - miss
+    texts = [ctypes.string_at(int(addr[t] + q0[t]), int(lens[t])).decode() for t in range(len(addr))]
+    dev = eng.seqset_raw(daddr, lens, None, keepalive=batches, src_kind=np.ones(len(daddr), dtype=np.uint8), src_first=dq0)
+    ref = eng.seqset(texts)
+    try:
+        for t in range(len(texts)):
+            assert all(np.array_equal(a, b) for a, b in zip(dev.planes(t), ref.planes(t))), t
+        assert np.array_equal(dev.n_exc, ref.n_exc) and np.array_equal(dev.n_invalid, ref.n_invalid)
+    finally:
+        dev.close(); ref.close()
+        for bt in batches:
+            bt.close()
+    # a source that is not a device source and one described badly
+    with pytest.raises(Exception):
+        eng.seqset_raw(daddr[:1], lens[:1], None, src_kind=np.asarray([2], dtype=np.uint8), src_first=np.zeros(1, dtype=np.int64))
+    # the CLI both ways
+    pipeline.set_engine(eng)
+    seqio.set_backend(be)
+    bed = tmp_path / "in.bed"
+    bed.write_text(synth.bed_text(w))
+    tables = {}
+    try:
+        for dev_on in ("1", "0"):
+            out = tmp_path / ("out%s.vapor" % dev_on)
+            os.environ["VAPOR_BAM_DEVICE"] = dev_on
+            os.environ["VAPOR_QC_SEED"] = "7"
+            assert cli.main(["bed", "--sv-input", str(bed), "--reference", fa, "--pacbio-input", bam,
+                             "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
+            tables[dev_on] = out.read_text()
+    finally:
+        os.environ.pop("VAPOR_BAM_DEVICE", None)
+        os.environ.pop("VAPOR_QC_SEED", None)
+        pipeline.set_engine(None)
+        seqio.set_backend(None)
+    assert tables["1"] == tables["0"] and tables["1"].count("\n") == 15

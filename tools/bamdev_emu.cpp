@@ -60,7 +60,7 @@ static int run(const std::vector<uint8_t>& comp, size_t u_len, uint32_t crc, std
     static std::vector<uint8_t> image;
     image.assign((size_t)U_MAX + 32, 0xAA);
     uint8_t* out = image.data() + align;
-    const int rc = inflate_block_wave<true>(L, T, out, comp.data(), (uint32_t)comp.size(), (uint32_t)u_len, crc, g_pow, 0);
+    const int rc = inflate_block_wave<1>(L, T, out, comp.data(), (uint32_t)comp.size(), (uint32_t)u_len, crc, g_pow, 0);
     got.assign(out, out + u_len);
     return rc;
 }

@@ -38,12 +38,17 @@
 // Lane 0's decoding is scalar work: what it reads from LDS is declared uniform (v_readfirstlane), so that the shifts, masks,
 // compares and branches on it go to the scalar unit - a vector instruction holds the SIMD for four clocks however few lanes
 // are on, the scalar unit takes one, and sixteen wavefronts a CU were queueing for the vector issue.
-// Two flavours of the decoder (template flag SC): with the declaration (scalar unit) and without (vector units).  Measured on
-// 8 240 blocks of 64 KB (profiles/r05_bamdev.txt): scalar 18.0 ms, vector 23.6 ms, alternating wavefronts 22.0 ms (a launch ends
-// with its slowest blocks) - the product runs the scalar flavour; -DVBD_FLAVOUR=0 (developer builds) the other.
-#define VBD_UNI(x) (SC ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(x)) : (uint32_t)(x))
+// Three flavours of the decoder (template flag SC).  Measured on 8 240 blocks of 64 KB (profiles/r05_bamdev.txt): all vector
+// 23.6 ms, all scalar 17.9 ms, scalar control over vector data 16.0 ms - the product's; -DVBD_FLAVOUR=0 / 1 (developer builds)
+// the others.
+// SC = 1: everything lane 0 reads is declared uniform (data and control on the scalar unit); SC = 2: only what a branch looks at
+// (VBD_CTL) - the bit buffer, the table entries, the cursors stay in vector registers, the decisions are scalar branches; SC = 0:
+// nothing (vector code under exec masks).
+#define VBD_UNI(x) (SC == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(x)) : (uint32_t)(x))
+#define VBD_CTL(x) (SC != 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(x)) : (uint32_t)(x))
 #else
 #define VBD_UNI(x) ((uint32_t)(x))
+#define VBD_CTL(x) ((uint32_t)(x))
 #define VBD_LANE_SLOTS 64
 #define VBD_DEV static inline
 #define VBD_SYNC() ((void)0)
@@ -52,7 +57,8 @@
 #define VBD_LANE0 (true)
 #endif
 
-#if (defined(VBD_TIMING) || defined(VBD_EXP_NOSTORE) || defined(VBD_EXP_NOMATCH) || defined(VBD_FLAVOUR)) && !defined(VAPOR_DEV_BUILD)
+#if (defined(VBD_TIMING) || defined(VBD_EXP_NOSTORE) || defined(VBD_EXP_NOMATCH) || defined(VBD_FLAVOUR) || defined(VBD_LLB) || defined(VBD_MIN_WAVES)) && \
+    !defined(VAPOR_DEV_BUILD) && !defined(VBD_EMU)
 #error "developer switch without -DVAPOR_DEV_BUILD: a product library cannot be an experimental one"
 #endif
 // -DVBD_TIMING (developer builds): lane 0 adds up the shader clock it spends per phase; the kernel stores the sums per block
@@ -275,7 +281,7 @@ struct Bits {
 };
 // Whole bytes up to 56..63 valid bits, out of three aligned words of the LDS copy.  The bits above n are not counted but
 // they are the stream's own next bits (zeros behind its end): the next refill puts the same bits there again.
-template <bool SC>
+template <int SC>
 VBD_DEV void refill(Bits& b)
 {
     if (b.n < 0) return;
@@ -310,17 +316,17 @@ VBD_DEV int read_fixed(InflateLds& L)
 
 // the header of a dynamic block (RFC 1951 3.2.7); the caller has made sure `in` holds the whole of it (it is at most
 // 14 + 19 * 3 + 316 * 14 bits = 562 bytes) or the end of the stream
-template <bool SC>
+template <int SC>
 VBD_DEV int read_dynamic(Bits& b, InflateLds& L)
 {
     const uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     refill<SC>(b);
-    const int hlit = (int)take(b, 5) + 257, hdist = (int)take(b, 5) + 1, hclen = (int)take(b, 4) + 4;
+    const int hlit = (int)VBD_CTL(take(b, 5)) + 257, hdist = (int)VBD_CTL(take(b, 5)) + 1, hclen = (int)VBD_CTL(take(b, 4)) + 4;
     if (hlit > 286 || hdist > 30) return BLK_BAD_STREAM;
     uint8_t* pl = L.pl;
     for (int i = 0; i < 19; ++i) pl[i] = 0;
     for (int i = 0; i < hclen; ++i) {
-        if (b.n < 3) refill<SC>(b);
+        if ((int)VBD_CTL(b.n) < 3) refill<SC>(b);
         pl[ORDER[i]] = (uint8_t)take(b, 3);
     }
     if (b.n < 0) return BLK_BAD_STREAM;
@@ -330,7 +336,7 @@ VBD_DEV int read_dynamic(Bits& b, InflateLds& L)
     const int total = hlit + hdist;
     while (i < total) {
         refill<SC>(b);
-        const uint32_t e = VBD_UNI(L.pre[peek(b, PREB)]);
+        const uint32_t e = VBD_CTL(L.pre[peek(b, PREB)]);
         if (!e) return BLK_BAD_STREAM;
         drop(b, (int)(e & 31u));
         const int sym = (int)(e >> 16);
@@ -339,11 +345,11 @@ VBD_DEV int read_dynamic(Bits& b, InflateLds& L)
         if (sym == 16) {
             if (i == 0) return BLK_BAD_STREAM;
             val = L.lens[i - 1];
-            rep = 3 + (int)take(b, 2);
+            rep = 3 + (int)VBD_CTL(take(b, 2));
         } else if (sym == 17) {
-            rep = 3 + (int)take(b, 3);
+            rep = 3 + (int)VBD_CTL(take(b, 3));
         } else {
-            rep = 11 + (int)take(b, 7);
+            rep = 11 + (int)VBD_CTL(take(b, 7));
         }
         if (i + rep > total) return BLK_BAD_STREAM;
         for (int t = 0; t < rep; ++t) L.lens[i + t] = (uint8_t)val;
@@ -359,7 +365,7 @@ VBD_DEV int read_dynamic(Bits& b, InflateLds& L)
 }
 
 // the refill of the fast loop: the caller has made sure sixteen stream bytes lie behind ip, so nothing is clamped
-template <bool SC>
+template <int SC>
 VBD_DEV void refill_fast(Bits& b)
 {
     const uint32_t* w = b.in_w + (b.ip >> 2);
@@ -375,17 +381,17 @@ VBD_DEV void refill_fast(Bits& b)
 // One batch of lane 0's work: block headers and symbols until Q_CAP matches are queued, the LDS copy of the stream runs low,
 // stored bytes wait to be copied, the stream ends or an error is found.  Literals go straight to `out`; matches are queued
 // (a match of distance 1 behind a byte lane 0 knows - a run - is queued as that byte: its copy needs no load).
-template <bool SC>
+template <int SC>
 VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t c_len)
 {
     InflateState& S = L.st;
     VBD_COUNT(3);
     Bits b;
     b.buf = (uint64_t)VBD_UNI((uint32_t)S.buf) | ((uint64_t)VBD_UNI((uint32_t)(S.buf >> 32)) << 32);
-    b.n = (int)VBD_UNI(S.n); b.ip = (int)VBD_UNI(S.ip); b.in_have = (int)VBD_UNI(S.in_have); b.in_w = L.in_w;
+    b.n = (int)VBD_UNI(S.n); b.ip = (int)VBD_UNI(S.ip); b.in_have = (int)VBD_CTL(S.in_have); b.in_w = L.in_w;
     uint32_t op = VBD_UNI(S.op), known = VBD_UNI(S.known);
-    int phase = (int)VBD_UNI(S.phase), last = (int)VBD_UNI(S.last), nq = 0, err = 0;
-    const bool all_loaded = VBD_UNI(S.g_next) >= c_len;
+    int phase = (int)VBD_CTL(S.phase), last = (int)VBD_CTL(S.last), nq = 0, err = 0;
+    const bool all_loaded = VBD_CTL(S.g_next) >= c_len;
     constexpr uint32_t LL_MASK = (1u << LLB) - 1u, D_MASK = (1u << DB) - 1u;
 #define VBD_IS_LIT1(e) (((e) & (E_LIT | E_SUB)) == E_LIT)
     // a match (len, dist) at op into the queue
@@ -393,7 +399,7 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
     do {                                                                                                         \
         uint32_t dw_ = (dist);                                                                                   \
         VBD_COUNT(2);                                                                                            \
-        if (dw_ == 1u && known) {                                                                                \
+        if (VBD_CTL((uint32_t)(dw_ == 1u && known != 0u))) {                                                     \
             VBD_COUNT(5);                                                                                        \
             const uint32_t byte_ = (known & E_LIT2) ? known >> 24 : (known >> 16) & 0xFFu;                       \
             dw_ = Q_FILL | (byte_ << 16) | 1u;                                                                   \
@@ -411,21 +417,21 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
             // (building tables uses the match queue's bytes: the queued matches are copied first)
             if (nq) break;
             // a block header: all of it must be in `in` (600 bytes cover the longest), or the stream's end
-            if (!all_loaded && b.in_have - b.ip < 600) break;
+            if (!all_loaded && b.in_have - (int)VBD_CTL(b.ip) < 600) break;
             refill<SC>(b);
-            last = (int)take(b, 1);
-            const uint32_t type = take(b, 2);
-            if (b.n < 0) { err = BLK_BAD_STREAM; break; }
+            last = (int)VBD_CTL(take(b, 1));
+            const uint32_t type = VBD_CTL(take(b, 2));
+            if ((int)VBD_CTL(b.n) < 0) { err = BLK_BAD_STREAM; break; }
             if (type == 0) {
                 // stored: to the byte boundary; LEN and NLEN; the bytes themselves are copied by the wavefront from the payload
                 drop(b, b.n & 7);
-                if (b.n < 32) refill<SC>(b);
-                if (b.n < 32) { err = BLK_BAD_STREAM; break; }
-                const uint32_t len = take(b, 16), nlen = take(b, 16);
+                if ((int)VBD_CTL(b.n) < 32) refill<SC>(b);
+                if ((int)VBD_CTL(b.n) < 32) { err = BLK_BAD_STREAM; break; }
+                const uint32_t len = VBD_CTL(take(b, 16)), nlen = VBD_CTL(take(b, 16));
                 if ((len ^ nlen) != 0xFFFFu) { err = BLK_BAD_STREAM; break; }
                 // payload offset of the first stored byte: what `in` holds from ip on lies behind the bytes still in the bit buffer
-                const uint32_t src = S.g_next - (uint32_t)(b.in_have - b.ip) - (uint32_t)(b.n >> 3);
-                if (src > c_len || len > c_len - src || len > u_len - op) { err = BLK_BAD_STREAM; break; }
+                const uint32_t src = VBD_CTL(S.g_next - (uint32_t)(b.in_have - b.ip) - (uint32_t)(b.n >> 3));
+                if (src > c_len || len > c_len - src || len > u_len - VBD_CTL(op)) { err = BLK_BAD_STREAM; break; }
                 S.st_src = src; S.st_len = len;
                 if (len) known = 0;
                 phase = 2;
@@ -441,7 +447,7 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
 #endif
             // (the table builders branch on what they read from LDS: what comes back from them is said to be uniform again, or
             // the compiler keeps the whole decoder state in vector registers from here on)
-            err = (int)VBD_UNI(err);
+            err = (int)VBD_CTL(err);
             b.buf = (uint64_t)VBD_UNI((uint32_t)b.buf) | ((uint64_t)VBD_UNI((uint32_t)(b.buf >> 32)) << 32);
             b.n = (int)VBD_UNI(b.n); b.ip = (int)VBD_UNI(b.ip);
             if (err) break;
@@ -449,7 +455,8 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
         }
         // ---- the fast loop: sixteen stream bytes behind ip (two refills that clamp nothing), eight bytes of room in the output
         // (four double literals stored without a test).  No bit count can go negative here: every symbol starts with 48 bits.
-        if (b.n >= 0 && b.ip + 16 <= b.in_have && op + 8 <= u_len) {
+        nq = (int)VBD_CTL(nq);
+        if ((int)VBD_CTL(b.n) >= 0 && (int)VBD_CTL(b.ip) + 16 <= b.in_have && VBD_CTL(op) + 8 <= u_len) {
             refill_fast<SC>(b);
             uint32_t e = VBD_UNI(L.ll[(uint32_t)b.buf & LL_MASK]);
             bool leave = false;
@@ -459,9 +466,9 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
                 // unit where a branch on something a table builder read made it doubt)
                 b.buf = (uint64_t)VBD_UNI((uint32_t)b.buf) | ((uint64_t)VBD_UNI((uint32_t)(b.buf >> 32)) << 32);
                 b.n = (int)VBD_UNI(b.n); b.ip = (int)VBD_UNI(b.ip); op = VBD_UNI(op); e = VBD_UNI(e); nq = (int)VBD_UNI(nq); known = VBD_UNI(known);
-                if (b.ip + 16 > b.in_have || op + 8 > u_len) break;
+                if ((int)VBD_CTL(b.ip) + 16 > b.in_have || VBD_CTL(op) + 8 > u_len) break;
                 refill_fast<SC>(b);
-                if (VBD_IS_LIT1(e)) {
+                if (VBD_IS_LIT1(VBD_CTL(e))) {
                     // up to four table hits out of one refill (40 of its 56 bits at most), each one literal or two: both bytes are
                     // stored either way, the cursor moves by one or two
 #ifdef VBD_EXP_NOSTORE
@@ -481,32 +488,34 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
         e = VBD_UNI(L.ll[(uint32_t)b.buf & LL_MASK]);                                        \
     } while (0)
                     VBD_EMIT();
-                    if (VBD_IS_LIT1(e)) {
+                    if (VBD_IS_LIT1(VBD_CTL(e))) {
                         VBD_EMIT();
-                        if (VBD_IS_LIT1(e)) {
+                        if (VBD_IS_LIT1(VBD_CTL(e))) {
                             VBD_EMIT();
-                            if (VBD_IS_LIT1(e)) VBD_EMIT();
+                            if (VBD_IS_LIT1(VBD_CTL(e))) VBD_EMIT();
                         }
                     }
 #undef VBD_EMIT
-                    if (VBD_IS_LIT1(e)) continue;
-                    if (b.ip + 8 > b.in_have || op + 8 > u_len) break;
+                    if (VBD_IS_LIT1(VBD_CTL(e))) continue;
+                    if ((int)VBD_CTL(b.ip) + 8 > b.in_have || VBD_CTL(op) + 8 > u_len) break;
                     refill_fast<SC>(b);
                 }
                 VBD_COUNT(4);
 #if defined(VBD_TIMING) && !defined(VBD_EMU)
                 const long long tg0 = clock64();
 #endif
-                if (e & E_SUB) {
+                uint32_t ec = VBD_CTL(e);                              // (what the branches look at)
+                if (ec & E_SUB) {
                     drop(b, LLB);
                     e = VBD_UNI(L.ll[(e >> 16) + peek(b, (int)((e >> 8) & 31u))]);
+                    ec = VBD_CTL(e);
                 }
-                if (!e) { err = BLK_BAD_STREAM; leave = true; break; }
+                if (!ec) { err = BLK_BAD_STREAM; leave = true; break; }
                 drop(b, (int)(e & 31u));
-                if (e & E_LIT) {
+                if (ec & E_LIT) {
                     out[op++] = (uint8_t)(e >> 16);
                     known = e;
-                } else if (e & E_EOB) {
+                } else if (ec & E_EOB) {
                     phase = last ? 3 : 0;
                     leave = true;
                     break;
@@ -515,16 +524,18 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
                     const uint32_t len = (e >> 16) + peek(b, xl);
                     drop(b, xl);
                     uint32_t f = VBD_UNI(L.ds[(uint32_t)b.buf & D_MASK]);
-                    if (f & E_SUB) {
+                    uint32_t fc = VBD_CTL(f);
+                    if (fc & E_SUB) {
                         drop(b, DB);
                         f = VBD_UNI(L.ds[(f >> 16) + peek(b, (int)((f >> 8) & 31u))]);
+                        fc = VBD_CTL(f);
                     }
-                    if (!f) { err = BLK_BAD_STREAM; leave = true; break; }
+                    if (!fc) { err = BLK_BAD_STREAM; leave = true; break; }
                     drop(b, (int)(f & 31u));
                     const int xd = (int)((f >> 8) & 31u);
                     const uint32_t dist = (f >> 16) + peek(b, xd);
                     drop(b, xd);
-                    if (dist > op || len > u_len - op) { err = BLK_BAD_STREAM; leave = true; break; }
+                    if (VBD_CTL((uint32_t)(dist > op || len > u_len - op))) { err = BLK_BAD_STREAM; leave = true; break; }
                     VBD_QUEUE(len, dist);
                     if (nq == Q_CAP) { leave = true; break; }
                 }
@@ -538,23 +549,23 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
         }
         // ---- one symbol with every test (the ends of the input and of the output): 48 bits cover the longest (15 + 5 + 15 + 13)
         VBD_COUNT(1);
-        if (b.n < 48) {
-            if (!all_loaded && b.ip + 8 > b.in_have) break;
+        if ((int)VBD_CTL(b.n) < 48) {
+            if (!all_loaded && (int)VBD_CTL(b.ip) + 8 > b.in_have) break;
             refill<SC>(b);
         }
-        uint32_t e = VBD_UNI(L.ll[(uint32_t)b.buf & LL_MASK]);
+        uint32_t e = VBD_CTL(L.ll[(uint32_t)b.buf & LL_MASK]);      // (this loop runs a dozen times a block: all of it scalar where any is)
         if (e & E_SUB) {
             drop(b, LLB);
-            e = VBD_UNI(L.ll[(e >> 16) + peek(b, (int)((e >> 8) & 31u))]);
+            e = VBD_CTL(L.ll[(e >> 16) + peek(b, (int)((e >> 8) & 31u))]);
         }
         if (!e) { err = BLK_BAD_STREAM; break; }
         drop(b, (int)(e & 31u));
-        if (b.n < 0) { err = BLK_BAD_STREAM; break; }
+        if ((int)VBD_CTL(b.n) < 0) { err = BLK_BAD_STREAM; break; }
         if (e & E_LIT) {
-            if (op >= u_len) { err = BLK_BAD_STREAM; break; }
+            if (VBD_CTL(op) >= u_len) { err = BLK_BAD_STREAM; break; }
             out[op++] = (uint8_t)(e >> 16);
             if (e & E_LIT2) {
-                if (op >= u_len) { err = BLK_BAD_STREAM; break; }
+                if (VBD_CTL(op) >= u_len) { err = BLK_BAD_STREAM; break; }
                 out[op++] = (uint8_t)(e >> 24);
             }
             known = e;
@@ -568,17 +579,17 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
         const int xl = (int)((e >> 8) & 31u);
         const uint32_t len = (e >> 16) + peek(b, xl);
         drop(b, xl);
-        uint32_t f = VBD_UNI(L.ds[(uint32_t)b.buf & D_MASK]);
+        uint32_t f = VBD_CTL(L.ds[(uint32_t)b.buf & D_MASK]);
         if (f & E_SUB) {
             drop(b, DB);
-            f = VBD_UNI(L.ds[(f >> 16) + peek(b, (int)((f >> 8) & 31u))]);
+            f = VBD_CTL(L.ds[(f >> 16) + peek(b, (int)((f >> 8) & 31u))]);
         }
         if (!f) { err = BLK_BAD_STREAM; break; }
         drop(b, (int)(f & 31u));
         const int xd = (int)((f >> 8) & 31u);
         const uint32_t dist = (f >> 16) + peek(b, xd);
         drop(b, xd);
-        if (b.n < 0 || dist > op || len > u_len - op) { err = BLK_BAD_STREAM; break; }
+        if (VBD_CTL((uint32_t)(b.n < 0 || dist > op || len > u_len - op))) { err = BLK_BAD_STREAM; break; }
         VBD_QUEUE(len, dist);
         if (nq == Q_CAP) break;
     }
@@ -611,7 +622,7 @@ VBD_DEV uint32_t crc_mulmod(uint32_t a, uint32_t b)
 // keeps a fourth workgroup off the CU)
 struct CrcTables { uint32_t t[1][256]; };
 
-template <bool SC>
+template <int SC>
 VBD_DEV int inflate_block_wave(InflateLds& L, const CrcTables& T, uint8_t* out, const uint8_t* payload, uint32_t c_len, uint32_t u_len,
                                uint32_t want_crc, const uint32_t* crc_pow, uint32_t lane)
 {
@@ -798,15 +809,10 @@ __global__ __launch_bounds__(64 * INFLATE_WAVES, VBD_MIN_WAVES) void bgzf_inflat
     if (lane == 0) for (int t = 0; t < 8; ++t) { L[wave].tm[t] = 0; L[wave].cn[t] = 0; }
     const long long t_all = clock64();
 #endif
-#if defined(VBD_FLAVOUR) && VBD_FLAVOUR == 0
-    const int rc = inflate_block_wave<false>(L[wave], T, arena + k.u_off, comp + k.c_off, k.c_len, k.u_len, k.crc, crc_pow, lane);
-#elif defined(VBD_FLAVOUR) && VBD_FLAVOUR == 2
-    // (alternating along the wavefronts of a workgroup and from workgroup to workgroup: every SIMD gets both)
-    const int rc = ((blockIdx.x + (unsigned)wave) & 1u) ? inflate_block_wave<true>(L[wave], T, arena + k.u_off, comp + k.c_off, k.c_len, k.u_len, k.crc, crc_pow, lane)
-                                                        : inflate_block_wave<false>(L[wave], T, arena + k.u_off, comp + k.c_off, k.c_len, k.u_len, k.crc, crc_pow, lane);
-#else
-    const int rc = inflate_block_wave<true>(L[wave], T, arena + k.u_off, comp + k.c_off, k.c_len, k.u_len, k.crc, crc_pow, lane);
+#ifndef VBD_FLAVOUR
+#define VBD_FLAVOUR 2
 #endif
+    const int rc = inflate_block_wave<VBD_FLAVOUR>(L[wave], T, arena + k.u_off, comp + k.c_off, k.c_len, k.u_len, k.crc, crc_pow, lane);
     if (lane == 0) blk_status[b] = rc;
 #if defined(VBD_TIMING)
     // (the sums go where the block's compressed bytes were: nothing reads those again)

@@ -223,14 +223,55 @@ class InProcessBam(SamtoolsHybrid):
                     flat.append(c[0])
                     flat.append(c[1])
             chunk_first[g + 1] = len(flat) >> 1
+        # One call holds the blocks of all its regions on the device at once (compressed and inflated): regions in groups of
+        # at most ~192 MB of compressed blocks (their inflated data stays far below the library's 2 GB a call), a group that the
+        # library still refuses for its size in halves.
+        flat_a = np.asarray(flat, dtype=np.uint64).reshape(-1, 2)
+        comp = np.zeros(n, dtype=np.int64)
+        if len(flat_a):
+            per_chunk = ((flat_a[:, 1] >> np.uint64(16)) - (flat_a[:, 0] >> np.uint64(16))).astype(np.int64) + 65600
+            np.add.at(comp, np.repeat(np.arange(n), np.diff(chunk_first)), per_chunk)
+        cap = int(os.environ.get("VAPOR_BAM_DEVICE_BATCH_MB", "192")) << 20
+        groups = []
+        a = 0
+        while a < n:
+            e, tot = a, 0
+            while e < n and (e == a or tot + int(comp[e]) <= cap):
+                tot += int(comp[e])
+                e += 1
+            groups.append((a, e))
+            a = e
         tl = b._take_handle(lib)
+        parts, batches = [], []
         try:
-            kf, addr, q0, miss, status, batch = engine.bam_chop_device(tl["native"], tids, starts, ends, flanks, chunk_first,
-                                                                       np.asarray(flat, dtype=np.uint64), max_keep)
+            while groups:
+                a, e = groups.pop(0)
+                c0, c1 = int(chunk_first[a]), int(chunk_first[e])
+                try:
+                    got = engine.bam_chop_device(tl["native"], tids[a:e], starts[a:e], ends[a:e], flanks[a:e], chunk_first[a:e + 1] - c0,
+                                                 flat_a[c0:c1].reshape(-1), max_keep)
+                except _lib.VaporHipError as err:
+                    if "in one call" in str(err) and e - a >= 2:
+                        groups[:0] = [(a, (a + e) // 2), ((a + e) // 2, e)]
+                        continue
+                    for bt in batches:
+                        bt.close()
+                    raise
+                parts.append(got[:5])
+                batches.append(got[5])
         finally:
             with b._lock:
                 b._free.append(tl)
-        return kf, addr, q0, miss, status, [batch]
+        kf = np.zeros(n + 1, dtype=np.int32)
+        w = 0
+        g = 0
+        for p in parts:
+            m = len(p[0]) - 1
+            kf[g:g + m + 1] = p[0] + w
+            w += int(p[0][-1])
+            g += m
+        cat = lambda k, dt: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, dtype=dt)    # noqa: E731
+        return kf, cat(1, np.uint64), cat(2, np.int64), cat(3, np.int64), cat(4, np.int32), batches
 
     def isfile(self, path: str) -> bool:
         # (bam_in_decide, SF:69-89, asks once per locus: a file this reader holds open is a file - no stat, and no release of
