@@ -372,6 +372,7 @@ def main() -> None:
             extras["inclusive"] = inclusive_rate(eng, w, wl)
             extras["pipeline"] = pipeline_rate()
             extras["pipeline_simulate_spans"] = pipeline_rate(span_dist="simulate")
+            extras["files_path"] = files_rate()
             if args.sub and args.sub != args.workload:
                 extras["sub"] = sub_record(eng, wl, args.sub, torch, cpu_seconds=0.0 if args.no_cpu else min(args.cpu_seconds, 10.0))
         if not args.no_cpu:
@@ -451,6 +452,8 @@ def main() -> None:
         out.update(extras)
         if "pipeline" in extras and "value" in extras["pipeline"]:
             out["pipeline_value"] = extras["pipeline"]["value"]    # the drivers end to end, one process (host-bound)
+        if "files_path" in extras and "value" in extras["files_path"]:
+            out["files_value"] = extras["files_path"]["value"]     # ... and from FASTA/BAM files, reads extracted on the device
         if "inclusive" in extras:
             # the same batch when every pass also pays upload + packing, the window self plots, planning and a blocking pass
             out["inclusive_value"] = extras["inclusive"]["value"]
@@ -685,6 +688,54 @@ def pipeline_rate(n_loci: int = 400, span_dist=None):
                 "spans": ("simulate/Structural_Variants_het distribution (vapor_amd/data/simulate_spans.json)" if span_dist else "uniform 100 - 4 000 bp"),
                 "includes": "cli.bed_jobs -> drivers -> pipeline.run_batch (one sequence set and plan per round) -> result rows; in-memory "
                             "world of %d DEL/INV/INS loci x 20 reads of 9.5 kb, one process, figures off; best of 3" % n_loci}
+    except Exception as e:      # noqa: BLE001 - a side record must not take the headline down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def files_rate(n_loci: int = 500):
+    """the same drivers from FASTA + BAM FILES through the product CLI in this process - what a `vapor bed` run
+    sees - with the read extraction on the device (vapor_bam_chop_device: the regions' BGZF blocks cross the link compressed, one
+    wavefront inflates a block, one walks a region's records) and, beside it, on the host's prefetch threads (vapor_bam_chop);
+    the two tables must be byte-identical.  The reference runs a samtools process per locus here (SF:340)."""
+    import contextlib
+    import hashlib
+    import io
+    import tempfile
+    try:
+        from vapor_amd import cli, synth
+        w = synth.make_world(seed=11, n_loci=n_loci, svtypes=("DEL", "DEL", "INV", "INS"), span_range=(100, 4000), read_len=9500, n_reads=20)
+        for c in w.reads:
+            w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+        tmp = tempfile.mkdtemp(prefix="vapor_bench_files_")
+        fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
+        bed = os.path.join(tmp, "in.bed")
+        open(bed, "w").write(synth.bed_text(w))
+        rec = {"unit": "loci/s", "loci": n_loci, "bam_mb": round(os.path.getsize(bam) / 1e6, 1)}
+        shas = {}
+        was = os.environ.get("VAPOR_BAM_DEVICE")
+        try:
+            for name, dev in (("device", "1"), ("host", "0")):
+                os.environ["VAPOR_BAM_DEVICE"] = dev
+                out = os.path.join(tmp, "o_%s.vapor" % name)
+                args = ["bed", "--sv-input", bed, "--reference", fa, "--pacbio-input", bam, "--output-path", tmp + "/f", "--output-file", out, "--no-figures"]
+                best = 1e9
+                with contextlib.redirect_stdout(io.StringIO()):
+                    cli.main(args)                                   # (warm: engines, pools, page cache)
+                    for _ in range(3):
+                        t0 = time.perf_counter(); cli.main(args); best = min(best, time.perf_counter() - t0)
+                shas[name] = hashlib.sha256(open(out, "rb").read()).hexdigest()[:16]
+                rec["value" if name == "device" else "host_extraction_value"] = round(n_loci / best, 1)
+        finally:
+            if was is None:
+                os.environ.pop("VAPOR_BAM_DEVICE", None)
+            else:
+                os.environ["VAPOR_BAM_DEVICE"] = was
+        rec["tables_equal"] = shas["device"] == shas["host"]
+        rec["table_sha"] = shas["device"]
+        rec["includes"] = ("cli.main bed from FASTA/.fai + BAM/.bai files (64 KB BGZF blocks, qualities 0xFF), one warm process, figures off, best of 3; "
+                           "value = reads by device address (vapor_bam_chop_device), host_extraction_value = the host reader on %d usable cores"
+                           % len(os.sched_getaffinity(0)))
+        return rec
     except Exception as e:      # noqa: BLE001 - a side record must not take the headline down
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

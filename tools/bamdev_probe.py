@@ -15,7 +15,7 @@ w = synth.make_world(seed=11, n_loci=n, svtypes=("DEL", "DEL", "INV", "INS"), sp
 for c in w.reads:
     w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
 tmp = tempfile.mkdtemp()
-fa, bam = synth.write_world_files(w, tmp, block_size=block)
+fa, bam = synth.write_world_files(w, tmp, block_size=block, qual_seed=(7 if '--qual' in sys.argv else None))
 print("files of %d loci: %.1f MB BAM, blocks of %d" % (n, os.path.getsize(bam) / 1e6, block), flush=True)
 rows = [l.split("\t") for l in synth.bed_text(w).strip().splitlines()]
 chroms = [r[0] for r in rows]

@@ -1,5 +1,4 @@
-for c in 666 256 128; do for f in 3 5; do
-  echo "== chunk $c, $f in flight"
-  VAPOR_CHUNKS_IN_FLIGHT=$f timeout -k 10 300 python tools/files_ab.py 2000 0xFF00 $c > gpurun_out/files_ab2.txt 2>&1 || { echo FAILED; tail -5 gpurun_out/files_ab2.txt; }
-  grep "extraction\|equal" gpurun_out/files_ab2.txt
-done; done
+VAPOR_DEBUG_BAMDEV=1 timeout -k 10 300 python tools/bamdev_probe.py 1000 > gpurun_out/bamdev_probe9.txt 2>&1 || { echo FAILED; tail -5 gpurun_out/bamdev_probe9.txt; }
+grep "status counts\|differ\|chop of" gpurun_out/bamdev_probe9.txt; grep "^bam_chop_device" gpurun_out/bamdev_probe9.txt | tail -1
+VAPOR_DEBUG_BAMDEV=1 timeout -k 10 300 python tools/bamdev_probe.py 1000 --qual > gpurun_out/bamdev_probe10.txt 2>&1 || { echo FAILED; tail -5 gpurun_out/bamdev_probe10.txt; }
+grep "files of\|status counts\|differ\|chop of" gpurun_out/bamdev_probe10.txt; grep "^bam_chop_device" gpurun_out/bamdev_probe10.txt | tail -1

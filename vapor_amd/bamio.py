@@ -424,9 +424,10 @@ _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000
 
 
 def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, int, int, str, str]],
-              block_size: int = 16384) -> None:
+              block_size: int = 16384, qual_seed=None) -> None:
     """records: (qname, tid, pos0, cigar string, seq), will be sorted by (tid, pos).  Writes path and
-    path + '.bai'."""
+    path + '.bai'.  Qualities are 0xFF ("absent") - or, with qual_seed, seeded values in runs of a few bases between 2 and 60,
+    which is what makes the blocks of a sequencer's file literal-heavy for its DEFLATE decoder."""
     import re
     import numpy as np
     lut = np.full(256, 15, dtype=np.uint8)               # 4-bit codes of "=ACMGRSVTWYHKDBN", anything else N
@@ -439,6 +440,7 @@ def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, i
     head += b"".join(struct.pack("<i", len(name) + 1) + name.encode() + b"\x00" + struct.pack("<i", ln) for name, ln in refs)
     blobs = []
     meta = []
+    qrng = np.random.default_rng(qual_seed) if qual_seed is not None else None
     for qname, tid, pos, cigar, seq in recs:
         ops = [(int(n), _CIG.index(o)) for n, o in re.findall(r"(\d+)([MIDNSHP=X])", cigar)]
         rlen = sum(n for n, o in ops if o in (0, 2, 3, 7, 8))
@@ -454,7 +456,12 @@ def write_bam(path: str, refs: List[Tuple[str, int]], records: List[Tuple[str, i
             aux = b"CGBI" + struct.pack("<i", len(packed)) + struct.pack("<%dI" % len(packed), *packed)
             packed = [(len(seq) << 4) | 4, (rlen << 4) | 3]
         body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname) + 1, 60, reg2bin(pos, end), len(packed), 0, len(seq), -1, -1, 0)
-        body += qname.encode() + b"\x00" + b"".join(struct.pack("<I", c) for c in packed) + bytes(sq) + b"\xff" * len(seq) + aux
+        if qrng is None:
+            qual = b"\xff" * len(seq)
+        else:
+            runs = qrng.integers(1, 6, size=len(seq) // 2 + 1)
+            qual = np.repeat(qrng.integers(2, 61, size=len(runs)).astype(np.uint8), runs)[:len(seq)].tobytes()
+        body += qname.encode() + b"\x00" + b"".join(struct.pack("<I", c) for c in packed) + bytes(sq) + qual + aux
         blobs.append(struct.pack("<i", len(body)) + body)
         meta.append((tid, pos, end))
     # lay the stream out in BGZF blocks, remembering the virtual offset of every record

@@ -498,7 +498,8 @@ VBD_DEV void decode_batch(InflateLds& L, uint8_t* out, uint32_t u_len, uint32_t 
 #undef VBD_EMIT
                     if (VBD_IS_LIT1(VBD_CTL(e))) continue;
                     if ((int)VBD_CTL(b.ip) + 8 > b.in_have || VBD_CTL(op) + 8 > u_len) break;
-                    refill_fast<SC>(b);
+                    // (the symbol that follows needs 48 bits at most; one literal step out of a refill of 57 and more leaves them)
+                    if ((int)VBD_CTL(b.n) < 48) refill_fast<SC>(b);
                 }
                 VBD_COUNT(4);
 #if defined(VBD_TIMING) && !defined(VBD_EMU)

@@ -560,7 +560,7 @@ def complex_vcf_text(world: SynthWorld, header: bool = False) -> str:
     return "\n".join(out) + "\n"
 
 
-def write_world_files(world: SynthWorld, directory: str, block_size: int = 8192) -> Tuple[str, str]:
+def write_world_files(world: SynthWorld, directory: str, block_size: int = 8192, qual_seed=None) -> Tuple[str, str]:
     """FASTA + .fai and coordinate-sorted BAM + .bai of a synthetic world, written by this package alone
     (vapor_amd.bamio); returns (fasta path, bam path).  Reads keep their order inside one start position."""
     import os
@@ -581,7 +581,7 @@ def write_world_files(world: SynthWorld, directory: str, block_size: int = 8192)
             off += len(seq) + (len(seq) + 59) // 60
     recs = [(r.qname, names.index(c), r.pos - 1, r.cigar, r.seq) for c, rs in world.reads.items() for r in rs]
     bam = os.path.join(directory, "reads.bam")
-    bamio.write_bam(bam, [(n, len(world.contigs[n])) for n in names], recs, block_size=block_size)
+    bamio.write_bam(bam, [(n, len(world.contigs[n])) for n in names], recs, block_size=block_size, qual_seed=qual_seed)
     return fa, bam
 
 
