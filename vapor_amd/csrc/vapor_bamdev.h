@@ -7,7 +7,7 @@
 //                         input straight into the block's place in the arena (HBM), the matches of a batch copied by all 64
 //                         lanes, the block's CRC-32 taken by 64 lanes (a slice each, combined by multiplication mod P).
 //                         Thousands of blocks are independent: that is the parallelism (a single DEFLATE stream has none),
-//                         and a dozen of them share a CU so that one's table lookup waits while another's shifts.
+//                         and twenty of them share a CU so that one's table lookup waits while another's shifts.
 //   bam_chop_kernel       one wavefront per region: the BAM records of its index chunks walked in file order, the region
 //                         rule of `samtools view`, POS <= start, the CIGAR walked to the window start 64 operations a step
 //                         (cigar2alignstart_by_pos, SF:309-337; the CG:B,I long-CIGAR convention included), miss_bp and
@@ -36,8 +36,8 @@
 #define VBD_LANE0 lane == 0
 #define VBD_LANE_SLOTS 1
 // Lane 0's decoding is scalar work: what it reads from LDS is declared uniform (v_readfirstlane), so that the shifts, masks,
-// compares and branches on it go to the scalar unit - a vector instruction holds the SIMD for four clocks however few lanes
-// are on, the scalar unit takes one, and sixteen wavefronts a CU were queueing for the vector issue.
+// compares and branches on it go to the scalar unit - a vector instruction holds its SIMD for its issue slot however few lanes
+// are on, and the wavefronts of a CU were queueing for the vector issue.
 // Three flavours of the decoder (template flag SC).  Measured on 8 240 blocks of 64 KB (profiles/r05_bamdev.txt): all vector
 // 23.6 ms, all scalar 17.9 ms, scalar control over vector data 16.0 ms - the product's; -DVBD_FLAVOUR=0 / 1 (developer builds)
 // the others.
@@ -79,7 +79,7 @@ namespace vapor_bamdev {
 #endif
 constexpr int LLB = VBD_LLB, DB = 8, PREB = 7;       // first-level bits of the literal / length, distance and code-length tables
 // first + second level entries a complete code can need - the bounds zlib's `enough` finds: 286 symbols, longest code 15, 9 bits
-// first: 852 (10: 1334); 30 symbols, 8 bits: 402.  (A block is 8 KB of LDS with 9 bits: sixteen blocks in flight a CU.)
+// first: 852 (10: 1334); 30 symbols, 8 bits: 402.  (A block is 7.4 KB of LDS with 9 bits: twenty blocks in flight a CU.)
 constexpr int LL_CAP = LLB == 9 ? 852 : 1334, D_CAP = 402;
 static_assert(LLB == 9 || LLB == 10, "table bound known for 9 and 10 bits");
 constexpr uint32_t E_LIT = 1u << 13, E_EOB = 1u << 14, E_SUB = 1u << 15;
@@ -119,8 +119,10 @@ struct InflateState {     // the decoder between batches (LDS; lane 0 works on a
 
 struct InflateLds {
     uint32_t ll[LL_CAP + 2];
-    uint32_t ds[D_CAP + 2];
-    uint32_t pre[1 << PREB];
+    union {
+        uint32_t ds[D_CAP + 2];
+        uint32_t pre[1 << PREB];    // (the code-length code is done with before the distance table is built)
+    };
 #if defined(VBD_TIMING) && !defined(VBD_EMU)
     long long tm[8];                // 0 top-up, 1 decode (tables included), 2 tables, 3 matches, 4 CRC
     long long cn[8];                // 0 fast literal steps, 1 symbols of the careful loop, 2 matches, 3 batches, 4 general symbols in the fast loop, 5 fills
@@ -129,10 +131,14 @@ struct InflateLds {
         uint32_t q[2 * Q_CAP];      // per match: position | length << 16, distance (| Q_FILL)
         uint8_t sub_bits[1 << LLB]; // (table building only: a batch that reaches a block header with matches queued ends there)
     };
-    uint32_t crc_part[64];
+    union {
+        uint32_t crc_part[64];      // (the end of a block)
+        struct {                    // build_table's small arrays (dynamically indexed: registers would spill to scratch)
+            int32_t count[16];
+            uint32_t next[16], nx[16];
+        };
+    };
     InflateState st;
-    int32_t count[16];              // build_table's small arrays (dynamically indexed: registers would spill to scratch)
-    uint32_t next[16], nx[16];
     uint32_t in_w[(IN_CAP + 16) / 4];   // the LDS copy of the stream (bytes; zeros behind in_have)
     uint8_t lens[288 + 32 + 16];
     uint8_t pl[20];
@@ -616,8 +622,9 @@ VBD_DEV uint32_t crc_mulmod(uint32_t a, uint32_t b)
 // ---------------------------------------------------------------------------------------------------------------------------
 // One BGZF block by one wavefront.  `out` is where the block's data goes in the arena (HBM): lane 0 stores the literals as it
 // decodes them, the wavefront copies the matches from what it has written before, the CRC is read back from there (L2).  Only
-// the tables, the LDS copy of the stream and the match queue live in LDS - 12 KB a block, a dozen blocks in flight per CU, which
-// is what hides the latency of lane 0's lookup -> shift -> lookup chain.  crc_pow[l] = x^(8 * 1024 * (63 - l)) mod P.
+// the tables, the LDS copy of the stream and the match queue live in LDS - 7.4 KB a block, twenty blocks in flight per CU (five
+// wavefronts a SIMD: 16 -> 20 blocks a CU took 16.0 -> 12.4 ms on 8 240 blocks), which is what hides the latency of lane 0's
+// lookup -> shift -> lookup chain.  crc_pow[l] = x^(8 * 1024 * (63 - l)) mod P.
 // ---------------------------------------------------------------------------------------------------------------------------
 // the byte table of the CRC-32 (one a workgroup; the CRC is a hundredth of a block's time: slicing tables would cost LDS that
 // keeps a fourth workgroup off the CU)
@@ -782,7 +789,7 @@ VBD_DEV int inflate_block_wave(InflateLds& L, const CrcTables& T, uint8_t* out, 
 // Four wavefronts a workgroup, a BGZF block each.
 constexpr int INFLATE_WAVES = 4;
 #ifndef VBD_MIN_WAVES
-#define VBD_MIN_WAVES 4             // wavefronts per SIMD the register budget is cut for (LDS admits four workgroups of four a CU)
+#define VBD_MIN_WAVES 5             // wavefronts per SIMD the register budget is cut for (LDS admits five workgroups of four a CU)
 #endif
 __global__ __launch_bounds__(64 * INFLATE_WAVES, VBD_MIN_WAVES) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const BgzfBlk* __restrict__ blks, int n_blks,
                                                                          uint8_t* arena, const uint32_t* __restrict__ crc_pow,
