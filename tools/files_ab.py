@@ -44,5 +44,12 @@ for name, dev in (("device", "1"), ("host", "0"), ("device", "1"), ("host", "0")
         best = min(best, dt)
     res.setdefault(name, []).append((best, sha, rows))
     print("%-6s extraction: %d loci in %.3f s -> %.0f loci/s; table %s (%d rows)" % (name, n, best, n / best, sha, rows), flush=True)
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    os.environ["VAPOR_BAM_DEVICE"] = "1"
+    pr = cProfile.Profile()
+    pr.runcall(run, "p")
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(22)
 shas = {v[1] for vs in res.values() for v in vs}
 print("tables equal: %s" % (len(shas) == 1), flush=True)
