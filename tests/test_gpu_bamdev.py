@@ -244,3 +244,16 @@ def test_cli_table_is_the_same_with_reads_by_device_address(eng, tmp_path):
         os.environ.pop("VAPOR_QC_SEED", None)
         seqio.set_backend(None)
     assert tables["1"] == tables["0"] and tables["1"].count("\n") == 61 and tables["1"].count("\tNA") < 10
+
+
+def test_fuzz_of_the_device_extraction_for_a_few_seconds(tmp_path):
+    """tools/fuzz_bamdev.py (random files of every block size, zlib level and strategy, clips / insertions / deletions / N,
+    seeded and absent qualities; random regions): a short run here (VAPOR_FUZZ_SECONDS for a long one; eight minutes of it -
+    2 086 files, 385 k kept reads - are logged in profiles/r05_fuzz_bamdev.txt)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bamdev.py"), os.environ.get("VAPOR_FUZZ_SECONDS", "12"), "5"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "all equal" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
