@@ -692,7 +692,7 @@ def pipeline_rate(n_loci: int = 400, span_dist=None):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def files_rate(n_loci: int = 500):
+def files_rate(n_loci: int = 500, repeat: int = 8):
     """the same drivers from FASTA + BAM FILES through the product CLI in this process - what a `vapor bed` run
     sees - with the read extraction on the device (vapor_bam_chop_device: the regions' BGZF blocks cross the link compressed, one
     wavefront inflates a block, one walks a region's records) and, beside it, on the host's prefetch threads (vapor_bam_chop);
@@ -709,8 +709,10 @@ def files_rate(n_loci: int = 500):
         tmp = tempfile.mkdtemp(prefix="vapor_bench_files_")
         fa, bam = synth.write_world_files(w, tmp, block_size=0xFF00)
         bed = os.path.join(tmp, "in.bed")
-        open(bed, "w").write(synth.bed_text(w))
-        rec = {"unit": "loci/s", "loci": n_loci, "bam_mb": round(os.path.getsize(bam) / 1e6, 1)}
+        open(bed, "w").write(synth.bed_text(w) * repeat)        # (the file's loci `repeat` times over: a run of several chunks from a file that is written in seconds)
+        n_file = n_loci
+        n_loci *= repeat
+        rec = {"unit": "loci/s", "loci": n_loci, "distinct_loci": n_file, "bam_mb": round(os.path.getsize(bam) / 1e6, 1)}
         shas = {}
         was = os.environ.get("VAPOR_BAM_DEVICE")
         try:
@@ -732,7 +734,8 @@ def files_rate(n_loci: int = 500):
                 os.environ["VAPOR_BAM_DEVICE"] = was
         rec["tables_equal"] = shas["device"] == shas["host"]
         rec["table_sha"] = shas["device"]
-        rec["includes"] = ("cli.main bed from FASTA/.fai + BAM/.bai files (64 KB BGZF blocks, qualities 0xFF), one warm process, figures off, best of 3; "
+        rec["includes"] = ("cli.main bed from FASTA/.fai + BAM/.bai files (64 KB BGZF blocks, qualities 0xFF; the BED lists the file's loci %d times), one warm process, "
+                           "figures off, best of 3; " % repeat +
                            "value = reads by device address (vapor_bam_chop_device), host_extraction_value = the host reader on %d usable cores"
                            % len(os.sched_getaffinity(0)))
         return rec

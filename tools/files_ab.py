@@ -1,13 +1,19 @@
 """The files path (FASTA + BAM through the product CLI, in one warm process) with the read extraction on the device
 (vapor_bam_chop_device) against the host's (vapor_bam_chop on the prefetch threads): the two output tables byte for byte, and
 loci/s of each.
-  python tools/files_ab.py [n_loci] [block_size] [chunk] [--qual]      (--qual: seeded qualities instead of 0xFF)"""
+  python tools/files_ab.py [n_loci] [block_size] [chunk] [--qual] [--repeat R]      (--qual: seeded qualities instead of 0xFF)"""
 import contextlib, hashlib, io, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vapor_amd import cli, synth
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+argv = sys.argv[1:]
+rep = 1
+if "--repeat" in argv:
+    k = argv.index("--repeat")
+    rep = int(argv[k + 1])
+    del argv[k:k + 2]
+args = [a for a in argv if not a.startswith("--")]
 n = int(args[0]) if args else 2000
 block = int(args[1], 0) if len(args) > 1 else 0xFF00
 chunk = args[2] if len(args) > 2 else None
@@ -17,7 +23,8 @@ for c in w.reads:
 tmp = tempfile.mkdtemp()
 fa, bam = synth.write_world_files(w, tmp, block_size=block, qual_seed=(7 if '--qual' in sys.argv else None))
 bed = os.path.join(tmp, "in.bed")
-open(bed, "w").write(synth.bed_text(w))
+open(bed, "w").write(synth.bed_text(w) * rep)               # (--repeat R: the same loci R times over - a long run from a short file)
+n *= rep
 print("files of %d loci: %.1f MB BAM, blocks of %d, %d usable cores" % (n, os.path.getsize(bam) / 1e6, block, len(os.sched_getaffinity(0))), flush=True)
 
 

@@ -254,6 +254,11 @@ class InProcessBam(SamtoolsHybrid):
                     if "in one call" in str(err) and e - a >= 2:
                         groups[:0] = [(a, (a + e) // 2), ((a + e) // 2, e)]
                         continue
+                    if "in one call" in str(err):
+                        # one region whose blocks alone are more than a call takes: the host route's (it streams them)
+                        parts.append((np.zeros(2, dtype=np.int32), np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.int64),
+                                      np.zeros(0, dtype=np.int64), np.ones(1, dtype=np.int32)))
+                        continue
                     for bt in batches:
                         bt.close()
                     raise
