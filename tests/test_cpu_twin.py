@@ -202,3 +202,41 @@ def test_reads_by_device_address_through_the_object_layer(eng, tmp_path):
         pipeline.set_engine(None)
         seqio.set_backend(None)
     assert tables["1"] == tables["0"] and tables["1"].count("\n") == 15
+
+
+def test_device_extraction_in_groups_and_a_region_too_large_for_a_call(eng, tmp_path, monkeypatch):
+    """chop_many_device sends its regions in size-bounded groups and halves a group the library refuses for its size; a single
+    region that is refused goes to the host route (status != 0), the others keep their answers."""
+    from vapor_amd import _lib, seqio, synth
+    w = synth.make_world(seed=54, n_loci=9, svtypes=("DEL", "INS"), span_range=(100, 900), read_len=3000, n_reads=22)
+    for c in w.reads:
+        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+    fa, bam = synth.write_world_files(w, str(tmp_path), block_size=0xFF00)
+    be = seqio.InProcessBam()
+    chroms = [l.chrom for l in w.loci]
+    st = np.asarray([l.start - 200 for l in w.loci], dtype=np.int64)
+    en = st + 700
+    fl = np.full(len(chroms), 200, dtype=np.int64)
+    want = be.chop_many_device(eng, bam, chroms, st, en, fl)
+    for bt in want[5]:
+        bt.close()
+    real = eng.bam_chop_device
+    calls = []
+
+    def picky(native, tids, starts, *rest):
+        calls.append(len(tids))
+        if len(tids) > 2 or int(starts[0]) == int(st[4]):          # refuses groups of three and more, and locus 4 by itself
+            raise _lib.VaporHipError(_lib.E_ARG, "vapor_bam_chop_device: more than 2 GB of block data in one call (use smaller batches)")
+        return real(native, tids, starts, *rest)
+    monkeypatch.setattr(eng, "bam_chop_device", picky)
+    got = be.chop_many_device(eng, bam, chroms, st, en, fl)
+    for bt in got[5]:
+        bt.close()
+    assert max(calls) == 9 and calls.count(1) >= 2
+    status = got[4].tolist()
+    assert status[4] != 0 and [s for t, s in enumerate(status) if t != 4] == [0] * 8
+    n_want, n_got = np.diff(want[0]), np.diff(got[0])
+    assert n_got[4] == 0 and np.array_equal(np.delete(n_got, 4), np.delete(n_want, 4))
+    keep = np.ones(len(want[3]), dtype=bool)
+    keep[int(want[0][4]):int(want[0][5])] = False
+    assert np.array_equal(got[3], want[3][keep]) and np.array_equal(got[2], want[2][keep])
