@@ -111,7 +111,9 @@ int vapor_destroy(vapor_ctx* ctx);
  * pair order), "clean_fit" (1, the default: after a plan's first blocking run the clean workgroups' LDS copy is sized for the
  * largest record count the pairs really have instead of the estimate made at vapor_plan_create - more workgroups per CU; 0: the
  * estimate stays), "stage_threads" (host threads that copy a
- * sequence set's bytes into the pinned staging buffer, default 3).  Results do not depend on any of them. */
+ * sequence set's bytes into the pinned staging buffer, default 3), "bam_cu_share" (0 .. 8: vapor_bam_chop_device's copies and kernels
+ * go to a stream masked to that many eighths of the CUs - 0 and 8: the context's own stream, all CUs; a caller that scores several
+ * batches at once on several contexts leaves CUs to the other contexts' kernels this way).  Results do not depend on any of them. */
 int vapor_set_param(vapor_ctx* ctx, const char* name, int64_t value);
 
 /* ---- sequences: ASCII in, packed bit planes resident in HBM ------------------------------ */

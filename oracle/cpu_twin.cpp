@@ -77,6 +77,7 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     if (!strcmp(name, "reads_per_task") || !strcmp(name, "join_tasks") || !strcmp(name, "max_pair_cap"))
         return v >= 1 ? VAPOR_OK : fail(VAPOR_E_ARG, "parameter out of range");
     if (!strcmp(name, "shared_join") || !strcmp(name, "stage_threads") || !strcmp(name, "clean_order") || !strcmp(name, "clean_fit") || !strcmp(name, "remap_in_clean")) return VAPOR_OK;
+    if (!strcmp(name, "bam_cu_share")) return v >= 0 && v <= 8 ? VAPOR_OK : fail(VAPOR_E_ARG, "parameter out of range");
     return fail(VAPOR_E_ARG, std::string("unknown parameter ") + name);
 }
 extern "C" int vapor_set_stream(vapor_ctx* c, void*) { return c ? VAPOR_OK : fail(VAPOR_E_ARG, "null context"); }

@@ -496,13 +496,30 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
         with ThreadPoolExecutor(max_workers=min(in_flight, len(starts))) as pool:
             import threading
             slot = {}
+            shared = set()
             lock = threading.Lock()
 
             def work(a):
                 with lock:
                     k = slot.setdefault(threading.get_ident(), len(slot))
-                return one_chunk(a, pipeline.engine_slot(k))
-            done = list(pool.map(work, starts))
+                eng = pipeline.engine_slot(k)
+                if k not in shared and hasattr(eng, "set_param"):
+                    # several chunks at once: a chunk's read extraction on the device keeps to five eighths of the CUs, so that
+                    # the other chunks' packing / join / clean kernels do not wait behind its inflating wavefronts
+                    shared.add(k)
+                    try:
+                        eng.set_param("bam_cu_share", int(os.environ.get("VAPOR_BAM_CU_EIGHTHS", "5")))
+                    except Exception:       # noqa: BLE001 - an engine without the parameter (tests' stand-ins)
+                        pass
+                return one_chunk(a, eng)
+            try:
+                done = list(pool.map(work, starts))
+            finally:
+                for k in shared:                       # (a later run of one chunk has the device to itself)
+                    try:
+                        pipeline.engine_slot(k).set_param("bam_cu_share", 0)
+                    except Exception:       # noqa: BLE001
+                        pass
     else:
         done = [one_chunk(a) for a in starts]
     for part, todo, res in done:

@@ -109,6 +109,13 @@ struct vapor_ctx {
     // (vapor_seqset_create_mixed takes packed bases by device address: only addresses inside one of these are followed)
     uint32_t* d_crc_pow = nullptr;
     std::map<const uint8_t*, size_t> arenas;
+    // the stream the extraction's copies and kernels go to: the context's own, or (parameter bam_cu_share = s of 8) one masked to
+    // s eighths of the CUs, so that the kernels other contexts' threads launch meanwhile (packing, joins, cleaning) find CUs whose
+    // LDS is not held by twenty inflating wavefronts (cli.py sets it when it scores several chunks at once: 25.5-26.8 k -> 27.5-30.5 k
+    // loci/s from files at 5 of 8, profiles/r05_bamdev.txt)
+    hipStream_t bam_stream = nullptr;
+    int bam_stream_share = 0;                  // the share bam_stream was made for
+    int bam_cu_share = 0;
     BlockPool pool;
 };
 
@@ -351,6 +358,7 @@ extern "C" int vapor_destroy(vapor_ctx* c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_gt) (void)hipFree(c->d_gt);
     if (c->d_crc_pow) (void)hipFree(c->d_crc_pow);
+    if (c->bam_stream) (void)hipStreamDestroy(c->bam_stream);
     delete c;
     return VAPOR_OK;
 }
@@ -361,6 +369,11 @@ extern "C" int vapor_set_param(vapor_ctx* c, const char* name, int64_t v)
     if (!strcmp(name, "reads_per_task")) {
         if (v < 1 || v > MAX_READS_PER_TASK) return fail(VAPOR_E_ARG, "reads_per_task out of range");
         c->reads_per_task = (int)v;
+        return VAPOR_OK;
+    }
+    if (!strcmp(name, "bam_cu_share")) {
+        if (v < 0 || v > 8) return fail(VAPOR_E_ARG, "bam_cu_share out of range (0 .. 8 eighths of the CUs; 0 and 8: all)");
+        c->bam_cu_share = (int)(v == 8 ? 0 : v);
         return VAPOR_OK;
     }
     if (!strcmp(name, "join_tasks")) {
@@ -1084,7 +1097,22 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
             BD_CHK(hipMalloc((void**)&ctx->d_crc_pow, sizeof pw));
             BD_CHK(hipMemcpy(ctx->d_crc_pow, pw, sizeof pw, hipMemcpyHostToDevice));
         }
-        hipStream_t st = ctx->stream;
+        {
+            const char* sh = getenv("VAPOR_BAM_CU_SHARE");            // (experiments: overrides the parameter)
+            const int share = ctx->user_stream ? 0 : (sh ? atoi(sh) : ctx->bam_cu_share);
+            if (share != ctx->bam_stream_share) {
+                if (ctx->bam_stream) { (void)hipStreamSynchronize(ctx->bam_stream); (void)hipStreamDestroy(ctx->bam_stream); ctx->bam_stream = nullptr; }
+                ctx->bam_stream_share = share;
+                if (share >= 1 && share <= 7) {
+                    // (CU i of the mask's enumeration is on in s of every 8: every XCD keeps CUs of both kinds)
+                    std::vector<uint32_t> mask((size_t)(ctx->n_cus + 31) / 32, 0u);
+                    for (int i = 0; i < ctx->n_cus; ++i)
+                        if (i % 8 < share) mask[(size_t)i / 32] |= 1u << (i % 32);
+                    if (hipExtStreamCreateWithCUMask(&ctx->bam_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) ctx->bam_stream = nullptr;
+                }
+            }
+        }
+        hipStream_t st = ctx->bam_stream ? ctx->bam_stream : ctx->stream;
         tq[2] = now();
         if (stage_bytes) BD_CHK(hipMemcpyAsync(d_comp, h_comp, stage_bytes, hipMemcpyHostToDevice, st));
         if (dbg_t) { BD_CHK(hipStreamSynchronize(st)); tq[3] = now(); }

@@ -66,6 +66,16 @@ def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: in
 
 
 def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
+    import os as _os
+    import time as _time
+    _dbg = _os.environ.get("VAPOR_DEBUG_FASTPATH")
+    _t = [_time.perf_counter()]
+
+    def _mark(tag):
+        if _dbg:
+            _t.append(_time.perf_counter())
+            _marks.append((tag, _t[-1] - _t[-2]))
+    _marks = []
     from . import pipeline
     from .engine import _ASCII_OFF
     be = seqio.get_backend()
@@ -91,13 +101,41 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
     # engine do that, else by host address (ASCII)
     on_device = False
     kf = None
+    refw_of = {}                         # locus -> its reference window as text, read ahead while the device extracts the reads
     if hasattr(be, "chop_many_device") and hasattr(engine, "bam_chop_device"):
+        # The extraction is a native call that waits for the device (it releases the interpreter lock): on a helper thread, while
+        # this one reads the loci's reference windows - the text work of the loop below that does not need to know the reads.
+        # (The context is still used by one thread at a time: this one does not touch the engine until the helper is back.)
+        import threading
+        box = {}
+
+        def extract():
+            try:
+                box["got"] = be.chop_many_device(engine, bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
+            except BaseException as e:       # noqa: BLE001 - handed to the calling thread below
+                box["err"] = e
+        th = threading.Thread(target=extract)
+        th.start()
         try:
-            kf, addr, q0, miss, status, keepalive = be.chop_many_device(engine, bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
+            for t in idx.tolist():
+                sp = specs[t]
+                f, s_ = int(flank[t]), int(s0[t])
+                if int(kind[t]) == 3:
+                    m = len(sp[4])
+                    refw_of[t] = be.fetch_seq(ref, sp[1], s_ - f, s_ + f + m if m < 5000 else s_ + f)
+                else:
+                    refw_of[t] = be.fetch_seq(ref, sp[1], s_ - f, int(e0[t]) + f)
+        except Exception:                    # noqa: BLE001 - the loop below reads the window again and meets the same error where the drivers would
+            pass
+        finally:
+            th.join()
+        _mark("extract+windows")
+        if "got" in box:
+            kf, addr, q0, miss, status, keepalive = box["got"]
             held.extend(keepalive)
             on_device = True
-        except NotImplementedError:
-            kf = None
+        elif not isinstance(box.get("err"), NotImplementedError):
+            raise box["err"]
     if kf is None:
         try:
             kf, addr, q0, miss, status, keepalive = be.chop_many(bam_in, chroms, r_start[idx], r_end[idx], flank[idx])
@@ -148,7 +186,7 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
             ins = sp[4]
             m = len(ins)
             w_end = s_ + f + m if m < 5000 else s_ + f
-            refw = be.fetch_seq(ref, sp[1], s_ - f, w_end)
+            refw = refw_of[t] if t in refw_of else be.fetch_seq(ref, sp[1], s_ - f, w_end)
             if not (type(refw) is str and refw.isascii() and type(ins) is str and ins.isascii()):
                 continue
             n_x = ins.count("X")
@@ -164,7 +202,7 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
             u_alt = der([(r_i, 0, f + 1, 0), (x_i, 0, m, 0), (r_i, f, f + 1, 0)], True) if twin else alt
             loc.append((j, t, 3, r_i, alt, u_ref, u_alt, win, None, len(refw), 2 * f + 2 + m))
             continue
-        refw = be.fetch_seq(ref, sp[1], s_ - f, e_ + f)
+        refw = refw_of[t] if t in refw_of else be.fetch_seq(ref, sp[1], s_ - f, e_ + f)
         lw = len(refw)
         if not (type(refw) is str and refw.isascii()) or lw != e_ - s_ + 2 * f + 1:       # (cut by a contig end: the drivers' way)
             continue
@@ -196,6 +234,7 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
             loc.append((j, t, 2, r_i, alt, r_i, alt, r_i, alt, lw, 2 * lw - 2 * f))
     if not loc:
         return out
+    _mark("alleles")
     # reads of the live loci behind the windows: slices of the records' own sequences
     n_lit_w = len(lit_addr)
     rd_first = []
@@ -237,6 +276,7 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
     else:
         ss = engine.seqset_raw(all_addr, all_len, (np.asarray(seg_first, dtype=np.int32), segs_a, np.asarray(dflags, dtype=np.uint8)),
                                keepalive=(keep, keepalive))
+    _mark("seqset")
     try:
         n_exc, n_inv, lens = ss.n_exc, ss.n_invalid, ss.lens
         # ---- window_size_refine's first self dot plot for every window (k = 10), in one plan -------------------------------
@@ -259,6 +299,7 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
             wst = plan.run().copy()
         finally:
             plan.close()
+        _mark("window plan")
         nh, nd, nl = wst[:, L.ST_N_HITS], wst[:, L.ST_N_DIAG], wst[:, L.ST_N_LOWER]
         with np.errstate(divide="ignore", invalid="ignore"):
             frac = nl.astype(np.float64) / nh.astype(np.float64)
@@ -301,10 +342,15 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
         is_ins = np.asarray([rec[2] == 3 for rec in loc], dtype=bool)
         refuse = (rd_inv > 0) | (is_ins & (rd_exc > 0)) | (rd_max > L.MAX_SEQ_LEN) | (cnt <= 0)
         keep_sc = [(q, k) for q, k in scored if not refuse[q]]
+        _mark("refine+select")
         if keep_sc:
             sc_lists = _score(engine, ss, loc, keep_sc, rd_first, kfl, rd_miss, n_lit_w, place)
             for (q, _k), v in zip(keep_sc, sc_lists):
                 out[loc[q][1]] = v
+        _mark("score")
+        if _dbg:
+            import sys as _sys
+            print("fastpath chunk of %d: %s" % (n, "  ".join("%s %.1f" % (a, b * 1e3) for a, b in _marks)), file=_sys.stderr)
     finally:
         ss.close()
     return out
