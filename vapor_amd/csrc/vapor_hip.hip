@@ -980,20 +980,36 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
         }
         span_first[(size_t)n_regions] = (int32_t)spans.size();
         if (stage_bytes > ((size_t)3 << 29)) return fail(VAPOR_E_ARG, "vapor_bam_chop_device: more than 1.5 GB of blocks in one call (use smaller batches)");
-        vapor_bam_batch* B = new vapor_bam_batch();
+        // (what the call holds while it runs goes back to the context's pool on every way out, an exception's included; the batch
+        // survives a successful return only)
+        struct Held {
+            vapor_ctx* ctx;
+            vapor_bam_batch* B = nullptr;
+            uint8_t *h_comp = nullptr, *d_comp = nullptr, *h_meta = nullptr, *d_meta = nullptr;
+            explicit Held(vapor_ctx* c) : ctx(c) {}
+            void release_temporaries()
+            {
+                if (h_comp) hfree(ctx, h_comp);
+                if (d_comp) dfree(ctx, d_comp);
+                if (h_meta) hfree(ctx, h_meta);
+                if (d_meta) dfree(ctx, d_meta);
+                h_comp = d_comp = h_meta = d_meta = nullptr;
+            }
+            ~Held()
+            {
+                release_temporaries();
+                if (B) vapor_bam_batch_destroy(B);
+            }
+        } held(ctx);
+        held.B = new vapor_bam_batch();
+        vapor_bam_batch*& B = held.B;
         B->ctx = ctx;
         B->device = ctx->device;
-        uint8_t* h_comp = nullptr;
-        uint8_t *d_comp = nullptr, *h_meta = nullptr, *d_meta = nullptr;
-        int rc = VAPOR_OK;
-        auto cleanup = [&](int code) {
-            if (h_comp) hfree(ctx, h_comp);
-            if (d_comp) dfree(ctx, d_comp);
-            if (h_meta) hfree(ctx, h_meta);
-            if (d_meta) dfree(ctx, d_meta);
-            if (code != VAPOR_OK) { vapor_bam_batch_destroy(B); B = nullptr; }
-            return code;
-        };
+        uint8_t*& h_comp = held.h_comp;
+        uint8_t*& d_comp = held.d_comp;
+        uint8_t*& h_meta = held.h_meta;
+        uint8_t*& d_meta = held.d_meta;
+        auto cleanup = [&](int code) { return code; };      // (the destructor above does the work)
 #define BD_CHK(expr)                                                                                                  \
     do {                                                                                                              \
         hipError_t _e = (expr);                                                                                       \
@@ -1016,7 +1032,12 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
                         got += (size_t)r;
                     }
                     sp.got = got;
-                    scan_span(sp, h_comp);
+                    try {
+                        scan_span(sp, h_comp);
+                    } catch (const std::exception&) {       // (out of memory for the block list: the region goes the host route)
+                        sp.blks.clear();
+                        sp.bad = true;
+                    }
                 }
             };
             if (n_thr <= 1) {
@@ -1180,12 +1201,15 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
             }
         }
         kept_first[n_regions] = w;
-        rc = cleanup(VAPOR_OK);
+        held.release_temporaries();
         *out = B;
-        return rc;
+        held.B = nullptr;
+        return VAPOR_OK;
 #undef BD_CHK
     } catch (const std::bad_alloc&) {
         return fail(VAPOR_E_NOMEM, "vapor_bam_chop_device: out of memory");
+    } catch (const std::exception& e) {             // (no exception crosses the C boundary: a thread that could not start, ...)
+        return fail(VAPOR_E_ARG, std::string("vapor_bam_chop_device: ") + e.what());
     }
 }
 
