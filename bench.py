@@ -732,6 +732,40 @@ def files_rate(n_loci: int = 500, repeat: int = 8):
                 os.environ.pop("VAPOR_BAM_DEVICE", None)
             else:
                 os.environ["VAPOR_BAM_DEVICE"] = was
+        # the extraction by itself: every locus's region (locus +- 500) through vapor_bam_chop_device and through the host reader's
+        # chop_many; the inflate kernel's duration between two HIP events on its stream (vapor_bam_last_stats)
+        try:
+            import numpy as np
+            from vapor_amd import pipeline, seqio
+            be = seqio.InProcessBam()
+            eng = pipeline.get_engine()
+            rows = [l.split("\t") for l in synth.bed_text(w).strip().splitlines()]
+            chroms = [r[0] for r in rows]
+            st = np.asarray([max(int(r[1]) - 500, 1) for r in rows], dtype=np.int64)
+            en = np.asarray([int(r[2]) + 500 for r in rows], dtype=np.int64)
+            fl = np.full(len(rows), 500, dtype=np.int64)
+            best = {"device": 1e9, "host": 1e9}
+            kept = {}
+            stats = None
+            for _ in range(4):
+                t0 = time.perf_counter(); got = be.chop_many_device(eng, bam, chroms, st, en, fl); dt = time.perf_counter() - t0
+                for bt in got[5]:
+                    bt.close()
+                kept["device"] = (got[0].tolist(), got[3].tolist())
+                if dt < best["device"]:
+                    best["device"], stats = dt, eng.bam_last_stats()
+                t0 = time.perf_counter(); got = be.chop_many(bam, chroms, st, en, fl); best["host"] = min(best["host"], time.perf_counter() - t0)
+                kept["host"] = (got[0].tolist(), got[3].tolist())
+            rec["extraction_alone"] = {
+                "device_loci_per_s": round(len(rows) / best["device"], 1), "host_loci_per_s": round(len(rows) / best["host"], 1),
+                "kept_reads_and_miss_bp_equal": kept["device"] == kept["host"], "blocks": stats["blocks"],
+                "compressed_mb": round(stats["compressed_bytes"] / 1e6, 1), "inflated_mb": round(stats["inflated_bytes"] / 1e6, 1),
+                "inflate_kernel_ms": round(stats["inflate_ms"], 3),
+                "inflate_gb_per_s": round(stats["inflated_bytes"] / 1e9 / (stats["inflate_ms"] / 1e3), 1) if stats["inflate_ms"] > 0 else None,
+                "note": "bgzf_inflate_kernel: one BGZF block per wavefront, twenty in flight per CU; bound by dependent table lookups of single "
+                        "lanes, not by bytes (DESIGN.md 4.5) - no roofline fraction is claimed for it"}
+        except Exception as e:      # noqa: BLE001
+            rec["extraction_alone"] = {"error": "%s: %s" % (type(e).__name__, e)}
         rec["tables_equal"] = shas["device"] == shas["host"]
         rec["table_sha"] = shas["device"]
         rec["includes"] = ("cli.main bed from FASTA/.fai + BAM/.bai files (64 KB BGZF blocks, qualities 0xFF; the BED lists the file's loci %d times), one warm process, "

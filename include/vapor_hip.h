@@ -314,6 +314,9 @@ int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_regions, con
                           int32_t max_keep, int32_t* kept_first, uint64_t* sq_addr, int64_t* q0, int64_t* miss, int32_t* status,
                           vapor_bam_batch** batch);
 int vapor_bam_batch_destroy(vapor_bam_batch* batch);
+/* what the context's last vapor_bam_chop_device did, for measurement (bench.py): out[0..5] = regions, BGZF blocks, compressed bytes
+ * sent over the link, inflated bytes, the inflate kernel's duration between two events on its stream (ms), the whole call (ms) */
+int vapor_bam_last_stats(vapor_ctx* ctx, double* out, int32_t n);
 /* the descriptor and the inflate-thread count of an open file (vapor_bam_chop_device reads with them) */
 int vapor_bam_fileno(vapor_bam* bam);
 int vapor_bam_threads(vapor_bam* bam);

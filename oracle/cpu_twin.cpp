@@ -668,6 +668,12 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
     return VAPOR_OK;
 }
 extern "C" int vapor_bam_batch_destroy(vapor_bam_batch* b) { delete b; return VAPOR_OK; }
+extern "C" int vapor_bam_last_stats(vapor_ctx* ctx, double* out, int32_t n)
+{
+    if (!ctx || !out || n < 0) return fail(VAPOR_E_ARG, "vapor_bam_last_stats: null argument");
+    for (int32_t i = 0; i < n && i < 6; ++i) out[i] = 0.;          // (no device, nothing measured)
+    return VAPOR_OK;
+}
 
 extern "C" int vapor_seqset_create_mixed(vapor_ctx* ctx, int32_t n, const uint8_t* const* seq, const int32_t* len, const uint8_t* flags,
                                          const uint8_t* src_kind, const int64_t* src_first, int32_t n_derived, const int32_t* seg_first,

@@ -46,7 +46,7 @@ EXPORTS = [
     "vapor_cigar2alignstart", "vapor_cigar2alignstart_ops",
     "vapor_bam_open", "vapor_bam_close", "vapor_bam_set_threads", "vapor_bam_last_error", "vapor_bam_chop",
     "vapor_inflate_raw", "vapor_chop_records", "vapor_chop_records_many", "vapor_row_tails", "vapor_crc32",
-    "vapor_bam_chop_device", "vapor_bam_batch_destroy", "vapor_bam_fileno", "vapor_bam_threads", "vapor_seqset_create_mixed",
+    "vapor_bam_chop_device", "vapor_bam_batch_destroy", "vapor_bam_fileno", "vapor_bam_threads", "vapor_seqset_create_mixed", "vapor_bam_last_stats",
 ]
 
 _lib = None
@@ -174,6 +174,7 @@ def bind(L: ctypes.CDLL) -> ctypes.CDLL:
                                  vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), vp]
     L.vapor_bam_chop_device.argtypes = [vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.POINTER(vp)]
     L.vapor_bam_batch_destroy.argtypes = [vp]
+    L.vapor_bam_last_stats.argtypes = [vp, vp, ctypes.c_int32]
     L.vapor_bam_fileno.argtypes = [vp]
     L.vapor_bam_threads.argtypes = [vp]
     L.vapor_seqset_create_mixed.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, ctypes.POINTER(vp)]

@@ -116,6 +116,8 @@ struct vapor_ctx {
     hipStream_t bam_stream = nullptr;
     int bam_stream_share = 0;                  // the share bam_stream was made for
     int bam_cu_share = 0;
+    hipEvent_t bam_ev[2] = {nullptr, nullptr}; // around the inflate launch of the last vapor_bam_chop_device (vapor_bam_last_stats)
+    double bam_stats[6] = {0, 0, 0, 0, 0, 0};  // regions, blocks, compressed bytes, inflated bytes, inflate ms, whole call ms
     BlockPool pool;
 };
 
@@ -359,6 +361,8 @@ extern "C" int vapor_destroy(vapor_ctx* c)
     if (c->d_gt) (void)hipFree(c->d_gt);
     if (c->d_crc_pow) (void)hipFree(c->d_crc_pow);
     if (c->bam_stream) (void)hipStreamDestroy(c->bam_stream);
+    for (hipEvent_t e : c->bam_ev)
+        if (e) (void)hipEventDestroy(e);
     delete c;
     return VAPOR_OK;
 }
@@ -1138,11 +1142,14 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
         if (stage_bytes) BD_CHK(hipMemcpyAsync(d_comp, h_comp, stage_bytes, hipMemcpyHostToDevice, st));
         if (dbg_t) { BD_CHK(hipStreamSynchronize(st)); tq[3] = now(); }
         BD_CHK(hipMemcpyAsync(d_meta, h_meta, in_bytes, hipMemcpyHostToDevice, st));
+        if (!ctx->bam_ev[0]) { BD_CHK(hipEventCreate(&ctx->bam_ev[0])); BD_CHK(hipEventCreate(&ctx->bam_ev[1])); }
+        BD_CHK(hipEventRecord(ctx->bam_ev[0], st));
         if (n_blks) {
             hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n_blks + INFLATE_WAVES - 1) / INFLATE_WAVES)), dim3(64 * INFLATE_WAVES), 0, st, d_comp, reinterpret_cast<const BgzfBlk*>(d_meta + o_blk),
                                (int)n_blks, B->d_arena, ctx->d_crc_pow, reinterpret_cast<int32_t*>(d_meta + o_bst));
             BD_CHK(hipGetLastError());
         }
+        BD_CHK(hipEventRecord(ctx->bam_ev[1], st));
         if (dbg_t) { BD_CHK(hipStreamSynchronize(st)); tq[4] = now(); }
         if (n_regions) {
             hipLaunchKernelGGL(bam_chop_kernel, dim3((unsigned)n_regions), dim3(64), 0, st, B->d_arena, reinterpret_cast<const BamRegion*>(d_meta + o_reg),
@@ -1154,6 +1161,12 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
         BD_CHK(hipMemcpyAsync(h_meta + o_bst, d_meta + o_bst, meta_bytes - o_bst, hipMemcpyDeviceToHost, st));
         BD_CHK(hipStreamSynchronize(st));
         tq[5] = now();
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->bam_ev[0], ctx->bam_ev[1]) != hipSuccess) ms = 0.f;
+            ctx->bam_stats[0] = n_regions; ctx->bam_stats[1] = (double)n_blks; ctx->bam_stats[2] = (double)stage_bytes;
+            ctx->bam_stats[3] = (double)arena; ctx->bam_stats[4] = ms; ctx->bam_stats[5] = tq[5] - tq[0];
+        }
         if (dbg_t)
             fprintf(stderr, "bam_chop_device: %d regions, %zu blocks, %.1f MB compressed -> %.1f MB; read+scan %.2f  layout+alloc %.2f  h2d %.2f  inflate %.2f  chop+d2h %.2f ms\n",
                     n_regions, n_blks, stage_bytes / 1e6, arena / 1e6, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
@@ -1211,6 +1224,15 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
     } catch (const std::exception& e) {             // (no exception crosses the C boundary: a thread that could not start, ...)
         return fail(VAPOR_E_ARG, std::string("vapor_bam_chop_device: ") + e.what());
     }
+}
+
+// what the context's last vapor_bam_chop_device did: regions, blocks, compressed bytes sent, inflated bytes, the inflate kernel's
+// duration between two events on its stream (ms), the whole call on the host's clock (ms)
+extern "C" int vapor_bam_last_stats(vapor_ctx* ctx, double* out, int32_t n)
+{
+    if (!ctx || !out || n < 0) return fail(VAPOR_E_ARG, "vapor_bam_last_stats: null argument");
+    for (int32_t i = 0; i < n && i < 6; ++i) out[i] = ctx->bam_stats[i];
+    return VAPOR_OK;
 }
 
 // vapor_seqset_create_derived with sequences whose bases are on the device already (vapor_bam_chop_device's reads): src_kind[i] = 1

@@ -366,6 +366,13 @@ class Engine:
         w = int(kept_first[n])
         return kept_first, addr[:w], q0[:w], miss[:w], status[:n], BamBatch(h)
 
+    def bam_last_stats(self) -> dict:
+        """What this engine's last bam_chop_device did (vapor_bam_last_stats)."""
+        out = np.zeros(6, dtype=np.float64)
+        L.check(L.load().vapor_bam_last_stats(self._ctx, out.ctypes.data_as(ctypes.c_void_p), 6))
+        return {"regions": int(out[0]), "blocks": int(out[1]), "compressed_bytes": int(out[2]), "inflated_bytes": int(out[3]),
+                "inflate_ms": float(out[4]), "call_ms": float(out[5])}
+
     def seqset_raw(self, addr: np.ndarray, lens: np.ndarray, derived=None, keepalive=None, src_kind=None, src_first=None) -> SeqSet:
         """A set from (address, length) pairs - slices of strings the caller keeps alive - and derived sequences as arrays."""
         return SeqSet.from_addresses(self, addr, lens, derived, keepalive, src_kind, src_first)
