@@ -692,6 +692,14 @@ def pipeline_rate(n_loci: int = 400, span_dist=None):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def _quota_cores() -> int:
+    try:
+        from vapor_amd import pipeline
+        return int(pipeline._usable_cores())
+    except Exception:       # noqa: BLE001
+        return len(os.sched_getaffinity(0))
+
+
 def files_rate(n_loci: int = 500, repeat: int = 8):
     """the same drivers from FASTA + BAM FILES through the product CLI in this process - what a `vapor bed` run
     sees - with the read extraction on the device (vapor_bam_chop_device: the regions' BGZF blocks cross the link compressed, one
@@ -770,8 +778,8 @@ def files_rate(n_loci: int = 500, repeat: int = 8):
         rec["table_sha"] = shas["device"]
         rec["includes"] = ("cli.main bed from FASTA/.fai + BAM/.bai files (64 KB BGZF blocks, qualities 0xFF; the BED lists the file's loci %d times), one warm process, "
                            "figures off, best of 3; " % repeat +
-                           "value = reads by device address (vapor_bam_chop_device), host_extraction_value = the host reader on %d usable cores"
-                           % len(os.sched_getaffinity(0)))
+                           "value = reads by device address (vapor_bam_chop_device), host_extraction_value = the host reader on the %d cores of this job's CPU quota"
+                           % _quota_cores())
         return rec
     except Exception as e:      # noqa: BLE001 - a side record must not take the headline down
         return {"error": "%s: %s" % (type(e).__name__, e)}
