@@ -257,3 +257,25 @@ def test_fuzz_of_the_device_extraction_for_a_few_seconds(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_bamdev.py"), os.environ.get("VAPOR_FUZZ_SECONDS", "12"), "5"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "all equal" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_extraction_on_a_stream_masked_to_a_share_of_the_cus(eng, tmp_path):
+    """`bam_cu_share` (what cli.py sets while several chunks are scored at once): the same kept reads from a stream masked to five,
+    one and seven eighths of the CUs as from the context's own; the parameter's range; vapor_bam_last_stats says what the call did."""
+    w = synth.make_world(seed=65, n_loci=24, svtypes=("DEL", "INS"), span_range=(100, 1500), read_len=6000, n_reads=22)
+    for c in w.reads:
+        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+    fa, bam = synth.write_world_files(w, str(tmp_path), block_size=0xFF00)
+    regions = [(l.chrom, max(l.start - 300, 1), l.start + 700, 300) for l in w.loci]
+    try:
+        for share in (0, 5, 1, 7, 8):
+            eng.set_param("bam_cu_share", share)
+            status, n = compare(eng, bam, regions)
+            assert status.tolist() == [0] * len(regions) and n > 200, share
+            st = eng.bam_last_stats()
+            assert st["regions"] == len(regions) and st["blocks"] > 20 and st["inflated_bytes"] > st["compressed_bytes"] > 0 and st["inflate_ms"] > 0
+        for bad in (-1, 9):
+            with pytest.raises(L.VaporHipError):
+                eng.set_param("bam_cu_share", bad)
+    finally:
+        eng.set_param("bam_cu_share", 0)
