@@ -358,6 +358,8 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
 
 def _score(engine, ss, loc, scored, rd_first, kfl, rd_miss, n_lit_w, place):
     """One plan for every scored locus: the pair and read tables of pipeline.score_requests, from arrays."""
+    import time as _time
+    _ts = _time.perf_counter()
     i32 = np.int32
     # vapor_read.kind: deletion = abs_dis + within_10Perc, inversion / insertion abs_dis, duplication directed
     kinds = np.asarray([0, 1, 3, 1], dtype=np.int64)
@@ -421,10 +423,17 @@ def _score(engine, ss, loc, scored, rd_first, kfl, rd_miss, n_lit_w, place):
     table["locus"] = rd_rq.astype(i32)
     table["len_ref"] = np.asarray(rq_lref, dtype=i32)[rd_rq]
     table["len_alt"] = np.asarray(rq_lalt, dtype=i32)[rd_rq]
+    import os as _os
+    import time as _time
+    _dbg = _os.environ.get("VAPOR_DEBUG_FASTPATH")
+    _t0 = _time.perf_counter()
     plan = engine.plan(ss, pairs)
     try:
+        _t1 = _time.perf_counter()
         plan.set_reads(table, len(scored))
+        _t2 = _time.perf_counter()
         plan.run_loci(want_host=False, want_scores=True)
+        _t3 = _time.perf_counter()
         sc = plan.read_scores[:n_reads_tot].tolist()
     finally:
         plan.close()
@@ -433,4 +442,8 @@ def _score(engine, ss, loc, scored, rd_first, kfl, rd_miss, n_lit_w, place):
         a = int(rq_first[x])
         # (a read whose scorer output holds a 0 is skipped, e.g. SF:1913: NaN here)
         out.append([v for v in sc[a:a + rq_n[x]] if v == v])
+    if _dbg:
+        import sys as _sys
+        print("  _score of %d loci, %d pairs: tables %.1f  plan %.1f  set_reads %.1f  run_loci %.1f  lists %.1f ms" % (
+            len(scored), len(pairs), (_t0 - _ts) * 1e3, (_t1 - _t0) * 1e3, (_t2 - _t1) * 1e3, (_t3 - _t2) * 1e3, (_time.perf_counter() - _t3) * 1e3), file=_sys.stderr)
     return out
