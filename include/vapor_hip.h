@@ -323,8 +323,7 @@ int vapor_bam_threads(vapor_bam* bam);
 /*
  * vapor_seqset_create_derived for a set some of whose sequences are on the device already: src_kind[i] = 1 says seq[i] is the
  * DEVICE address of BAM-packed bases (4 bits a base, "=ACMGRSVTWYHKDBN", the first base of a byte in its high half) inside the
- * data of a live vapor_bam_batch of this process (of any context on the same device: the reads of the next batch of loci may be
- * extracted on one context while another scores the current one; vapor_bam_batch_destroy on the thread of the batch's own context), and the sequence is the len[i] bases from base src_first[i] on; src_kind[i] = 0
+ * data of a live vapor_bam_batch of this context, and the sequence is the len[i] bases from base src_first[i] on; src_kind[i] = 0
  * (or src_kind == NULL): bytes on the host, as vapor_seqset_create_derived takes them.  Only the host bytes cross the link.
  * VAPOR_E_ARG for a device source that does not lie inside a live batch.
  */

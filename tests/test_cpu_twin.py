@@ -204,45 +204,6 @@ def test_reads_by_device_address_through_the_object_layer(eng, tmp_path):
     assert tables["1"] == tables["0"] and tables["1"].count("\n") == 15
 
 
-def test_reads_extracted_ahead_of_the_chunks_that_score_them(eng, tmp_path):
-    """Several chunks: the CLI asks the extraction service (its own thread and context) for the chunks' reads ahead of their
-    scoring (fastpath.prefetch, seqio.InProcessBam.extract_ahead); the table is the one the host extraction gives, chunk by chunk
-    and with the chunks in flight at once, and every extracted chunk is handed back (the service ends with nothing alive)."""
-    from vapor_amd import cli, pipeline, seqio, synth
-    w = synth.make_world(seed=55, n_loci=36, svtypes=("DEL", "INS", "INV", "DEL"), span_range=(80, 1200), read_len=4200, n_reads=22)
-    for c in w.reads:
-        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
-    fa, bam = synth.write_world_files(w, str(tmp_path), block_size=0xFF00)
-    pipeline.set_engine(eng)
-    seqio.set_backend(seqio.InProcessBam())
-    bed = tmp_path / "in.bed"
-    bed.write_text(synth.bed_text(w))
-    asked = []
-    real = seqio.InProcessBam.extract_ahead
-
-    def counting(self, *a, **k):
-        fut = real(self, *a, **k)                          # (NotImplementedError with VAPOR_BAM_DEVICE=0: not counted)
-        asked.append(len(a[1]))
-        return fut
-    seqio.InProcessBam.extract_ahead = counting
-    tables = {}
-    try:
-        for tag, dev, flight in (("ahead3", "1", "3"), ("ahead1", "1", "1"), ("host", "0", "3")):
-            out = tmp_path / ("out_%s.vapor" % tag)
-            os.environ.update(VAPOR_BAM_DEVICE=dev, VAPOR_QC_SEED="7", VAPOR_CHUNKS_IN_FLIGHT=flight)
-            assert cli.main(["bed", "--sv-input", str(bed), "--reference", fa, "--pacbio-input", bam, "--chunk", "12",
-                             "--output-path", str(tmp_path / "figs"), "--output-file", str(out), "--no-figures"]) == 0
-            tables[tag] = out.read_text()
-    finally:
-        seqio.InProcessBam.extract_ahead = real
-        for k in ("VAPOR_BAM_DEVICE", "VAPOR_QC_SEED", "VAPOR_CHUNKS_IN_FLIGHT"):
-            os.environ.pop(k, None)
-        pipeline.set_engine(None)
-        seqio.set_backend(None)
-    assert tables["ahead3"] == tables["host"] == tables["ahead1"] and tables["host"].count("\n") == 37
-    assert len(asked) == 6 and sum(asked) >= 30            # (three chunks of twelve loci, asked for in both device runs)
-
-
 def test_device_extraction_in_groups_and_a_region_too_large_for_a_call(eng, tmp_path, monkeypatch):
     """chop_many_device sends its regions in size-bounded groups and halves a group the library refuses for its size; a single
     region that is refused goes to the host route (status != 0), the others keep their answers."""

@@ -452,56 +452,24 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
     mine = vdist.my_share(len(jobs), costs)
     local: dict = {}
 
-    fast = figure_fn is None and os.environ.get("VAPOR_FAST_PATH", "1") != "0"
-    ahead_of: dict = {}                  # (chunk start, context of the loci) -> the read extraction asked for ahead of the chunk's scoring
-    ahead_state = {"next": 0, "starts": [], "share": 0}
-    import threading as _threading
-    ahead_lock = _threading.Lock()
-
-    def groups(a):
-        """The loci of the chunk at `a` the array route may take, by the context they are scored in (bam, reference, read cut-off)."""
-        by_ctx = {}
-        for t in mine[a:a + chunk]:
-            j = jobs[t]
-            if j.make is not None and j.spec is not None and j.ctx is not None:
-                by_ctx.setdefault(j.ctx, []).append(t)
-        return by_ctx
-
-    def ask_ahead(count=1):
-        """The read extraction of the next `count` chunks nobody has asked for yet, on the backend's extraction service (its own
-        thread and device context; fastpath.prefetch): a chunk's scoring thread then finds the reads extracted while the chunks
-        before it were being scored."""
-        if not fast:
-            return
-        from . import fastpath, seqio
-        for _ in range(count):
-            with ahead_lock:
-                k = ahead_state["next"]
-                if k >= len(ahead_state["starts"]):
-                    return
-                ahead_state["next"] = k + 1
-            a = ahead_state["starts"][k]
-            eng = pipeline.get_engine()
-            for ctx, ts in groups(a).items():
-                if len(ts) >= 8 and fastpath.capable(seqio.get_backend(), ctx[1], eng):
-                    h = fastpath.prefetch(eng, [jobs[t].spec for t in ts], ctx[1], cu_share=ahead_state["share"])
-                    if h is not None:
-                        ahead_of[(a, ctx)] = h
-
     def one_chunk(a, engine=None):
         part = mine[a:a + chunk]
         todo = [t for t in part if jobs[t].make is not None]
         done = {}
-        if fast:
+        if figure_fn is None and os.environ.get("VAPOR_FAST_PATH", "1") != "0":
             # the simple types of the chunk in array form (vapor_amd.fastpath); what leaves the drivers' straight route comes
             # back unanswered and goes the generators' way below - as everything does when figures are drawn (they need the
             # best read as text)
             from . import fastpath, seqio
-            ask_ahead(1)                                   # (the service extracts in the order asked: this chunk's successor next)
-            for ctx, ts in groups(a).items():
+            by_ctx = {}
+            for t in todo:
+                j = jobs[t]
+                if j.spec is not None and j.ctx is not None:
+                    by_ctx.setdefault(j.ctx, []).append(t)
+            for ctx, ts in by_ctx.items():
                 eng = engine or pipeline.get_engine()
                 if len(ts) >= 8 and fastpath.capable(seqio.get_backend(), ctx[1], eng):
-                    got = fastpath.run(eng, [jobs[t].spec for t in ts], ctx[1], ctx[2], ctx[0], ahead=ahead_of.pop((a, ctx), None))
+                    got = fastpath.run(eng, [jobs[t].spec for t in ts], ctx[1], ctx[2], ctx[0])
                     for t, r in zip(ts, got):
                         if r is not fastpath.FALLBACK:
                             done[t] = r
@@ -519,10 +487,6 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
         # chunk's work (read selection, upload, planning, kernels) runs beside the others' Python
         chunk = -(-len(mine) // (min(in_flight, 3) if len(mine) >= 1536 else 2))
     starts = list(range(0, len(mine), max(chunk, 1)))
-    ahead_state["starts"] = starts
-    ahead_state["share"] = int(os.environ.get("VAPOR_BAM_CU_EIGHTHS", "5")) if len(starts) >= 2 else 0
-    if len(starts) >= 2 and os.environ.get("VAPOR_BAM_AHEAD", "3") != "0":
-        ask_ahead(min(in_flight, len(starts)))                # (the first chunks' reads: asked for now, extracted one after the other)
     if len(starts) >= 2 and in_flight >= 2:
         # Two chunks in flight (the reference's loop over loci, vapor_vali/vapor:334-367, has no such stage): each on a thread
         # with a library context of its own (one host thread per context), so that the host preparation of one chunk - allele
@@ -558,14 +522,6 @@ def _score_jobs(jobs, chunk, figure_fn, t0):
                         pass
     else:
         done = [one_chunk(a) for a in starts]
-    for h in list(ahead_of.values()):                        # (asked for and not taken up: a chunk that went another way)
-        try:
-            from . import seqio
-            if h.future is not None:
-                seqio.get_backend().extract_done(h.future.result(timeout=900)[5])
-        except Exception:       # noqa: BLE001
-            pass
-    ahead_of.clear()
     for part, todo, res in done:
         for t, r in zip(todo, res):
             local[t] = r

@@ -67,11 +67,6 @@ struct BlockPool {
 };
 static std::mutex g_live_m;
 static std::set<const void*> g_live_ctx;
-// The arenas of the vapor_bam_batch objects that are alive, of every context of the process (vapor_seqset_create_mixed takes packed
-// bases by device address: only addresses inside one of these are followed).  Process-wide: a caller may extract the reads of the
-// next batch of loci on one context (one thread) while another context scores the current one - the addresses are good on any.
-static std::mutex g_arena_m;
-static std::map<const uint8_t*, size_t> g_arenas;
 
 static size_t pool_round(size_t bytes)
 {
@@ -110,8 +105,10 @@ struct vapor_ctx {
     int stage_threads = 3;                     // host threads that copy a large upload into the pinned staging buffer (measured:
                                                // two to four are as fast as it gets, more are slower - tools/upload_sweep.py)
     bool attrs_set = false;
-    // vapor_bam_chop_device: the CRC combination constants on the device
+    // vapor_bam_chop_device: the CRC combination constants on the device, and the arenas of the batches that are alive
+    // (vapor_seqset_create_mixed takes packed bases by device address: only addresses inside one of these are followed)
     uint32_t* d_crc_pow = nullptr;
+    std::map<const uint8_t*, size_t> arenas;
     // the stream the extraction's copies and kernels go to: the context's own, or (parameter bam_cu_share = s of 8) one masked to
     // s eighths of the CUs, so that the kernels other contexts' threads launch meanwhile (packing, joins, cleaning) find CUs whose
     // LDS is not held by twenty inflating wavefronts (cli.py sets it when it scores several chunks at once: 25.5-26.8 k -> 27.5-30.5 k
@@ -846,8 +843,8 @@ extern "C" int vapor_bam_batch_destroy(vapor_bam_batch* b)
         if (b->ctx && ctx_alive(b->ctx)) {
             // (kernels that read the arena - bam_expand_kernel of a set made from it - are on the context's stream)
             (void)hipStreamSynchronize(b->ctx->stream);
+            b->ctx->arenas.erase(b->d_arena);
         }
-        { std::lock_guard<std::mutex> g(g_arena_m); g_arenas.erase(b->d_arena); }
         dfree(b->ctx, b->d_arena);
     }
     delete b;
@@ -1104,7 +1101,7 @@ extern "C" int vapor_bam_chop_device(vapor_ctx* ctx, vapor_bam* bam, int32_t n_r
         BD_CHK(dmalloc(ctx, (void**)&d_comp, std::max<size_t>(stage_bytes, 64)));
         BD_CHK(dmalloc(ctx, (void**)&B->d_arena, arena + 64));
         B->arena_bytes = arena + 64;
-        { std::lock_guard<std::mutex> g(g_arena_m); g_arenas[B->d_arena] = B->arena_bytes; }
+        ctx->arenas[B->d_arena] = B->arena_bytes;
         if (n_blks) memcpy(h_meta + o_blk, blks.data(), sizeof(BgzfBlk) * n_blks);
         if (!dspans.empty()) memcpy(h_meta + o_span, dspans.data(), sizeof(BamSpan) * dspans.size());
         memcpy(h_meta + o_reg, regs.data(), sizeof(BamRegion) * regs.size());
@@ -1261,9 +1258,8 @@ extern "C" int vapor_seqset_create_mixed(vapor_ctx* ctx, int32_t n_seqs, const u
         // the bytes that will be read must lie inside the arena of a batch that is alive
         const uint8_t* a = seq[i] + (src_first[i] >> 1);
         const uint8_t* b = seq[i] + ((src_first[i] + len[i] - 1) >> 1);
-        std::lock_guard<std::mutex> g(g_arena_m);
-        auto it = g_arenas.upper_bound(a);
-        if (it == g_arenas.begin()) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: a device source outside every live batch");
+        auto it = ctx->arenas.upper_bound(a);
+        if (it == ctx->arenas.begin()) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: a device source outside every live batch");
         --it;
         if (b >= it->first + it->second) return fail(VAPOR_E_ARG, "vapor_seqset_create_mixed: a device source outside every live batch");
     }

@@ -54,71 +54,18 @@ def capable(backend, bam_in, engine=None) -> bool:
             and (engine is None or hasattr(engine, "seqset_raw")))
 
 
-def _regions(specs):
-    """What every driver hands to chop_pacbio_read_by_pos for its locus, for all loci of a chunk: (kind, s0, e0, flank, r_start,
-    r_end, idx = the loci the array route can take, their contig names)."""
-    n = len(specs)
-    kind = np.fromiter((_KIND.get(sp[0], -1) for sp in specs), dtype=np.int64, count=n)
-    s0 = np.fromiter((int(sp[2]) for sp in specs), dtype=np.int64, count=n)
-    e0 = np.fromiter((int(sp[3]) if sp[0] != "INS" else int(sp[2]) + len(sp[4]) for sp in specs), dtype=np.int64, count=n)
-    ilen = np.fromiter((len(sp[4]) if sp[0] == "INS" else 0 for sp in specs), dtype=np.int64, count=n)
-    span = e0 - s0
-    flank = np.where(kind == 3, np.minimum(ilen, 500), np.where(span < 500, span, 500))       # SF:794-802, 1862
-    ok = (kind >= 0) & (span >= 1) & (flank >= 1) & ((kind == 3) | (span < DEFAULT_MAX_SV_TEST)) & (s0 - flank >= 1)
-    # ---- reads: the region every driver hands to chop_pacbio_read_by_pos --------------------------------------------------
-    r_start = s0 - flank
-    r_end = np.where(kind == 0, s0 + flank, np.where(kind == 2, s0 + 2 * span + flank, e0 + flank))
-    idx = np.flatnonzero(ok)
-    chroms = [specs[t][1] for t in idx.tolist()]
-    return kind, s0, e0, flank, r_start, r_end, idx, chroms
-
-
-class Ahead:
-    """The read extraction of a chunk asked for before its scoring begins (prefetch): the regions and the future of the reads."""
-
-    def __init__(self, regs, future):
-        self.regs, self.future = regs, future
-
-
-def prefetch(engine, specs: Sequence[tuple], bam_in: str, cu_share: int = 0):
-    """Asks the backend's extraction service for the reads of this chunk now (None where there is none: another backend, an engine
-    without the device reader, VAPOR_BAM_AHEAD=0); `run(..., ahead=)` takes them up."""
-    be = seqio.get_backend()
-    if not (hasattr(be, "extract_ahead") and hasattr(engine, "bam_chop_device")) or len(specs) == 0:
-        return None
-    regs = _regions(specs)
-    flank, r_start, r_end, idx, chroms = regs[3], regs[4], regs[5], regs[6], regs[7]
-    if len(idx) == 0:
-        return None
-    try:
-        return Ahead(regs, be.extract_ahead(bam_in, chroms, r_start[idx], r_end[idx], flank[idx], cu_share=cu_share))
-    except NotImplementedError:
-        return None
-
-
-def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: int, ahead=None) -> List[object]:
+def run(engine, specs: Sequence[tuple], bam_in: str, ref: str, num_reads_cff: int) -> List[object]:
     """specs: (type, chrom, start, end, ins_seq) per locus (`end` unused for INS, `start` its position).  Returns per locus the
-    list of read scores the driver would return, or FALLBACK.  `ahead`: what prefetch() returned for these specs."""
-    held: list = []                       # device batches of the read selection: closed on every way out
+    list of read scores the driver would return, or FALLBACK."""
+    held: list = []                       # device batches of the read selection: closed on this thread on every way out
     try:
-        return _run(engine, specs, bam_in, ref, num_reads_cff, held, ahead)
+        return _run(engine, specs, bam_in, ref, num_reads_cff, held)
     finally:
-        if ahead is not None:
-            # (extracted on the service's thread and context: closed there; the service then begins the next chunk's)
-            if ahead.future is not None:                  # (not handed back yet: a way out before the sequence set was made)
-                if not held:
-                    try:
-                        held.extend(ahead.future.result(timeout=900)[5])
-                    except Exception:       # noqa: BLE001
-                        pass
-                ahead.future = None
-                seqio.get_backend().extract_done(held)
-        else:
-            for bt in held:
-                bt.close()
+        for bt in held:
+            bt.close()
 
 
-def _run(engine, specs, bam_in, ref, num_reads_cff, held, ahead=None) -> List[object]:
+def _run(engine, specs, bam_in, ref, num_reads_cff, held) -> List[object]:
     import os as _os
     import time as _time
     _dbg = _os.environ.get("VAPOR_DEBUG_FASTPATH")
@@ -136,35 +83,26 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held, ahead=None) -> List[ob
     out: List[object] = [FALLBACK] * n
     if n == 0 or not (0 < _ASCII_OFF < 256):
         return out
-    kind, s0, e0, flank, r_start, r_end, idx, chroms = ahead.regs if ahead is not None else _regions(specs)
+    kind = np.fromiter((_KIND.get(sp[0], -1) for sp in specs), dtype=np.int64, count=n)
+    s0 = np.fromiter((int(sp[2]) for sp in specs), dtype=np.int64, count=n)
+    e0 = np.fromiter((int(sp[3]) if sp[0] != "INS" else int(sp[2]) + len(sp[4]) for sp in specs), dtype=np.int64, count=n)
+    ilen = np.fromiter((len(sp[4]) if sp[0] == "INS" else 0 for sp in specs), dtype=np.int64, count=n)
+    span = e0 - s0
+    flank = np.where(kind == 3, np.minimum(ilen, 500), np.where(span < 500, span, 500))       # SF:794-802, 1862
+    ok = (kind >= 0) & (span >= 1) & (flank >= 1) & ((kind == 3) | (span < DEFAULT_MAX_SV_TEST)) & (s0 - flank >= 1)
+    # ---- reads: the region every driver hands to chop_pacbio_read_by_pos --------------------------------------------------
+    r_start = s0 - flank
+    r_end = np.where(kind == 0, s0 + flank, np.where(kind == 2, s0 + 2 * span + flank, e0 + flank))
+    idx = np.flatnonzero(ok)
     if len(idx) == 0:
         return out
+    chroms = [specs[t][1] for t in idx.tolist()]
     # reads by device address (4-bit bases in the inflated blocks of a vapor_bam_chop_device batch) where the backend and the
     # engine do that, else by host address (ASCII)
     on_device = False
     kf = None
     refw_of = {}                         # locus -> its reference window as text, read ahead while the device extracts the reads
-
-    def read_windows():
-        try:
-            for t in idx.tolist():
-                sp = specs[t]
-                f, s_ = int(flank[t]), int(s0[t])
-                if int(kind[t]) == 3:
-                    m = len(sp[4])
-                    refw_of[t] = be.fetch_seq(ref, sp[1], s_ - f, s_ + f + m if m < 5000 else s_ + f)
-                else:
-                    refw_of[t] = be.fetch_seq(ref, sp[1], s_ - f, int(e0[t]) + f)
-        except Exception:                    # noqa: BLE001 - the loop below reads the window again and meets the same error where the drivers would
-            pass
-    if ahead is not None:
-        # the reads were asked of the extraction service when the run began: the windows first, then whatever is left to wait
-        read_windows()
-        kf, addr, q0, miss, status, keepalive = ahead.future.result(timeout=900)
-        held.extend(keepalive)
-        on_device = True
-        _mark("windows+wait for reads")
-    elif hasattr(be, "chop_many_device") and hasattr(engine, "bam_chop_device"):
+    if hasattr(be, "chop_many_device") and hasattr(engine, "bam_chop_device"):
         # The extraction is a native call that waits for the device (it releases the interpreter lock): on a helper thread, while
         # this one reads the loci's reference windows - the text work of the loop below that does not need to know the reads.
         # (The context is still used by one thread at a time: this one does not touch the engine until the helper is back.)
@@ -179,7 +117,16 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held, ahead=None) -> List[ob
         th = threading.Thread(target=extract)
         th.start()
         try:
-            read_windows()
+            for t in idx.tolist():
+                sp = specs[t]
+                f, s_ = int(flank[t]), int(s0[t])
+                if int(kind[t]) == 3:
+                    m = len(sp[4])
+                    refw_of[t] = be.fetch_seq(ref, sp[1], s_ - f, s_ + f + m if m < 5000 else s_ + f)
+                else:
+                    refw_of[t] = be.fetch_seq(ref, sp[1], s_ - f, int(e0[t]) + f)
+        except Exception:                    # noqa: BLE001 - the loop below reads the window again and meets the same error where the drivers would
+            pass
         finally:
             th.join()
         _mark("extract+windows")
@@ -324,13 +271,8 @@ def _run(engine, specs, bam_in, ref, num_reads_cff, held, ahead=None) -> List[ob
     if on_device:
         ss = engine.seqset_raw(all_addr, all_len, (np.asarray(seg_first, dtype=np.int32), segs_a, np.asarray(dflags, dtype=np.uint8)),
                                keepalive=(keep, keepalive), src_kind=src_kind, src_first=src_first)
-        if ahead is None:
-            for bt in keepalive:                          # (the planes are made: the inflated blocks can go)
-                bt.close()
-        else:
-            seqio.get_backend().extract_done(keepalive)   # (... through the thread that extracted them, which then begins the next chunk)
-            held.clear()
-            ahead.future = None
+        for bt in keepalive:                              # (the planes are made: the inflated blocks can go)
+            bt.close()
     else:
         ss = engine.seqset_raw(all_addr, all_len, (np.asarray(seg_first, dtype=np.int32), segs_a, np.asarray(dflags, dtype=np.uint8)),
                                keepalive=(keep, keepalive))

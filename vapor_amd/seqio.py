@@ -106,78 +106,6 @@ class SamtoolsHybrid(SamtoolsCLI):
         return fa.lines(region)
 
 
-class _ExtractService:
-    """The read extraction of the chunks of a run AHEAD of their scoring: one thread with a library context of its own runs
-    vapor_bam_chop_device jobs in the order they were asked for, at most `ahead` extracted chunks alive at a time (their inflated
-    blocks stay on the device until the chunk's sequence set is made).  The scoring threads then find their reads extracted:
-    with the extraction inside each scoring thread the chunks that start together extract together and queue for the
-    interpreter together, and the two phases add up instead of overlapping (profiles/r05_bamdev.txt).  A batch is closed on this
-    thread too (a context is used by one thread)."""
-
-    def __init__(self):
-        import queue
-        self.q = queue.Queue()
-        self.thread = None
-        self.lock = threading.Lock()
-        self.ahead = max(1, int(os.environ.get("VAPOR_BAM_AHEAD", "3")))
-
-    def _start(self):
-        with self.lock:
-            if self.thread is None or not self.thread.is_alive():
-                self.thread = threading.Thread(target=self._loop, name="vapor-extract", daemon=True)
-                self.thread.start()
-
-    def _loop(self):
-        from collections import deque
-        from . import _lib as _lib_mod
-        from .dist import _device_ordinal
-        from .engine import Engine
-        engine, engine_lib = None, None
-        pending = deque()
-        alive = 0
-        while True:
-            item = self.q.get()
-            if item is None:
-                break
-            if item[0] == "close":
-                for bt in item[1]:
-                    try:
-                        bt.close()
-                    except Exception:       # noqa: BLE001
-                        pass
-                alive -= 1
-            else:
-                pending.append(item)
-            while pending and alive < self.ahead:
-                _kind, fut, fn = pending.popleft()
-                if not fut.set_running_or_notify_cancel():
-                    continue
-                try:
-                    lib_now = id(_lib_mod.load())
-                    if engine is None or engine_lib != lib_now:      # (tests bind another build of the library: a context belongs to one)
-                        engine, engine_lib = Engine(_device_ordinal()), lib_now
-                    fut.set_result(fn(engine))
-                    alive += 1
-                except BaseException as e:      # noqa: BLE001 - handed to whoever waits for the chunk
-                    fut.set_exception(e)
-
-    def submit(self, fn):
-        """fn(engine) on the service's thread; its result's batches are given back through done()."""
-        from concurrent.futures import Future
-        self._start()
-        fut = Future()
-        self.q.put(("job", fut, fn))
-        return fut
-
-    def done(self, batches):
-        """The chunk a job extracted has its sequence set: its batches are closed (on the service's thread) and the next
-        extraction may begin."""
-        self.q.put(("close", list(batches)))
-
-
-_extract_service = _ExtractService()
-
-
 class InProcessBam(SamtoolsHybrid):
     """BAM and BAI read in-process as well (vapor_amd.bamio): no process per locus at all, and the records reach
     the trimming code as fields, not as text to be split again.  The default backend."""
@@ -349,30 +277,6 @@ class InProcessBam(SamtoolsHybrid):
             g += m
         cat = lambda k, dt: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, dtype=dt)    # noqa: E731
         return kf, cat(1, np.uint64), cat(2, np.int64), cat(3, np.int64), cat(4, np.int32), batches
-
-    def extract_ahead(self, bam: str, chroms, starts, ends, flanks, max_keep: int = 20, cu_share: int = 0):
-        """chop_many_device asked of the extraction service (its own thread and context): returns at once with a future of
-        chop_many_device's tuple; whoever takes the result hands its batches to `extract_done` when the sequence set is made."""
-        import numpy as np
-        if _env_is(b"VAPOR_BAM_NATIVE", b"0") or _env_is(b"VAPOR_BAM_DEVICE", b"0") or _env_is(b"VAPOR_BAM_AHEAD", b"0"):
-            raise NotImplementedError("no extraction ahead")
-        from . import _lib
-        if not hasattr(_lib.load(), "vapor_bam_chop_device"):
-            raise NotImplementedError("no device reader")
-        chroms = list(chroms)
-        st, en, fl = (np.array(x, dtype=np.int64) for x in (starts, ends, flanks))
-
-        def job(engine):
-            try:
-                engine.set_param("bam_cu_share", int(cu_share))
-            except Exception:       # noqa: BLE001
-                pass
-            return self.chop_many_device(engine, bam, chroms, st, en, fl, max_keep)
-        return _extract_service.submit(job)
-
-    @staticmethod
-    def extract_done(batches) -> None:
-        _extract_service.done(batches)
 
     def isfile(self, path: str) -> bool:
         # (bam_in_decide, SF:69-89, asks once per locus: a file this reader holds open is a file - no stat, and no release of
