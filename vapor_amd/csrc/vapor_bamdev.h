@@ -1,7 +1,7 @@
 // vapor_bamdev.h - the read extraction of a batch of loci ON the device: `samtools view bam chrom:start-end`
 // piped into chop_pacbio_read_by_pos (SF:339-354), which the reference runs as a process per locus and vapor_bam.cpp runs on
 // host threads, for hundreds of regions at once.  The host reads the regions' BGZF blocks as they lie in the file and sends
-// them over the link COMPRESSED (a fifth of their inflated size); three kernels do the rest:
+// them over the link COMPRESSED (a third to a fifth of their inflated size); three kernels do the rest:
 //
 //   bgzf_inflate_kernel   one wavefront per BGZF block: DEFLATE (RFC 1951) decoded by lane 0 out of an LDS copy of the
 //                         input straight into the block's place in the arena (HBM), the matches of a batch copied by all 64
