@@ -279,3 +279,38 @@ def test_extraction_on_a_stream_masked_to_a_share_of_the_cus(eng, tmp_path):
                 eng.set_param("bam_cu_share", bad)
     finally:
         eng.set_param("bam_cu_share", 0)
+
+
+def test_three_threads_extract_at_once_each_on_its_context(tmp_path):
+    """What cli.py does with three chunks in flight: three threads, a context each, vapor_bam_chop_device of different region sets
+    of one file at the same time (one of them on a masked stream) - every thread's kept reads are the host reader's."""
+    import threading
+    w = synth.make_world(seed=66, n_loci=45, svtypes=("DEL", "INS", "INV"), span_range=(100, 2000), read_len=6000, n_reads=22)
+    for c in w.reads:
+        w.reads[c] = sorted(w.reads[c], key=lambda r: r.pos)
+    fa, bam = synth.write_world_files(w, str(tmp_path), block_size=0xFF00)
+    regions = [(l.chrom, max(l.start - 300, 1), l.start + 800, 300) for l in w.loci]
+    shares = [regions[k::3] for k in range(3)]
+    out, errs = [None] * 3, []
+
+    def work(k):
+        try:
+            e = Engine(0)
+            try:
+                if k == 1:
+                    e.set_param("bam_cu_share", 5)
+                for _ in range(3):
+                    out[k] = compare(e, bam, shares[k])
+            finally:
+                e.close()
+        except BaseException as ex:       # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    for k in range(3):
+        status, n = out[k]
+        assert status.tolist() == [0] * len(shares[k]) and n > 150
