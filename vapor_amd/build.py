@@ -18,7 +18,10 @@ DEPS = SOURCES + [os.path.join(HERE, "csrc", "vapor_kernels.h"), os.path.join(HE
 
 # The kernels issue their wave-level atomics from one lane already (`if (lane == 0) atomicAdd(...)`); LLVM's atomic
 # optimizer wraps each of them in another mbcnt / compare / exec-mask sequence.  Off: clean_kernel 0.0837 -> 0.0826 ms.
-EXTRA_FLAGS = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+# The kernels are vector-issue-bound with their occupancy set by LDS, not by registers: the scheduler strategy that orders for
+# instruction-level parallelism instead of for the fewest registers takes a cfg2 pass from 0.1258 to 0.1246 ms (two plans in
+# flight; cfg3 the same within 0.2 %, checksums equal; profiles/r05_sched_strategy.txt).
+EXTRA_FLAGS = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def hipcc() -> str:
